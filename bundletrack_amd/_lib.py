@@ -1,0 +1,157 @@
+"""ctypes binding of libbtba.so (the C ABI of include/btba.h).
+
+The HIP library is the product; this module only loads it.  It fails loudly when the
+library is missing -- there is no CPU fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libbtba.so")
+SRC_DIR = os.path.join(_PKG, "csrc")
+HEADER = os.path.join(_ROOT, "include", "btba.h")
+
+BTBA_OK, BTBA_EINVAL, BTBA_EHIP, BTBA_ENUMERIC, BTBA_ENOMEM = 0, 1, 2, 3, 4
+PAIRS_TARGET_LOWER, PAIRS_TARGET_MORE_VALID, PAIRS_EXPLICIT = 0, 1, 2
+FLAG_TRACE, FLAG_TIME_KERNELS, FLAG_NO_GRAPH = 1, 2, 4
+
+ENTRYJ_DTYPE = np.dtype(
+    [("imgIdx_i", "<u4"), ("imgIdx_j", "<u4"), ("pos_i", "<f4", (3,)), ("pos_j", "<f4", (3,))]
+)
+
+EXPORTED_SYMBOLS = [
+    "btba_params_default", "btba_strerror", "btba_last_hip_error", "btba_version",
+    "btba_workspace_create", "btba_workspace_destroy", "btba_workspace_sync",
+    "btba_optimize_frames", "btba_build_cache", "btba_solve_batch", "btba_collect_stats",
+    "btba_trace_layout_get", "btba_bucket_correspondences",
+    "btba_matrices_to_poses", "btba_poses_to_matrices",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("n_gn_iters", C.c_int32), ("n_pcg_iters", C.c_int32),
+        ("robust_delta", C.c_float), ("dense_dist_thresh", C.c_float), ("dense_normal_thresh", C.c_float),
+        ("depth_min", C.c_float), ("depth_max", C.c_float),
+        ("weight_sparse", C.c_float), ("weight_dense_depth", C.c_float), ("image_downscale", C.c_float),
+        ("pair_policy", C.c_int32), ("dense_tiles", C.c_int32), ("sparse_chunks", C.c_int32), ("flags", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_instances", C.c_int32), ("n_frames", C.c_int32), ("n_pairs", C.c_int32), ("n_dense_pairs", C.c_int32),
+        ("n_corr", C.c_int64),
+        ("dense_tiles", C.c_int32), ("sparse_chunks", C.c_int32),
+        ("ms_total", C.c_float), ("ms_upload", C.c_float), ("ms_cache", C.c_float), ("ms_solve", C.c_float),
+        ("ms_dense_sweep", C.c_float), ("ms_sparse_sweep", C.c_float), ("ms_system_solve", C.c_float),
+        ("n_dense_launches", C.c_int32), ("n_sparse_launches", C.c_int32), ("n_solve_launches", C.c_int32),
+        ("bytes_dense_alg", C.c_int64), ("bytes_sparse_alg", C.c_int64),
+    ]
+
+    def as_dict(self):
+        return {f[0]: getattr(self, f[0]) for f in self._fields_}
+
+
+class TraceLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in
+                ("record_floats", "off_x", "off_T", "off_rhs", "off_precond", "off_pcg", "off_delta", "off_dense_pair", "off_A")]
+
+
+class BtbaError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        msg = lib().btba_strerror(status).decode() if _lib is not None else str(status)
+        extra = f" (hipError {lib().btba_last_hip_error()})" if status == BTBA_EHIP else ""
+        super().__init__(f"{where}: {msg}{extra}")
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR)] + [HEADER]
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-o", LIB_PATH, os.path.join(SRC_DIR, "btba_api.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libbtba.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.btba_strerror.restype = C.c_char_p
+        L.btba_strerror.argtypes = [C.c_int]
+        for name in EXPORTED_SYMBOLS:
+            getattr(L, name)           # AttributeError if the ABI and the header drift apart
+        L.btba_workspace_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p]
+        L.btba_workspace_destroy.argtypes = [C.c_void_p]
+        L.btba_workspace_destroy.restype = None
+        L.btba_workspace_sync.argtypes = [C.c_void_p]
+        L.btba_collect_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.btba_optimize_frames.argtypes = [
+            C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_void_p,
+            C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Stats)]
+        L.btba_build_cache.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.btba_solve_batch.argtypes = [
+            C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.btba_trace_layout_get.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(TraceLayout)]
+        L.btba_trace_layout_get.restype = None
+        L.btba_bucket_correspondences.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        L.btba_matrices_to_poses.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.btba_poses_to_matrices.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(status: int, where: str) -> None:
+    if status != BTBA_OK:
+        raise BtbaError(status, where)
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().btba_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def declared_symbols() -> list[str]:
+    """Function names declared in include/btba.h (used by the ABI test)."""
+    import re
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"\b(btba_[a-z_0-9]+)\s*\(", txt)))
+
+
+def bucket_correspondences(corr: np.ndarray, n_frames: int):
+    """Host helper: stable bucketing of EntryJ by canonical frame pair -> (sorted, offsets[P+1])."""
+    corr = np.ascontiguousarray(corr, ENTRYJ_DTYPE)
+    P = n_frames * (n_frames - 1) // 2
+    out = np.zeros(max(corr.shape[0], 1), ENTRYJ_DTYPE)
+    off = np.zeros(P + 1, np.uint32)
+    check(lib().btba_bucket_correspondences(corr.ctypes.data, corr.shape[0], n_frames, out.ctypes.data, off.ctypes.data),
+          "btba_bucket_correspondences")
+    return out[: int(off[P])], off

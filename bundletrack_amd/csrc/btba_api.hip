@@ -1,0 +1,553 @@
+// btba_api.hip -- host side of libbtba.so: the C ABI declared in include/btba.h.
+//
+// Mirrors, call for call, what the reference does between Bundler::optimizeGPU and the kernels
+// (LossGPU.cu:53-139 -> CUDACache.cpp:76-88 -> SBA.cpp:81-126 -> CUDASolverBundling.cpp:190-280 ->
+// SolverBundling.cu:931-1003), re-designed for MI355X: no per-call allocation storm (grow-only
+// workspace), no per-iteration host sync (the dense pair list is static), three launches per
+// Gauss-Newton iteration, batches of independent instances in one grid.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/btba.h"
+#include "btba_kernels.hpp"
+
+using namespace btba;
+
+static thread_local int g_last_hip_error = 0;
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) {                         \
+            g_last_hip_error = (int)e_;                 \
+            return BTBA_EHIP;                           \
+        }                                               \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return BTBA_OK;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) { g_last_hip_error = (int)e; return BTBA_EHIP; } }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; p = nullptr; return e == hipErrorOutOfMemory ? BTBA_ENOMEM : BTBA_EHIP; }
+        cap = want;
+        return BTBA_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct EventPair { hipEvent_t a, b; int kind; };   // kind 0 dense, 1 sparse, 2 system, 3 solve region, 4 cache
+
+}  // namespace
+
+struct btba_workspace {
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int device = 0;
+    DevBuf x, T, Tinv, sparse_part, dense_part, pairsum, dense_pairs, ptrs;
+    DevBuf corr, offsets, poses, campos, normals, nvalid;   // optimize_frames staging
+    std::vector<int32_t> dense_pairs_host;                  // what dense_pairs currently holds
+    std::vector<EventPair> events;                          // pending timed regions
+    std::vector<hipEvent_t> event_pool;
+    btba_stats stats{};
+    bool lds_attr_set = false;
+
+    hipEvent_t get_event()
+    {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+
+extern "C" {
+
+void btba_params_default(btba_params *p)
+{
+    if (!p) return;
+    p->n_gn_iters = 7;
+    p->n_pcg_iters = 5;
+    p->robust_delta = 0.005f;
+    p->dense_dist_thresh = 0.02f;
+    p->dense_normal_thresh = (float)std::cos(45.0 / 180.0 * M_PI);
+    p->depth_min = 0.1f;
+    p->depth_max = 9999.0f;
+    p->weight_sparse = 1.0f;
+    p->weight_dense_depth = 1.0f;
+    p->image_downscale = 4.0f;
+    p->pair_policy = BTBA_PAIRS_TARGET_LOWER;
+    p->dense_tiles = 0;
+    p->sparse_chunks = 0;
+    p->flags = 0;
+}
+
+const char *btba_strerror(int status)
+{
+    switch (status) {
+    case BTBA_OK: return "ok";
+    case BTBA_EINVAL: return "invalid argument";
+    case BTBA_EHIP: return "HIP runtime error (see btba_last_hip_error)";
+    case BTBA_ENUMERIC: return "non-finite value in the output poses";
+    case BTBA_ENOMEM: return "out of device memory";
+    default: return "unknown status";
+    }
+}
+
+int btba_last_hip_error(void) { return g_last_hip_error; }
+int btba_version(void) { return BTBA_VERSION; }
+
+int btba_workspace_create(btba_workspace **out, void *stream)
+{
+    if (!out) return BTBA_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { g_last_hip_error = (int)hipErrorNoDevice; return BTBA_EHIP; }
+    btba_workspace *ws = new (std::nothrow) btba_workspace();
+    if (!ws) return BTBA_ENOMEM;
+    if (hipGetDevice(&ws->device) != hipSuccess) { delete ws; return BTBA_EHIP; }
+    if (stream) {
+        ws->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; delete ws; return BTBA_EHIP; }
+        ws->owns_stream = true;
+    }
+    *out = ws;
+    return BTBA_OK;
+}
+
+void btba_workspace_destroy(btba_workspace *ws)
+{
+    if (!ws) return;
+    (void)hipStreamSynchronize(ws->stream);
+    for (auto &ep : ws->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    for (auto e : ws->event_pool) (void)hipEventDestroy(e);
+    DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs,
+                       &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid };
+    for (auto b : bufs) b->release();
+    if (ws->owns_stream) (void)hipStreamDestroy(ws->stream);
+    delete ws;
+}
+
+int btba_workspace_sync(btba_workspace *ws)
+{
+    if (!ws) return BTBA_EINVAL;
+    HIP_TRY(hipStreamSynchronize(ws->stream));
+    return BTBA_OK;
+}
+
+void btba_trace_layout_get(int n_frames, int n_dense_pairs, int n_pcg_iters, btba_trace_layout *L)
+{
+    if (!L) return;
+    const int64_t N = n_frames, n = 6 * N;
+    int64_t o = 0;
+    L->off_x = o; o += N * 6;
+    L->off_T = o; o += N * 16;
+    L->off_rhs = o; o += N * 6;
+    L->off_precond = o; o += N * 6;
+    L->off_pcg = o; o += (int64_t)n_pcg_iters * 4;
+    L->off_delta = o; o += N * 6;
+    L->off_dense_pair = o; o += (int64_t)n_dense_pairs * kDenseVals;
+    L->off_A = o; o += n * n;
+    L->record_floats = o;
+}
+
+int btba_bucket_correspondences(const btba_entryj *in, uint32_t n, int n_frames, btba_entryj *out_sorted, uint32_t *out_offsets)
+{
+    if ((!in && n) || n_frames < 2 || !out_sorted || !out_offsets) return BTBA_EINVAL;
+    const int P = n_frames * (n_frames - 1) / 2;
+    std::vector<uint32_t> cnt(P + 1, 0);
+    auto pidx = [n_frames](uint32_t i, uint32_t j) { return (int)(i * n_frames - i * (i + 1) / 2 + (j - i - 1)); };
+    for (uint32_t e = 0; e < n; e++) {
+        const btba_entryj &c = in[e];
+        if (c.imgIdx_i == 0xFFFFFFFFu) continue;
+        if (c.imgIdx_i >= (uint32_t)n_frames || c.imgIdx_j >= (uint32_t)n_frames || c.imgIdx_i >= c.imgIdx_j) return BTBA_EINVAL;
+        cnt[pidx(c.imgIdx_i, c.imgIdx_j) + 1]++;
+    }
+    out_offsets[0] = 0;
+    for (int p = 0; p < P; p++) out_offsets[p + 1] = out_offsets[p] + cnt[p + 1];
+    std::vector<uint32_t> cur(out_offsets, out_offsets + P);
+    for (uint32_t e = 0; e < n; e++) {                       // stable: keeps the caller's order inside a pair
+        const btba_entryj &c = in[e];
+        if (c.imgIdx_i == 0xFFFFFFFFu) continue;
+        out_sorted[cur[pidx(c.imgIdx_i, c.imgIdx_j)]++] = c;
+    }
+    return BTBA_OK;
+}
+
+}  // extern "C"
+
+// ---- internal: enqueue one batched solve on ws->stream ------------------------------------------
+static int time_begin(btba_workspace *ws, bool on, int kind, size_t *slot)
+{
+    *slot = (size_t)-1;
+    if (!on) return BTBA_OK;
+    EventPair ep{ ws->get_event(), ws->get_event(), kind };
+    if (!ep.a || !ep.b) return BTBA_EHIP;
+    HIP_TRY(hipEventRecord(ep.a, ws->stream));
+    ws->events.push_back(ep);
+    *slot = ws->events.size() - 1;
+    return BTBA_OK;
+}
+static int time_end(btba_workspace *ws, size_t slot)
+{
+    if (slot == (size_t)-1) return BTBA_OK;
+    HIP_TRY(hipEventRecord(ws->events[slot].b, ws->stream));
+    return BTBA_OK;
+}
+
+static int pick_chunks(const btba_params *prm, int B, int P, uint32_t max_corr_per_pair)
+{
+    if (prm->sparse_chunks > 0) return prm->sparse_chunks;
+    if (max_corr_per_pair == 0) return 1;
+    const long blocks = (long)B * P;
+    int want = (int)((1024 + blocks - 1) / blocks);
+    const int cap = (int)((max_corr_per_pair + kBlock - 1) / kBlock);
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    if (want > 16) want = 16;
+    return want;
+}
+static int pick_tiles(const btba_params *prm, int B, int Pd, int npix)
+{
+    if (prm->dense_tiles > 0) return prm->dense_tiles;
+    if (Pd == 0) return 1;
+    const long blocks = (long)B * Pd;
+    int want = (int)((4096 + blocks - 1) / blocks);
+    const int cap = (npix + kBlock - 1) / kBlock;
+    if (want > cap) want = cap;
+    if (want < 2) want = 2;
+    if (want > 25) want = 25;
+    return want;
+}
+
+static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int N, int Hd, int Wd, const float *intr,
+                         const float *campos, const float *normals, const btba_entryj *corr, int64_t corr_stride,
+                         const uint32_t *pair_offsets, uint32_t max_corr_per_pair,
+                         const int32_t *dense_pairs, int Pd_in, float *poses, float *trace)
+{
+    if (!ws || !prm || B < 1 || N < 2 || Hd < 2 || Wd < 2 || !intr || !poses) return BTBA_EINVAL;
+    if (prm->n_gn_iters < 1 || prm->n_pcg_iters < 0) return BTBA_EINVAL;   // MLIB_ASSERT, CUDASolverBundling.cpp:194
+    if (N > 40) return BTBA_EINVAL;                                         // 6N x 6N system must fit one CU's LDS
+    const int P = N * (N - 1) / 2;
+    const bool use_sparse = prm->weight_sparse > 0.0f && corr && pair_offsets && max_corr_per_pair > 0;
+    // dense pair list
+    std::vector<int32_t> pairs;
+    if (prm->weight_dense_depth > 0.0f) {
+        if (dense_pairs && Pd_in >= 0) pairs.assign(dense_pairs, dense_pairs + 2 * (size_t)Pd_in);
+        else for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) { pairs.push_back(i); pairs.push_back(j); }
+        for (size_t k = 0; k < pairs.size(); k += 2)
+            if (pairs[k] < 0 || pairs[k] >= N || pairs[k + 1] < 0 || pairs[k + 1] >= N || pairs[k] == pairs[k + 1]) return BTBA_EINVAL;
+    }
+    const int Pd = (int)(pairs.size() / 2);
+    const bool use_dense = Pd > 0 && campos && normals;      // Pd == 0: "no overlapping images", SolverBundling.cu:280-283
+    if (!use_sparse && !use_dense) {
+        // nothing to optimise: poses still go through Log/Exp like the reference (SBA.cpp:106,115)
+    }
+    const int npix = Hd * Wd;
+    const int chunks = use_sparse ? pick_chunks(prm, B, P, max_corr_per_pair) : 1;
+    const int tiles = use_dense ? pick_tiles(prm, B, Pd, npix) : 1;
+    const bool timing = (prm->flags & BTBA_FLAG_TIME_KERNELS) != 0;
+
+    int rc;
+    if ((rc = ws->x.ensure(sizeof(float) * 6 * (size_t)B * N))) return rc;
+    if ((rc = ws->T.ensure(sizeof(float) * 16 * (size_t)B * N))) return rc;
+    if ((rc = ws->Tinv.ensure(sizeof(float) * 16 * (size_t)B * N))) return rc;
+    if ((rc = ws->sparse_part.ensure(sizeof(float) * (size_t)B * P * chunks * kSparseVals))) return rc;
+    if ((rc = ws->dense_part.ensure(sizeof(float) * (size_t)B * (Pd > 0 ? Pd : 1) * tiles * kDenseVals))) return rc;
+    if (Pd > 0 && pairs != ws->dense_pairs_host) {
+        if ((rc = ws->dense_pairs.ensure(sizeof(int32_t) * pairs.size()))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws->dense_pairs.p, pairs.data(), sizeof(int32_t) * pairs.size(), hipMemcpyHostToDevice, ws->stream));
+        HIP_TRY(hipStreamSynchronize(ws->stream));         // `pairs` is a local; copy must land before it dies
+        ws->dense_pairs_host = pairs;
+    }
+
+    SolveDims D{};
+    D.n_frames = N; D.n_pairs = P; D.n_dense_pairs = use_dense ? Pd : 0;
+    D.npix = npix; D.width = Wd; D.height = Hd;
+    D.sparse_chunks = chunks; D.dense_tiles = tiles; D.n_pcg = prm->n_pcg_iters;
+    D.use_sparse = use_sparse; D.use_dense = use_dense;
+    D.fx = intr[0]; D.fy = intr[1]; D.cx = intr[2]; D.cy = intr[3];
+    D.robust_delta = prm->robust_delta; D.dist_thresh = prm->dense_dist_thresh; D.normal_thresh = prm->dense_normal_thresh;
+    D.depth_min = prm->depth_min; D.depth_max = prm->depth_max;
+    D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
+    D.corr_stride = corr_stride;
+    D.n_gn = prm->n_gn_iters;
+    D.trace_on = (trace != nullptr) && (prm->flags & BTBA_FLAG_TRACE);
+    btba_trace_layout L;
+    btba_trace_layout_get(N, D.n_dense_pairs, prm->n_pcg_iters, &L);
+    D.trace_record = L.record_floats; D.tr_x = L.off_x; D.tr_T = L.off_T; D.tr_rhs = L.off_rhs; D.tr_prec = L.off_precond;
+    D.tr_pcg = L.off_pcg; D.tr_delta = L.off_delta; D.tr_dpair = L.off_dense_pair; D.tr_A = L.off_A;
+
+    const size_t n = 6 * (size_t)N, ld = n | 1;
+    const size_t lds_core = (n * ld + 6 * n + 16) * sizeof(float);
+    const size_t lds_pairs = ((size_t)P * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals) * sizeof(float);
+    const size_t lds_limit = 160 * 1024;
+    D.pairsum_in_lds = (lds_core + lds_pairs <= 64 * 1024) ? 1 : 0;   // keep two workgroups per CU when it fits
+    if (!D.pairsum_in_lds && lds_core + lds_pairs <= lds_limit && B <= 256) D.pairsum_in_lds = 1;
+    const size_t lds_bytes = lds_core + (D.pairsum_in_lds ? lds_pairs : 0);
+    if (lds_bytes > lds_limit) return BTBA_EINVAL;
+    if (!D.pairsum_in_lds) { if ((rc = ws->pairsum.ensure((size_t)B * lds_pairs + 16))) return rc; }
+    if (lds_bytes > 64 * 1024 || !ws->lds_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        ws->lds_attr_set = true;
+    }
+
+    // stats bookkeeping (collected after sync)
+    btba_stats &S = ws->stats;
+    std::memset(&S, 0, sizeof S);
+    S.n_instances = B; S.n_frames = N; S.n_pairs = P; S.n_dense_pairs = D.n_dense_pairs;
+    S.dense_tiles = tiles; S.sparse_chunks = chunks;
+    S.bytes_dense_alg = use_dense ? (int64_t)64 * D.n_dense_pairs * npix * B : 0;
+    S.bytes_sparse_alg = 0;   // filled by callers that know C (optimize_frames) or from offsets on request
+
+    size_t reg;
+    if ((rc = time_begin(ws, true, 3, &reg))) return rc;
+    // Log, Exp, inverse of the incoming matrices
+    {
+        const int total = B * N;
+        k_prepare<<<(total + 63) / 64, 64, 0, ws->stream>>>(total, poses, ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>());
+    }
+    for (int it = 0; it < prm->n_gn_iters; it++) {
+        size_t slot;
+        if (use_sparse) {
+            if ((rc = time_begin(ws, timing, 1, &slot))) return rc;
+            k_sparse_sweep<<<dim3(chunks, P, B), kBlock, 0, ws->stream>>>(D, reinterpret_cast<const float4 *>(corr), pair_offsets, ws->T.as<float>(), ws->sparse_part.as<float>());
+            if ((rc = time_end(ws, slot))) return rc;
+        }
+        if (use_dense) {
+            if ((rc = time_begin(ws, timing, 0, &slot))) return rc;
+            k_dense_sweep<<<dim3(tiles, D.n_dense_pairs, B), kBlock, 0, ws->stream>>>(D, reinterpret_cast<const float4 *>(campos), reinterpret_cast<const float4 *>(normals),
+                                                                                     ws->dense_pairs.as<int2>(), ws->T.as<float>(), ws->Tinv.as<float>(), ws->dense_part.as<float>());
+            if ((rc = time_end(ws, slot))) return rc;
+        }
+        if ((rc = time_begin(ws, timing, 2, &slot))) return rc;
+        k_system_solve<<<B, kBlock, lds_bytes, ws->stream>>>(D, it, ws->sparse_part.as<float>(), ws->dense_part.as<float>(), ws->dense_pairs.as<int2>(),
+                                                             ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>(), ws->pairsum.as<float>(), trace);
+        if ((rc = time_end(ws, slot))) return rc;
+    }
+    // convertPosesToMatricesCU: T already holds Exp(x) of the final iterate
+    HIP_TRY(hipMemcpyAsync(poses, ws->T.p, sizeof(float) * 16 * (size_t)B * N, hipMemcpyDeviceToDevice, ws->stream));
+    if ((rc = time_end(ws, reg))) return rc;
+    HIP_TRY(hipGetLastError());
+    return BTBA_OK;
+}
+
+extern "C" {
+
+int btba_collect_stats(btba_workspace *ws, btba_stats *stats)
+{
+    if (!ws) return BTBA_EINVAL;
+    HIP_TRY(hipStreamSynchronize(ws->stream));
+    btba_stats &S = ws->stats;
+    for (auto &ep : ws->events) {
+        float ms = 0.0f;
+        hipError_t e = hipEventElapsedTime(&ms, ep.a, ep.b);
+        if (e == hipSuccess) {
+            switch (ep.kind) {
+            case 0: S.ms_dense_sweep += ms; S.n_dense_launches++; break;
+            case 1: S.ms_sparse_sweep += ms; S.n_sparse_launches++; break;
+            case 2: S.ms_system_solve += ms; S.n_solve_launches++; break;
+            case 3: S.ms_solve += ms; break;
+            case 4: S.ms_cache += ms; break;
+            default: break;
+            }
+        }
+        ws->event_pool.push_back(ep.a);
+        ws->event_pool.push_back(ep.b);
+    }
+    ws->events.clear();
+    if (stats) *stats = S;
+    return BTBA_OK;
+}
+
+int btba_solve_batch(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames, int Hd, int Wd, const float *intr,
+                     const float *campos_dev, const float *normals_dev, const btba_entryj *corr_dev, int64_t corr_stride,
+                     const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
+                     float *poses_dev, float *trace_dev)
+{
+    if (!ws) return BTBA_EINVAL;
+    // drop stale timing events of a previous un-collected call
+    for (auto &ep : ws->events) { ws->event_pool.push_back(ep.a); ws->event_pool.push_back(ep.b); }
+    ws->events.clear();
+    return solve_enqueue(ws, params, n_instances, n_frames, Hd, Wd, intr, campos_dev, normals_dev, corr_dev, corr_stride,
+                         pair_offsets_dev, max_corr_per_pair, dense_pairs, dense_pairs ? n_dense_pairs : -1, poses_dev, trace_dev);
+}
+
+static void scaled_intrinsics(int H, int W, int Hd, int Wd, const float *K, float intr[4], Mat4 *Kinv)
+{
+    // CUDACache.cpp:20-24
+    intr[0] = K[0] * ((float)Wd / (float)W);
+    intr[1] = K[4] * ((float)Hd / (float)H);
+    intr[2] = K[2] * ((float)(Wd - 1) / (float)(W - 1));
+    intr[3] = K[5] * ((float)(Hd - 1) / (float)(H - 1));
+    // m_inputIntrinsicsInv (CUDACache.cpp:33): generic cofactor inverse of the 4x4 embedding of K, in fp32
+    const float m[16] = { K[0], K[1], K[2], 0, K[3], K[4], K[5], 0, K[6], K[7], K[8], 0, 0, 0, 0, 1 };
+    auto minor = [&](int r0, int r1, int r2, int c0, int c1, int c2) {
+        return m[4 * r0 + c0] * (m[4 * r1 + c1] * m[4 * r2 + c2] - m[4 * r1 + c2] * m[4 * r2 + c1])
+             - m[4 * r0 + c1] * (m[4 * r1 + c0] * m[4 * r2 + c2] - m[4 * r1 + c2] * m[4 * r2 + c0])
+             + m[4 * r0 + c2] * (m[4 * r1 + c0] * m[4 * r2 + c1] - m[4 * r1 + c1] * m[4 * r2 + c0]);
+    };
+    float adj[16];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            int rr[3], cc[3], a = 0, b = 0;
+            for (int k = 0; k < 4; k++) { if (k != r) rr[a++] = k; if (k != c) cc[b++] = k; }
+            float mn = minor(rr[0], rr[1], rr[2], cc[0], cc[1], cc[2]);
+            adj[4 * c + r] = ((r + c) & 1) ? -mn : mn;
+        }
+    const float det = m[0] * adj[0] + m[1] * adj[4] + m[2] * adj[8] + m[3] * adj[12];
+    const float rdet = 1.0f / det;
+    for (int k = 0; k < 16; k++) Kinv->m[k] = adj[k] * rdet;
+}
+
+int btba_build_cache(btba_workspace *ws, int n_frames, int H, int W, const float *K, float image_downscale,
+                     const float *const *depth_dev, const float *const *normal_dev,
+                     float *campos_dev, float *normals_dev, int32_t *n_valid_dev, float *intr_out)
+{
+    if (!ws || n_frames < 1 || H < 2 || W < 2 || !K || !depth_dev || !normal_dev || !campos_dev || !normals_dev || !(image_downscale >= 1.0f)) return BTBA_EINVAL;
+    const int Wd = (int)(W / image_downscale), Hd = (int)(H / image_downscale);     // LossGPU.cu:56-57
+    if (Wd < 2 || Hd < 2) return BTBA_EINVAL;
+    float intr[4];
+    Mat4 Kinv;
+    scaled_intrinsics(H, W, Hd, Wd, K, intr, &Kinv);
+    if (intr_out) std::memcpy(intr_out, intr, sizeof intr);
+    int rc;
+    if ((rc = ws->ptrs.ensure(sizeof(void *) * 2 * (size_t)n_frames))) return rc;
+    std::vector<const float *> h(2 * (size_t)n_frames);
+    for (int k = 0; k < n_frames; k++) {
+        if (!depth_dev[k] || !normal_dev[k]) return BTBA_EINVAL;
+        h[k] = depth_dev[k]; h[n_frames + k] = normal_dev[k];
+    }
+    HIP_TRY(hipMemcpyAsync(ws->ptrs.p, h.data(), sizeof(void *) * h.size(), hipMemcpyHostToDevice, ws->stream));
+    HIP_TRY(hipStreamSynchronize(ws->stream));    // h is a local
+    if (n_valid_dev) HIP_TRY(hipMemsetAsync(n_valid_dev, 0, sizeof(int32_t) * n_frames, ws->stream));
+    const int npix = Wd * Hd;
+    size_t slot;
+    if ((rc = time_begin(ws, true, 4, &slot))) return rc;
+    k_build_cache<<<dim3((npix + kBlock - 1) / kBlock, n_frames), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, Kinv, ws->ptrs.as<const float *>(), ws->ptrs.as<const float *>() + n_frames,
+                                                                                         reinterpret_cast<float4 *>(campos_dev), reinterpret_cast<float4 *>(normals_dev), n_valid_dev);
+    if ((rc = time_end(ws, slot))) return rc;
+    HIP_TRY(hipGetLastError());
+    return BTBA_OK;
+}
+
+int btba_optimize_frames(btba_workspace *ws_in, const btba_params *params_in, int n_frames, int H, int W, const float *K,
+                         const btba_entryj *corres_host, uint32_t n_corres, const int *n_match_per_pair,
+                         const float *const *depth_dev, const float *const *normal_dev,
+                         const int32_t *dense_pairs, int n_dense_pairs, float *poses, btba_stats *stats)
+{
+    (void)n_match_per_pair;   // stored and never read by the reference either (SBA.cpp:85)
+    const auto t0 = std::chrono::steady_clock::now();
+    btba_params prm;
+    if (params_in) prm = *params_in; else btba_params_default(&prm);
+    if (n_frames < 2 || H < 2 || W < 2 || !K || !depth_dev || !normal_dev || !poses || (!corres_host && n_corres)) return BTBA_EINVAL;
+    if (prm.pair_policy == BTBA_PAIRS_EXPLICIT && (!dense_pairs || n_dense_pairs < 0)) return BTBA_EINVAL;
+    btba_workspace *ws = ws_in;
+    int rc = BTBA_OK;
+    if (!ws) { if ((rc = btba_workspace_create(&ws, nullptr))) return rc; }
+    auto finish = [&](int code) { if (!ws_in) btba_workspace_destroy(ws); return code; };
+    for (auto &ep : ws->events) { ws->event_pool.push_back(ep.a); ws->event_pool.push_back(ep.b); }
+    ws->events.clear();
+
+    const int N = n_frames, P = N * (N - 1) / 2;
+    const int Wd = (int)(W / prm.image_downscale), Hd = (int)(H / prm.image_downscale);
+    if (Wd < 2 || Hd < 2) return finish(BTBA_EINVAL);
+    const int npix = Wd * Hd;
+
+    // A0/A6: bucket by frame pair (a pair-major input, the only order Bundler::optimizeGPU produces, passes through)
+    std::vector<btba_entryj> sorted(n_corres ? n_corres : 1);
+    std::vector<uint32_t> offsets(P + 1, 0);
+    if ((rc = btba_bucket_correspondences(corres_host, n_corres, N, sorted.data(), offsets.data()))) return finish(rc);
+    const uint32_t kept = offsets[P];
+    uint32_t max_per_pair = 0;
+    for (int p = 0; p < P; p++) max_per_pair = std::max(max_per_pair, offsets[p + 1] - offsets[p]);
+
+    const auto tu0 = std::chrono::steady_clock::now();
+    if ((rc = ws->corr.ensure(sizeof(btba_entryj) * (size_t)(kept ? kept : 1)))) return finish(rc);
+    if ((rc = ws->offsets.ensure(sizeof(uint32_t) * (P + 1)))) return finish(rc);
+    if ((rc = ws->poses.ensure(sizeof(float) * 16 * (size_t)N))) return finish(rc);
+    if ((rc = ws->campos.ensure(sizeof(float) * 4 * (size_t)N * npix))) return finish(rc);
+    if ((rc = ws->normals.ensure(sizeof(float) * 4 * (size_t)N * npix))) return finish(rc);
+    if ((rc = ws->nvalid.ensure(sizeof(int32_t) * N))) return finish(rc);
+    auto hip_fail = [&](hipError_t e) { g_last_hip_error = (int)e; return finish(BTBA_EHIP); };
+    hipError_t e;
+    if (kept && (e = hipMemcpyAsync(ws->corr.p, sorted.data(), sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
+    if ((e = hipMemcpyAsync(ws->offsets.p, offsets.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
+    if ((e = hipMemcpyAsync(ws->poses.p, poses, sizeof(float) * 16 * N, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
+    if ((e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
+    const auto tu1 = std::chrono::steady_clock::now();
+
+    float intr[4];
+    if ((rc = btba_build_cache(ws, N, H, W, K, prm.image_downscale, depth_dev, normal_dev, ws->campos.as<float>(), ws->normals.as<float>(), ws->nvalid.as<int32_t>(), intr))) return finish(rc);
+
+    std::vector<int32_t> pairs;
+    const int32_t *pairs_ptr = nullptr;
+    int n_pairs_dense = -1;
+    if (prm.pair_policy == BTBA_PAIRS_EXPLICIT) {
+        pairs_ptr = dense_pairs; n_pairs_dense = n_dense_pairs;
+    } else if (prm.pair_policy == BTBA_PAIRS_TARGET_MORE_VALID) {
+        std::vector<int32_t> nv(N);
+        if ((e = hipMemcpyAsync(nv.data(), ws->nvalid.p, sizeof(int32_t) * N, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) return hip_fail(e);
+        if ((e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
+        for (int i = 0; i < N; i++)
+            for (int j = i + 1; j < N; j++) {
+                if (nv[i] >= nv[j]) { pairs.push_back(i); pairs.push_back(j); }   // ties: i<j (SolverBundling.cu:25-33)
+                else { pairs.push_back(j); pairs.push_back(i); }
+            }
+        pairs_ptr = pairs.data(); n_pairs_dense = (int)pairs.size() / 2;
+    } else if (prm.pair_policy != BTBA_PAIRS_TARGET_LOWER) {
+        return finish(BTBA_EINVAL);
+    }
+
+    // keep cache-build timing event, then enqueue the solve (solve_enqueue resets stats)
+    rc = solve_enqueue(ws, &prm, 1, N, Hd, Wd, intr, ws->campos.as<float>(), ws->normals.as<float>(), ws->corr.as<btba_entryj>(), (int64_t)(kept ? kept : 1),
+                       ws->offsets.as<uint32_t>(), max_per_pair, pairs_ptr, n_pairs_dense, ws->poses.as<float>(), nullptr);
+    if (rc) return finish(rc);
+    std::vector<float> out(16 * (size_t)N);
+    if ((e = hipMemcpyAsync(out.data(), ws->poses.p, sizeof(float) * 16 * N, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) return hip_fail(e);
+    btba_stats S;
+    if ((rc = btba_collect_stats(ws, &S))) return finish(rc);       // synchronises
+    for (float v : out) if (!std::isfinite(v)) return finish(BTBA_ENUMERIC);
+    std::memcpy(poses, out.data(), sizeof(float) * out.size());
+    if (stats) {
+        S.n_corr = kept;
+        S.bytes_sparse_alg = (int64_t)32 * kept;
+        S.ms_upload = std::chrono::duration<float, std::milli>(tu1 - tu0).count();
+        S.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        *stats = S;
+    }
+    return finish(BTBA_OK);
+}
+
+int btba_matrices_to_poses(btba_workspace *ws, int n, const float *T_dev, float *x_dev)
+{
+    if (!ws || n < 1 || !T_dev || !x_dev) return BTBA_EINVAL;
+    k_prepare<<<(n + 63) / 64, 64, 0, ws->stream>>>(n, T_dev, x_dev, nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    return BTBA_OK;
+}
+
+int btba_poses_to_matrices(btba_workspace *ws, int n, const float *x_dev, float *T_dev, float *Tinv_dev)
+{
+    if (!ws || n < 1 || !x_dev || (!T_dev && !Tinv_dev)) return BTBA_EINVAL;
+    k_poses_to_matrices<<<(n + 63) / 64, 64, 0, ws->stream>>>(n, x_dev, T_dev, Tinv_dev);
+    HIP_TRY(hipGetLastError());
+    return BTBA_OK;
+}
+
+}  // extern "C"

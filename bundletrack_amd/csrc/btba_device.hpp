@@ -1,0 +1,252 @@
+// btba_device.hpp -- device-side SE(3) math and wave64 reductions for gfx950.
+//
+// The SE(3) helpers restate (not copy) the branch structure and thresholds of the reference's
+//   src/cuda/Solver/LieDerivUtil.h:17-201 (exp_rotation, ln_rotation, matrixToPose, poseToMatrix,
+//   computeLieUpdate) and the generic cofactor inverse cuda_SimpleMatrixUtil.h:978-1104,
+// because the solver's iterates depend on exactly those thresholds (theta^2 < 1e-8 / 1e-6,
+// cos > 0.7071.., theta > 1e-5 / 1e-3).  Matrices are row-major float[16] in registers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace btba {
+
+struct Mat4 { float m[16]; };
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) { return ax * bx + ay * by + az * bz; }
+
+__device__ __forceinline__ Mat4 mat_mul(const Mat4 &a, const Mat4 &b)
+{
+    Mat4 o;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            o.m[4 * r + c] = a.m[4 * r] * b.m[c] + a.m[4 * r + 1] * b.m[4 + c] + a.m[4 * r + 2] * b.m[8 + c] + a.m[4 * r + 3] * b.m[12 + c];
+    return o;
+}
+
+// rigid transform of a point (w = 1), float4x4::operator*(float3)
+__device__ __forceinline__ void xform_point(const Mat4 &t, float x, float y, float z, float &ox, float &oy, float &oz)
+{
+    ox = t.m[0] * x + t.m[1] * y + t.m[2] * z + t.m[3];
+    oy = t.m[4] * x + t.m[5] * y + t.m[6] * z + t.m[7];
+    oz = t.m[8] * x + t.m[9] * y + t.m[10] * z + t.m[11];
+}
+
+__device__ __forceinline__ float minor3(const float *m, int r0, int r1, int r2, int c0, int c1, int c2)
+{
+    return m[4 * r0 + c0] * (m[4 * r1 + c1] * m[4 * r2 + c2] - m[4 * r1 + c2] * m[4 * r2 + c1])
+         - m[4 * r0 + c1] * (m[4 * r1 + c0] * m[4 * r2 + c2] - m[4 * r1 + c2] * m[4 * r2 + c0])
+         + m[4 * r0 + c2] * (m[4 * r1 + c0] * m[4 * r2 + c1] - m[4 * r1 + c1] * m[4 * r2 + c0]);
+}
+
+// generic 4x4 inverse by cofactors (the reference does NOT use the rigid shortcut)
+__device__ __forceinline__ Mat4 mat_inverse(const Mat4 &a)
+{
+    Mat4 adj;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int r0 = (r == 0) ? 1 : 0, r1 = (r <= 1) ? 2 : 1, r2 = (r <= 2) ? 3 : 2;
+            const int c0 = (c == 0) ? 1 : 0, c1 = (c <= 1) ? 2 : 1, c2 = (c <= 2) ? 3 : 2;
+            float mn = minor3(a.m, r0, r1, r2, c0, c1, c2);
+            adj.m[4 * c + r] = ((r + c) & 1) ? -mn : mn;
+        }
+    }
+    float det = a.m[0] * adj.m[0] + a.m[1] * adj.m[4] + a.m[2] * adj.m[8] + a.m[3] * adj.m[12];
+    float rdet = 1.0f / det;
+    Mat4 o;
+#pragma unroll
+    for (int k = 0; k < 16; k++) o.m[k] = adj.m[k] * rdet;
+    return o;
+}
+
+#define BTBA_ONE_TWENTIETH 0.05f
+#define BTBA_ONE_SIXTH 0.16666667f
+
+// R (row-major 3x3 into r[9]) from w with coefficients A, B  (rodrigues_so3_exp)
+__device__ __forceinline__ void rodrigues(const float w[3], float A, float B, float r[9])
+{
+    const float wx2 = w[0] * w[0], wy2 = w[1] * w[1], wz2 = w[2] * w[2];
+    r[0] = 1.0f - B * (wy2 + wz2);
+    r[4] = 1.0f - B * (wx2 + wz2);
+    r[8] = 1.0f - B * (wx2 + wy2);
+    float a = A * w[2], b = B * (w[0] * w[1]);
+    r[1] = b - a; r[3] = b + a;
+    a = A * w[1]; b = B * (w[0] * w[2]);
+    r[2] = b + a; r[6] = b - a;
+    a = A * w[0]; b = B * (w[1] * w[2]);
+    r[5] = b - a; r[7] = b + a;
+}
+
+__device__ __forceinline__ void exp_rotation(const float w[3], float r[9])
+{
+    const float theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const float theta = sqrtf(theta_sq);
+    float A, B;
+    if ((double)theta_sq < 1e-8) {
+        A = 1.0f - BTBA_ONE_SIXTH * theta_sq;
+        B = 0.5f;
+    } else if ((double)theta_sq < 1e-6) {
+        B = 0.5f - 0.25f * BTBA_ONE_SIXTH * theta_sq;
+        A = 1.0f - theta_sq * BTBA_ONE_SIXTH * (1.0f - BTBA_ONE_TWENTIETH * theta_sq);
+    } else {
+        const float inv_theta = 1.0f / theta;
+        A = sinf(theta) * inv_theta;
+        B = (1.0f - cosf(theta)) * (inv_theta * inv_theta);
+    }
+    rodrigues(w, A, B, r);
+}
+
+__device__ __forceinline__ void ln_rotation(const float R[9], float out[3])
+{
+    const float cos_angle = ((R[0] + R[4] + R[8]) - 1.0f) * 0.5f;
+    float r0 = (R[7] - R[5]) * 0.5f, r1 = (R[2] - R[6]) * 0.5f, r2 = (R[3] - R[1]) * 0.5f;
+    const float sin_angle_abs = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+    if (cos_angle > 0.70710678118654752440f) {
+        if (sin_angle_abs > 0) {
+            const float s = asinf(sin_angle_abs) / sin_angle_abs;
+            r0 *= s; r1 *= s; r2 *= s;
+        }
+    } else if (cos_angle > -0.70710678118654752440f) {
+        const float s = acosf(cos_angle) / sin_angle_abs;
+        r0 *= s; r1 *= s; r2 *= s;
+    } else {
+        const float angle = 3.14159265358979323846f - asinf(sin_angle_abs);
+        const float d0 = R[0] - cos_angle, d1 = R[4] - cos_angle, d2 = R[8] - cos_angle;
+        float q0, q1, q2;
+        if (fabsf(d0) > fabsf(d1) && fabsf(d0) > fabsf(d2)) {
+            q0 = d0; q1 = (R[3] + R[1]) * 0.5f; q2 = (R[2] + R[6]) * 0.5f;
+        } else if (fabsf(d1) > fabsf(d2)) {
+            q0 = (R[3] + R[1]) * 0.5f; q1 = d1; q2 = (R[7] + R[5]) * 0.5f;
+        } else {
+            q0 = (R[2] + R[6]) * 0.5f; q1 = (R[7] + R[5]) * 0.5f; q2 = d2;
+        }
+        if (q0 * r0 + q1 * r1 + q2 * r2 < 0) { q0 = -q0; q1 = -q1; q2 = -q2; }
+        const float s = angle / sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+        r0 = q0 * s; r1 = q1 * s; r2 = q2 * s;
+    }
+    out[0] = r0; out[1] = r1; out[2] = r2;
+}
+
+// SE(3) log: 4x4 -> (rot, trans)   (matrixToPose)
+__device__ __forceinline__ void matrix_to_pose(const Mat4 &M, float rot[3], float trans[3])
+{
+    const float R[9] = { M.m[0], M.m[1], M.m[2], M.m[4], M.m[5], M.m[6], M.m[8], M.m[9], M.m[10] };
+    const float t[3] = { M.m[3], M.m[7], M.m[11] };
+    ln_rotation(R, rot);
+    const float theta = sqrtf(rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
+    float shtot = 0.5f;
+    if (theta > 0.00001f) shtot = sinf(theta * 0.5f) / theta;
+    const float rh[3] = { rot[0] * -0.5f, rot[1] * -0.5f, rot[2] * -0.5f };
+    float Hh[9];
+    exp_rotation(rh, Hh);
+    float tr0 = Hh[0] * t[0] + Hh[1] * t[1] + Hh[2] * t[2];
+    float tr1 = Hh[3] * t[0] + Hh[4] * t[1] + Hh[5] * t[2];
+    float tr2 = Hh[6] * t[0] + Hh[7] * t[1] + Hh[8] * t[2];
+    const float tdr = t[0] * rot[0] + t[1] * rot[1] + t[2] * rot[2];
+    float s;
+    if (theta > 0.001f) s = tdr * (1.0f - 2.0f * shtot) / (rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
+    else s = tdr / 24.0f;
+    tr0 -= rot[0] * s; tr1 -= rot[1] * s; tr2 -= rot[2] * s;
+    const float k = 1.0f / (2.0f * shtot);
+    trans[0] = tr0 * k; trans[1] = tr1 * k; trans[2] = tr2 * k;
+}
+
+// SE(3) exp: (rot, trans) -> 4x4   (poseToMatrix)
+__device__ __forceinline__ Mat4 pose_to_matrix(const float rot[3], const float trans[3])
+{
+    const float theta_sq = rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2];
+    const float theta = sqrtf(theta_sq);
+    float A, B;
+    const float cr[3] = { rot[1] * trans[2] - rot[2] * trans[1], rot[2] * trans[0] - rot[0] * trans[2], rot[0] * trans[1] - rot[1] * trans[0] };
+    float tx, ty, tz;
+    if ((double)theta_sq < 1e-8) {
+        A = 1.0f - BTBA_ONE_SIXTH * theta_sq;
+        B = 0.5f;
+        tx = trans[0] + 0.5f * cr[0]; ty = trans[1] + 0.5f * cr[1]; tz = trans[2] + 0.5f * cr[2];
+    } else {
+        float C;
+        if ((double)theta_sq < 1e-6) {
+            C = BTBA_ONE_SIXTH * (1.0f - BTBA_ONE_TWENTIETH * theta_sq);
+            A = 1.0f - theta_sq * C;
+            B = 0.5f - 0.25f * BTBA_ONE_SIXTH * theta_sq;
+        } else {
+            const float inv_theta = 1.0f / theta;
+            A = sinf(theta) * inv_theta;
+            B = (1.0f - cosf(theta)) * (inv_theta * inv_theta);
+            C = (1.0f - A) * (inv_theta * inv_theta);
+        }
+        const float wc[3] = { rot[1] * cr[2] - rot[2] * cr[1], rot[2] * cr[0] - rot[0] * cr[2], rot[0] * cr[1] - rot[1] * cr[0] };
+        tx = trans[0] + B * cr[0] + C * wc[0]; ty = trans[1] + B * cr[1] + C * wc[1]; tz = trans[2] + B * cr[2] + C * wc[2];
+    }
+    float R[9];
+    rodrigues(rot, A, B, R);
+    Mat4 M;
+    M.m[0] = R[0]; M.m[1] = R[1]; M.m[2] = R[2];  M.m[3] = tx;
+    M.m[4] = R[3]; M.m[5] = R[4]; M.m[6] = R[5];  M.m[7] = ty;
+    M.m[8] = R[6]; M.m[9] = R[7]; M.m[10] = R[8]; M.m[11] = tz;
+    M.m[12] = 0.0f; M.m[13] = 0.0f; M.m[14] = 0.0f; M.m[15] = 1.0f;
+    return M;
+}
+
+// Huber IRLS weight rho' (huberLoss .y, SolverBundlingUtil.h:24-40: float sqrt held in a double)
+__device__ __forceinline__ float huber_weight(float e, float delta)
+{
+    const float dsqr = delta * delta;
+    if (e <= dsqr) return 1.0f;
+    const double sq = (double)sqrtf(e);
+    return (float)((double)delta / sq);
+}
+
+// ---- wave64 reductions on DPP (no LDS, no ds_bpermute) -----------------------------------
+// Butterfly inside each row of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror: every
+// lane of the row ends with the row sum), then row_bcast:15 / row_bcast:31 fold the four rows so
+// that lane 63 holds the wave total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);   // row_mirror
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum_all(float v)
+{
+    v = wave_sum_to_lane63(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Reduce NV per-thread registers over a workgroup of NWAVES waves into out[0..NV) (global or LDS).
+// lds_scratch must hold NWAVES*NV floats.  Deterministic: fixed tree inside the wave, fixed
+// wave order across waves.
+template <int NV, int NWAVES>
+__device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float *lds_scratch, float *out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const float s = wave_sum_to_lane63(acc[k]);
+        if (lane == 63) lds_scratch[wave * NV + k] = s;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < NV; k += blockDim.x) {
+        float s = lds_scratch[k];
+#pragma unroll
+        for (int w = 1; w < NWAVES; w++) s += lds_scratch[w * NV + k];
+        out[k] = s;
+    }
+}
+
+}  // namespace btba

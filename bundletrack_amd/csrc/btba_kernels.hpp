@@ -1,0 +1,560 @@
+// btba_kernels.hpp -- the gfx950 kernels of the bundle-adjustment hot path.
+//
+// One Gauss-Newton iteration = three launches (reference: 37 launches, 11 memsets, one blocking
+// D2H copy and a cudaMalloc/cudaFree pair):
+//
+//   sparse_sweep  (A11/A12)  one pass over EntryJ[]: per frame pair the Huber-weighted right-hand
+//                            side, the Jacobi preconditioner diagonal AND the moment sums from
+//                            which the *unweighted* sparse J^T J blocks follow in closed form.
+//                            Replaces PCGInit_Kernel1 (one thread per frame!) and the 5 x
+//                            (PCGStep_Kernel0 + PCGStep_Kernel1a) matrix-free passes.
+//   dense_sweep   (A10)      the point-to-plane Jacobian sweep: per (pair, pixel) projective
+//                            association, bilinear target lookup, residual, Huber weight and the
+//                            closed-form row a = [-n_w ; n_w x w]; since row_i = -row_j only
+//                            S = sum w a a^T (21) and g = sum w a res (6) are reduced per pair.
+//                            Replaces BuildDenseSystem_Kernel + FlipJtJ_Kernel (and drops the dead
+//                            FindDenseCorrespondences_Kernel twin pass).
+//   system_solve  (A11-A13)  one workgroup per instance: fixed-order reduction of the partials,
+//                            assembly of the 6N x 6N normal matrix in LDS, Jacobi-PCG entirely in
+//                            LDS, SE(3) update, next iterate's T and T^-1.
+//
+// Summation is deterministic (fixed DPP tree inside a wave, fixed order across waves, tiles and
+// pairs); the reference uses float atomics (SURVEY.md section 5 "race detection").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "btba_device.hpp"
+
+namespace btba {
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kSparseVals = 44;      // per-pair sparse partial record
+constexpr int kDenseVals = 28;       // per-pair dense partial record: S(21) g(6) count(1)
+constexpr float kEps = 0.000001f;    // FLOAT_EPSILON, SolverUtil.h:10
+
+// sparse record layout
+//  0      n (valid count)
+//  1..3   sum w_i           4..6   sum w_j
+//  7..12  sum w_i w_i^T (xx xy xz yy yz zz)     13..18 same for w_j
+//  19..27 sum w_i w_j^T (row-major 3x3)
+//  28..30 sum rho r         31..33 sum rho (w_i x r)      34..36 sum rho (w_j x r)
+//  37     sum rho
+//  38..40 sum rho (wy^2+wz^2, wx^2+wz^2, wx^2+wy^2) at w_i     41..43 same at w_j
+
+struct SolveDims {
+    int n_frames;        // N
+    int n_pairs;         // P = N(N-1)/2 canonical correspondence pairs
+    int n_dense_pairs;   // Pd
+    int npix, width, height;
+    int sparse_chunks;   // workgroups per correspondence segment
+    int dense_tiles;     // workgroups per dense pair
+    int n_pcg;
+    int use_sparse, use_dense;
+    float fx, fy, cx, cy;
+    float robust_delta, dist_thresh, normal_thresh, depth_min, depth_max;
+    float w_sparse, w_dense;
+    int64_t corr_stride; // EntryJ per instance block
+    int trace_on;
+    int64_t trace_record; // floats per (instance, iteration) record
+    int64_t tr_x, tr_T, tr_rhs, tr_prec, tr_pcg, tr_delta, tr_dpair, tr_A;
+    int n_gn;
+    int pairsum_in_lds;  // 1: stage reduced pair sums in LDS, 0: in global scratch
+};
+
+// canonical pair index -> (i, j), i < j, outer i
+__device__ __forceinline__ void pair_from_index(int p, int n, int &i, int &j)
+{
+    int ii = 0, rem = p;
+    while (rem >= n - 1 - ii) { rem -= n - 1 - ii; ii++; }
+    i = ii; j = ii + 1 + rem;
+}
+__device__ __forceinline__ int pair_index(int i, int j, int n) { return i * n - i * (i + 1) / 2 + (j - i - 1); }
+
+__device__ __forceinline__ Mat4 load_mat4(const float *p)
+{
+    Mat4 m;
+    const float4 *q = reinterpret_cast<const float4 *>(p);
+    float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    m.m[0] = a.x; m.m[1] = a.y; m.m[2] = a.z; m.m[3] = a.w;
+    m.m[4] = b.x; m.m[5] = b.y; m.m[6] = b.z; m.m[7] = b.w;
+    m.m[8] = c.x; m.m[9] = c.y; m.m[10] = c.z; m.m[11] = c.w;
+    m.m[12] = d.x; m.m[13] = d.y; m.m[14] = d.z; m.m[15] = d.w;
+    return m;
+}
+__device__ __forceinline__ void store_mat4(float *p, const Mat4 &m)
+{
+    float4 *q = reinterpret_cast<float4 *>(p);
+    q[0] = make_float4(m.m[0], m.m[1], m.m[2], m.m[3]);
+    q[1] = make_float4(m.m[4], m.m[5], m.m[6], m.m[7]);
+    q[2] = make_float4(m.m[8], m.m[9], m.m[10], m.m[11]);
+    q[3] = make_float4(m.m[12], m.m[13], m.m[14], m.m[15]);
+}
+
+// ---- prepare: Log of the input matrices, then Exp and inverse (SBA.cu:71-79, SolverBundling.cu:890-897)
+__global__ void __launch_bounds__(64) k_prepare(int total, const float *__restrict__ poses, float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const Mat4 M = load_mat4(poses + 16 * (size_t)idx);
+    float rot[3], trans[3];
+    matrix_to_pose(M, rot, trans);
+    if (x) { float *o = x + 6 * (size_t)idx; o[0] = rot[0]; o[1] = rot[1]; o[2] = rot[2]; o[3] = trans[0]; o[4] = trans[1]; o[5] = trans[2]; }
+    if (T || Tinv) {
+        const Mat4 E = pose_to_matrix(rot, trans);
+        if (T) store_mat4(T + 16 * (size_t)idx, E);
+        if (Tinv) store_mat4(Tinv + 16 * (size_t)idx, mat_inverse(E));
+    }
+}
+
+__global__ void __launch_bounds__(64) k_poses_to_matrices(int total, const float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const float *o = x + 6 * (size_t)idx;
+    const float rot[3] = { o[0], o[1], o[2] }, trans[3] = { o[3], o[4], o[5] };
+    const Mat4 E = pose_to_matrix(rot, trans);
+    if (T) store_mat4(T + 16 * (size_t)idx, E);
+    if (Tinv) store_mat4(Tinv + 16 * (size_t)idx, mat_inverse(E));
+}
+
+// ---- frame cache (A3): CUDACache::storeFrame as ONE launch for all frames --------------------
+// grid (ceil(npix/256), n_frames).  Reads only the full-res pixels the nearest-neighbour
+// resample picks (CUDAImageUtil.cu:57-61) instead of converting the whole 640x480 image first.
+__global__ void __launch_bounds__(kBlock) k_build_cache(int W, int H, int Wd, int Hd, Mat4 Kinv,
+                                                       const float *const *__restrict__ depth, const float *const *__restrict__ normals,
+                                                       float4 *__restrict__ campos_out, float4 *__restrict__ normals_out, int *__restrict__ n_valid)
+{
+    const int f = blockIdx.y;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    const int npix = Wd * Hd;
+    int valid = 0;
+    if (o < npix) {
+        const int x = o % Wd, y = o / Wd;
+        const float scaleW = (float)(W - 1) / (float)(Wd - 1);
+        const float scaleH = (float)(H - 1) / (float)(Hd - 1);
+        const unsigned xi = (unsigned)(x * scaleW + 0.5f);
+        const unsigned yi = (unsigned)(y * scaleH + 0.5f);
+        if (xi < (unsigned)W && yi < (unsigned)H) {
+            const size_t s = (size_t)yi * W + xi;
+            const float d = depth[f][s];
+            float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((double)d >= 0.1) {
+                // intrinsicsInv * (x d, y d, d, d); output (x, y, w, 1)  (CUDAImageUtil.cu:310-327)
+                const float vx = (float)xi * d, vy = (float)yi * d;
+                cp.x = Kinv.m[0] * vx + Kinv.m[1] * vy + Kinv.m[2] * d + Kinv.m[3] * d;
+                cp.y = Kinv.m[4] * vx + Kinv.m[5] * vy + Kinv.m[6] * d + Kinv.m[7] * d;
+                cp.z = Kinv.m[12] * vx + Kinv.m[13] * vy + Kinv.m[14] * d + Kinv.m[15] * d;
+                cp.w = 1.0f;
+                valid = 1;
+            }
+            campos_out[(size_t)f * npix + o] = cp;
+            normals_out[(size_t)f * npix + o] = reinterpret_cast<const float4 *>(normals[f])[s];
+        }
+    }
+    if (n_valid) {
+        const unsigned long long b = __ballot(valid);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&n_valid[f], __popcll(b));
+    }
+}
+
+// ---- sparse sweep -----------------------------------------------------------------------------
+// grid (sparse_chunks, P, B).  Workgroup (c, p, b) owns slice c of pair p's contiguous EntryJ
+// segment: two coalesced 16-byte loads per correspondence, 44 register accumulators per lane.
+__global__ void __launch_bounds__(kBlock) k_sparse_sweep(SolveDims D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
+                                                        const float *__restrict__ T, float *__restrict__ partials)
+{
+    __shared__ float red[4 * kSparseVals];
+    const int chunk = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
+    int fi, fj;
+    pair_from_index(p, D.n_frames, fi, fj);
+    const uint32_t *off = pair_offsets + (size_t)b * (D.n_pairs + 1);
+    const uint32_t seg0 = off[p], seg1 = off[p + 1];
+    const uint32_t len = seg1 - seg0;
+    const uint32_t per = (len + D.sparse_chunks - 1) / D.sparse_chunks;
+    const uint32_t lo = seg0 + min(len, per * chunk), hi = seg0 + min(len, per * (chunk + 1));
+    const Mat4 Ti = load_mat4(T + 16 * ((size_t)b * D.n_frames + fi));
+    const Mat4 Tj = load_mat4(T + 16 * ((size_t)b * D.n_frames + fj));
+    const float4 *cb = corr + 2 * (size_t)b * D.corr_stride;
+    float acc[kSparseVals];
+#pragma unroll
+    for (int k = 0; k < kSparseVals; k++) acc[k] = 0.0f;
+
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += kBlock) {
+        const float4 q0 = cb[2 * (size_t)e], q1 = cb[2 * (size_t)e + 1];
+        if (__float_as_uint(q0.x) == 0xFFFFFFFFu) continue;   // EntryJ::isValid
+        // q0 = (imgIdx_i, imgIdx_j, pos_i.x, pos_i.y)  q1 = (pos_i.z, pos_j.x, pos_j.y, pos_j.z)
+        float wix, wiy, wiz, wjx, wjy, wjz;
+        xform_point(Ti, q0.z, q0.w, q1.x, wix, wiy, wiz);
+        xform_point(Tj, q1.y, q1.z, q1.w, wjx, wjy, wjz);
+        const float rx = wix - wjx, ry = wiy - wjy, rz = wiz - wjz;
+        const float rho = huber_weight(rx * rx + ry * ry + rz * rz, D.robust_delta);
+        acc[0] += 1.0f;
+        acc[1] += wix; acc[2] += wiy; acc[3] += wiz;
+        acc[4] += wjx; acc[5] += wjy; acc[6] += wjz;
+        acc[7] += wix * wix; acc[8] += wix * wiy; acc[9] += wix * wiz; acc[10] += wiy * wiy; acc[11] += wiy * wiz; acc[12] += wiz * wiz;
+        acc[13] += wjx * wjx; acc[14] += wjx * wjy; acc[15] += wjx * wjz; acc[16] += wjy * wjy; acc[17] += wjy * wjz; acc[18] += wjz * wjz;
+        acc[19] += wix * wjx; acc[20] += wix * wjy; acc[21] += wix * wjz;
+        acc[22] += wiy * wjx; acc[23] += wiy * wjy; acc[24] += wiy * wjz;
+        acc[25] += wiz * wjx; acc[26] += wiz * wjy; acc[27] += wiz * wjz;
+        acc[28] += rho * rx; acc[29] += rho * ry; acc[30] += rho * rz;
+        acc[31] += rho * (wiy * rz - wiz * ry); acc[32] += rho * (wiz * rx - wix * rz); acc[33] += rho * (wix * ry - wiy * rx);
+        acc[34] += rho * (wjy * rz - wjz * ry); acc[35] += rho * (wjz * rx - wjx * rz); acc[36] += rho * (wjx * ry - wjy * rx);
+        acc[37] += rho;
+        acc[38] += rho * (wiy * wiy + wiz * wiz); acc[39] += rho * (wix * wix + wiz * wiz); acc[40] += rho * (wix * wix + wiy * wiy);
+        acc[41] += rho * (wjy * wjy + wjz * wjz); acc[42] += rho * (wjx * wjx + wjz * wjz); acc[43] += rho * (wjx * wjx + wjy * wjy);
+    }
+    float *out = partials + (((size_t)b * D.n_pairs + p) * D.sparse_chunks + chunk) * kSparseVals;
+    block_reduce_store<kSparseVals, 4>(acc, red, out);
+}
+
+// ---- dense sweep ------------------------------------------------------------------------------
+// bilinearInterpolationFloat4 (ICPUtil.h:83-110): out-of-image taps are skipped, zero (invalid)
+// taps are blended in, weights renormalised per row then per column.
+__device__ __forceinline__ bool bilinear4(const float4 *__restrict__ img, float x, float y, int W, int H, float4 &out)
+{
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float alpha = x - (float)x0, beta = y - (float)y0;
+    const bool okx0 = (unsigned)x0 < (unsigned)W, okx1 = (unsigned)(x0 + 1) < (unsigned)W;
+    const bool oky0 = (unsigned)y0 < (unsigned)H, oky1 = (unsigned)(y0 + 1) < (unsigned)H;
+    const float ninf = -INFINITY;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    float w0 = 0.f, w1 = 0.f;
+    if (okx0 && oky0) { const float4 v = img[y0 * W + x0]; if (v.x != ninf) { const float a = 1.0f - alpha; s0.x += a * v.x; s0.y += a * v.y; s0.z += a * v.z; s0.w += a * v.w; w0 += a; } }
+    if (okx1 && oky0) { const float4 v = img[y0 * W + x0 + 1]; if (v.x != ninf) { s0.x += alpha * v.x; s0.y += alpha * v.y; s0.z += alpha * v.z; s0.w += alpha * v.w; w0 += alpha; } }
+    if (okx0 && oky1) { const float4 v = img[(y0 + 1) * W + x0]; if (v.x != ninf) { const float a = 1.0f - alpha; s1.x += a * v.x; s1.y += a * v.y; s1.z += a * v.z; s1.w += a * v.w; w1 += a; } }
+    if (okx1 && oky1) { const float4 v = img[(y0 + 1) * W + x0 + 1]; if (v.x != ninf) { s1.x += alpha * v.x; s1.y += alpha * v.y; s1.z += alpha * v.z; s1.w += alpha * v.w; w1 += alpha; } }
+    float4 ss = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ww = 0.f;
+    if (w0 > 0.0f) { const float bb = 1.0f - beta; ss.x += bb * (s0.x / w0); ss.y += bb * (s0.y / w0); ss.z += bb * (s0.z / w0); ss.w += bb * (s0.w / w0); ww += bb; }
+    if (w1 > 0.0f) { ss.x += beta * (s1.x / w1); ss.y += beta * (s1.y / w1); ss.z += beta * (s1.z / w1); ss.w += beta * (s1.w / w1); ww += beta; }
+    if (ww > 0.0f) { out = make_float4(ss.x / ww, ss.y / ww, ss.z / ww, ss.w / ww); return true; }
+    out = make_float4(ninf, ninf, ninf, ninf);
+    return false;
+}
+
+// grid (dense_tiles, Pd, B).  Lane = consecutive source pixel (coalesced float4 loads of the
+// source camPos / normal); the four target taps are gathers that stay in L1/L2 because
+// neighbouring source pixels project to neighbouring target pixels.
+__global__ void __launch_bounds__(kBlock) k_dense_sweep(SolveDims D, const float4 *__restrict__ campos, const float4 *__restrict__ normals,
+                                                       const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
+                                                       float *__restrict__ partials)
+{
+    __shared__ float red[4 * kDenseVals];
+    const int tile = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
+    const int2 ij = dense_pairs[p];
+    const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
+    const size_t fb = (size_t)b * D.n_frames;
+    const Mat4 Ti = load_mat4(T + 16 * (fb + fi));
+    const Mat4 Tj = load_mat4(T + 16 * (fb + fj));
+    const Mat4 Tii = load_mat4(Tinv + 16 * (fb + fi));
+    const Mat4 Tij = mat_mul(Tii, Tj);                    // source camera -> target camera
+    const float4 *cam_t = campos + (fb + fi) * (size_t)D.npix, *nrm_t = normals + (fb + fi) * (size_t)D.npix;
+    const float4 *cam_s = campos + (fb + fj) * (size_t)D.npix, *nrm_s = normals + (fb + fj) * (size_t)D.npix;
+    const int per = (D.npix + D.dense_tiles - 1) / D.dense_tiles;
+    const int lo = min(D.npix, per * tile), hi = min(D.npix, per * (tile + 1));
+    float acc[kDenseVals];
+#pragma unroll
+    for (int k = 0; k < kDenseVals; k++) acc[k] = 0.0f;
+
+    for (int s = lo + threadIdx.x; s < hi; s += kBlock) {
+        const float4 cs = cam_s[s];
+        if (!(cs.z > D.depth_min && cs.z < D.depth_max)) continue;
+        const float4 ns = nrm_s[s];
+        if (!(ns.x != -INFINITY)) continue;
+        // n' = Tij * float4(ns) (w = 0 for valid data -> rotation only), q = Tij * cs.xyz
+        const float nqx = Tij.m[0] * ns.x + Tij.m[1] * ns.y + Tij.m[2] * ns.z + Tij.m[3] * ns.w;
+        const float nqy = Tij.m[4] * ns.x + Tij.m[5] * ns.y + Tij.m[6] * ns.z + Tij.m[7] * ns.w;
+        const float nqz = Tij.m[8] * ns.x + Tij.m[9] * ns.y + Tij.m[10] * ns.z + Tij.m[11] * ns.w;
+        const float nqw = Tij.m[12] * ns.x + Tij.m[13] * ns.y + Tij.m[14] * ns.z + Tij.m[15] * ns.w;
+        float qx, qy, qz;
+        xform_point(Tij, cs.x, cs.y, cs.z, qx, qy, qz);
+        const float u = qx * D.fx / qz + D.cx;
+        const float v = qy * D.fy / qz + D.cy;
+        const int sx = (int)roundf(u), sy = (int)roundf(v);
+        if (!(sx >= 0 && sy >= 0 && sx < D.width && sy < D.height)) continue;
+        float4 ci, ni;
+        bilinear4(cam_t, u, v, D.width, D.height, ci);
+        if (!(ci.z > D.depth_min && ci.z < D.depth_max)) continue;
+        bilinear4(nrm_t, u, v, D.width, D.height, ni);
+        if (!(ni.x != -INFINITY)) continue;
+        const float dx = qx - ci.x, dy = qy - ci.y, dz = qz - ci.z;
+        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float dn = nqx * ni.x + nqy * ni.y + nqz * ni.z + nqw * ni.w;
+        if (!(dn >= D.normal_thresh && dist <= D.dist_thresh)) continue;
+        const float res = (ci.x - qx) * ni.x + (ci.y - qy) * ni.y + (ci.z - qz) * ni.z;
+        const float wgt = D.w_dense * huber_weight(res * res, D.robust_delta);
+        // row_j = [-n_w ; n_w x w],  w = T_j c_j (model frame),  n_w = R_i n_i
+        float wx, wy, wz;
+        xform_point(Tj, cs.x, cs.y, cs.z, wx, wy, wz);
+        const float nx = Ti.m[0] * ni.x + Ti.m[1] * ni.y + Ti.m[2] * ni.z;
+        const float ny = Ti.m[4] * ni.x + Ti.m[5] * ni.y + Ti.m[6] * ni.z;
+        const float nz = Ti.m[8] * ni.x + Ti.m[9] * ni.y + Ti.m[10] * ni.z;
+        const float a[6] = { -nx, -ny, -nz, ny * wz - nz * wy, nz * wx - nx * wz, nx * wy - ny * wx };
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const float wa = wgt * a[r];
+#pragma unroll
+            for (int c = r; c < 6; c++) acc[k++] += wa * a[c];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++) acc[21 + r] += wgt * a[r] * res;
+        acc[27] += 1.0f;
+    }
+    float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
+    block_reduce_store<kDenseVals, 4>(acc, red, out);
+}
+
+// ---- system solve -------------------------------------------------------------------------------
+// index of (r, c), r <= c, in the 21-entry upper-triangle row-major packing of a symmetric 6x6
+__device__ __forceinline__ int tri21(int r, int c) { if (r > c) { const int t = r; r = c; c = t; } return r * 6 - r * (r - 1) / 2 + (c - r); }
+// symmetric 3x3 packed xx xy xz yy yz zz
+__device__ __forceinline__ float sym3(const float *m, int r, int c) { if (r > c) { const int t = r; r = c; c = t; } return m[r * 3 - r * (r - 1) / 2 + (c - r)]; }
+// [v]x (r, c)
+__device__ __forceinline__ float skew(const float *v, int r, int c)
+{
+    if (r == c) return 0.0f;
+    const int k = 3 - r - c;                          // the remaining axis
+    const float s = ((c - r + 3) % 3 == 1) ? -1.0f : 1.0f;   // (0,1)->-z (1,2)->-x (2,0)->-y
+    return s * v[k];
+}
+
+// 6x6 sparse block entries in [trans, rot] order from the per-pair moment sums.
+//   J_k = [ I | D(w_k) ],  D(w) = -[w]x.
+// diag block of endpoint e (0 = i, 1 = j):  [[ n I, -[s]x ], [ [s]x, tr(M) I - M ]]
+__device__ __forceinline__ float sparse_diag_entry(const float *rec, int e, int r, int c)
+{
+    const float *s = rec + 1 + 3 * e, *M = rec + 7 + 6 * e;
+    const int br = r / 3, bc = c / 3, rr = r % 3, cc = c % 3;
+    if (br == 0 && bc == 0) return rr == cc ? rec[0] : 0.0f;
+    if (br == 0 && bc == 1) return -skew(s, rr, cc);
+    if (br == 1 && bc == 0) return skew(s, rr, cc);
+    const float tr = M[0] + M[3] + M[5];
+    return (rr == cc ? tr : 0.0f) - sym3(M, rr, cc);
+}
+// cross block J_i^T J_j (row index on frame i, column on frame j):
+//   [[ n I, -[s_j]x ], [ [s_i]x, tr(Mij) I - Mij^T ]]
+__device__ __forceinline__ float sparse_cross_entry(const float *rec, int r, int c)
+{
+    const float *si = rec + 1, *sj = rec + 4, *Mij = rec + 19;
+    const int br = r / 3, bc = c / 3, rr = r % 3, cc = c % 3;
+    if (br == 0 && bc == 0) return rr == cc ? rec[0] : 0.0f;
+    if (br == 0 && bc == 1) return -skew(sj, rr, cc);
+    if (br == 1 && bc == 0) return skew(si, rr, cc);
+    const float tr = Mij[0] + Mij[4] + Mij[8];
+    return (rr == cc ? tr : 0.0f) - Mij[cc * 3 + rr];
+}
+
+__device__ __forceinline__ float block_sum(float v, float *scratch)
+{
+    // all threads must call; returns the workgroup total to every thread
+    const float s = wave_sum_to_lane63(v);
+    const int nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) scratch[threadIdx.x >> 6] = s;
+    __syncthreads();
+    float t = scratch[0];
+    for (int w = 1; w < nw; w++) t += scratch[w];
+    return t;
+}
+
+// grid (B); dynamic LDS: A[n*ld] + 7 vectors[n] + scratch + (optionally) reduced pair sums.
+// cross_ok[p] (dense) = 1 when the dense cross block survives FlipJtJ (target < source).
+__global__ void __launch_bounds__(kBlock) k_system_solve(SolveDims D, int iter,
+                                                        const float *__restrict__ sparse_partials, const float *__restrict__ dense_partials,
+                                                        const int2 *__restrict__ dense_pairs,
+                                                        float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv,
+                                                        float *__restrict__ pairsum_global, float *__restrict__ trace)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int N = D.n_frames, n = 6 * N, ld = n | 1;
+    float *A = lds;
+    float *vb = A + (size_t)n * ld;       // rhs / residual r
+    float *vM = vb + n, *vz = vM + n, *vp = vz + n, *vAp = vp + n, *vd = vAp + n;
+    float *scratch = vd + n;              // 16 floats
+    float *ps = D.pairsum_in_lds ? scratch + 16 : pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals);
+    float *pd = ps + (size_t)D.n_pairs * kSparseVals;
+    float *tr = D.trace_on ? trace + ((size_t)b * D.n_gn + iter) * D.trace_record : nullptr;
+
+    // Phase A: fixed-order reduction of the sweep partials
+    if (D.use_sparse) {
+        const float *src = sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals;
+        for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) {
+            const int p = e / kSparseVals, k = e % kSparseVals;
+            const float *q = src + (size_t)p * D.sparse_chunks * kSparseVals + k;
+            float s = q[0];
+            for (int c = 1; c < D.sparse_chunks; c++) s += q[(size_t)c * kSparseVals];
+            ps[e] = s;
+        }
+    } else {
+        for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) ps[e] = 0.0f;
+    }
+    if (D.use_dense) {
+        const float *src = dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals;
+        for (int e = tid; e < D.n_dense_pairs * kDenseVals; e += nthr) {
+            const int p = e / kDenseVals, k = e % kDenseVals;
+            const float *q = src + (size_t)p * D.dense_tiles * kDenseVals + k;
+            float s = q[0];
+            for (int c = 1; c < D.dense_tiles; c++) s += q[(size_t)c * kDenseVals];
+            pd[e] = s;
+        }
+    }
+    for (int e = tid; e < n * ld; e += nthr) A[e] = 0.0f;
+    __syncthreads();
+    if (tr && D.use_dense) for (int e = tid; e < D.n_dense_pairs * kDenseVals; e += nthr) tr[D.tr_dpair + e] = pd[e];
+
+    // Phase B1: off-diagonal 6x6 blocks, one canonical pair (i<j) each: A_ij = -(ws Ji^T Jj + S_dense)
+    for (int e = tid; e < D.n_pairs * 36; e += nthr) {
+        const int p = e / 36, r = (e % 36) / 6, c = e % 6;
+        int i, j;
+        pair_from_index(p, N, i, j);
+        if (i == 0) continue;
+        float v = 0.0f;
+        if (D.use_sparse) v -= D.w_sparse * sparse_cross_entry(ps + (size_t)p * kSparseVals, r, c);
+        A[(6 * i + r) * ld + 6 * j + c] = v;
+        A[(6 * j + c) * ld + 6 * i + r] = v;
+    }
+    __syncthreads();
+    if (D.use_dense) {
+        // dense cross blocks: several dense pairs may map onto one canonical block only through
+        // an explicit list; handle by serialising over dense pairs per block entry owner.
+        for (int e = tid; e < D.n_dense_pairs * 36; e += nthr) {
+            const int p = e / 36, r = (e % 36) / 6, c = e % 6;
+            const int2 ij = dense_pairs[p];
+            if (ij.x == 0 || ij.y == 0 || ij.x >= ij.y) continue;      // i>j: erased by FlipJtJ
+            // duplicates of the same (i,j) in an explicit list are not supported (documented)
+            const float s = pd[(size_t)p * kDenseVals + tri21(r, c)];
+            A[(6 * ij.x + r) * ld + 6 * ij.y + c] -= s;
+            A[(6 * ij.y + c) * ld + 6 * ij.x + r] -= s;
+        }
+    }
+    // Phase B2: diagonal blocks, rhs, preconditioner: thread per (frame k >= 1, entry)
+    for (int e = tid; e < (N - 1) * 36; e += nthr) {
+        const int k = 1 + e / 36, r = (e % 36) / 6, c = e % 6;
+        float v = 0.0f;
+        if (D.use_sparse) {
+            for (int m = 0; m < N; m++) {
+                if (m == k) continue;
+                const int i = m < k ? m : k, j = m < k ? k : m;
+                v += D.w_sparse * sparse_diag_entry(ps + (size_t)pair_index(i, j, N) * kSparseVals, k == i ? 0 : 1, r, c);
+            }
+        }
+        if (D.use_dense) {
+            for (int p = 0; p < D.n_dense_pairs; p++) {
+                const int2 ij = dense_pairs[p];
+                if (ij.x == k || ij.y == k) v += pd[(size_t)p * kDenseVals + tri21(r, c)];
+            }
+        }
+        A[(6 * k + r) * ld + 6 * k + c] = v;
+    }
+    for (int e = tid; e < n; e += nthr) {
+        const int k = e / 6, r = e % 6;
+        float rhs = 0.0f, md = 0.0f;
+        if (k > 0) {
+            if (D.use_sparse) {
+                for (int m = 0; m < N; m++) {
+                    if (m == k) continue;
+                    const int i = m < k ? m : k, j = m < k ? k : m;
+                    const float *rec = ps + (size_t)pair_index(i, j, N) * kSparseVals;
+                    if (k == i) {
+                        rhs += (r < 3) ? -rec[28 + r] : -rec[31 + r - 3];
+                        md += (r < 3) ? rec[37] : rec[38 + r - 3];
+                    } else {
+                        rhs += (r < 3) ? rec[28 + r] : rec[34 + r - 3];
+                        md += (r < 3) ? rec[37] : rec[41 + r - 3];
+                    }
+                }
+                rhs *= D.w_sparse;
+            }
+            if (D.use_dense) {
+                float jtr = 0.0f;
+                for (int p = 0; p < D.n_dense_pairs; p++) {
+                    const int2 ij = dense_pairs[p];
+                    const float g = pd[(size_t)p * kDenseVals + 21 + r];
+                    if (ij.y == k) jtr += g;            // row_j = a
+                    else if (ij.x == k) jtr -= g;       // row_i = -a
+                }
+                rhs -= jtr;
+            }
+        }
+        vb[e] = rhs;
+        vM[e] = (k > 0) ? ((md > kEps) ? 1.0f / md : 1.0f) : 0.0f;
+        vd[e] = 0.0f;
+    }
+    __syncthreads();
+    if (tr) {
+        for (int e = tid; e < n; e += nthr) {
+            const int k = e / 6, r = e % 6;           // trace order (rot, trans); internal [trans, rot]
+            const int o = k * 6 + (r < 3 ? r + 3 : r - 3);
+            tr[D.tr_rhs + o] = vb[e];
+            tr[D.tr_prec + o] = vM[e];
+        }
+        for (int e = tid; e < n * n; e += nthr) tr[D.tr_A + e] = A[(e / n) * ld + (e % n)];
+    }
+
+    // Phase C: Jacobi-preconditioned CG, SolverBundling.cu:575-818 (frame 0 entries stay 0)
+    float rz;
+    {
+        float part = 0.0f;
+        for (int e = tid; e < n; e += nthr) { const float z = vM[e] * vb[e]; vp[e] = z; part += vb[e] * z; }
+        rz = block_sum(part, scratch);
+    }
+    for (int li = 0; li < D.n_pcg; li++) {
+        __syncthreads();
+        // Ap = A p : 4 lanes per row
+        {
+            const int seg = tid & 3;
+            float part_pAp = 0.0f;
+            for (int row = tid >> 2; row < n; row += nthr >> 2) {
+                const float *ar = A + (size_t)row * ld;
+                float s = 0.0f;
+                for (int c = seg; c < n; c += 4) s += ar[c] * vp[c];
+                s = dpp_add<0xB1, 0xf>(s);
+                s = dpp_add<0x4E, 0xf>(s);
+                if (seg == 0) { vAp[row] = s; part_pAp += vp[row] * s; }
+            }
+            const float pAp = block_sum(part_pAp, scratch);
+            const float alpha = (pAp > kEps) ? rz / pAp : 0.0f;
+            float part = 0.0f;
+            for (int e = tid; e < n; e += nthr) {
+                vd[e] = vd[e] + alpha * vp[e];
+                const float r = vb[e] - alpha * vAp[e];
+                vb[e] = r;
+                const float z = vM[e] * r;
+                vz[e] = z;
+                part += z * r;
+            }
+            const float rz_new = block_sum(part, scratch);
+            const float beta = (rz > kEps) ? rz_new / rz : 0.0f;
+            if (tr && tid == 0) { float *s = tr + D.tr_pcg + 4 * li; s[0] = pAp; s[1] = alpha; s[2] = rz_new; s[3] = beta; }
+            rz = rz_new;
+            for (int e = tid; e < n; e += nthr) vp[e] = vz[e] + beta * vp[e];
+        }
+    }
+    __syncthreads();
+
+    // Phase D: x_k <- Log(Exp(delta_k) Exp(x_k)); next iterate's T, T^-1  (SolverBundling.cu:805-815, 890-897)
+    for (int k = tid; k < N; k += nthr) {
+        float *xk = x + 6 * ((size_t)b * N + k);
+        float rot[3] = { xk[0], xk[1], xk[2] }, trans[3] = { xk[3], xk[4], xk[5] };
+        if (k > 0) {
+            const float dW[3] = { vd[6 * k + 3], vd[6 * k + 4], vd[6 * k + 5] }, dT[3] = { vd[6 * k], vd[6 * k + 1], vd[6 * k + 2] };
+            const Mat4 U = pose_to_matrix(dW, dT);
+            const Mat4 C = pose_to_matrix(rot, trans);
+            matrix_to_pose(mat_mul(U, C), rot, trans);
+            xk[0] = rot[0]; xk[1] = rot[1]; xk[2] = rot[2]; xk[3] = trans[0]; xk[4] = trans[1]; xk[5] = trans[2];
+        }
+        const Mat4 E = pose_to_matrix(rot, trans);
+        store_mat4(T + 16 * ((size_t)b * N + k), E);
+        store_mat4(Tinv + 16 * ((size_t)b * N + k), mat_inverse(E));
+        if (tr) {
+            for (int q = 0; q < 3; q++) { tr[D.tr_x + 6 * k + q] = rot[q]; tr[D.tr_x + 6 * k + 3 + q] = trans[q]; }
+            for (int q = 0; q < 16; q++) tr[D.tr_T + 16 * k + q] = E.m[q];
+            for (int q = 0; q < 3; q++) { tr[D.tr_delta + 6 * k + q] = vd[6 * k + 3 + q]; tr[D.tr_delta + 6 * k + 3 + q] = vd[6 * k + q]; }
+        }
+    }
+}
+
+}  // namespace btba

@@ -1,0 +1,236 @@
+"""Host-side mirror of the reference's optimiser interface on top of the C ABI.
+
+`OptimizerGpu.optimizeFrames` keeps the name, argument order and meaning of
+src/cuda/LossGPU.h:50 (std::vector<EntryJ>, n_match_per_pair, n_frames, H, W, depths_gpu,
+colors_gpu, normals_gpu, poses&, K).  Device buffers are torch CUDA tensors (torch is the
+device-memory plumbing here, nothing more); everything numerical happens inside libbtba.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import ENTRYJ_DTYPE, Params, Stats, TraceLayout, check, default_params, lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Workspace:
+    """One HIP stream + grow-only device scratch (btba_workspace).  By default it runs on
+    torch's current stream so torch tensors and events order naturally with the solver."""
+
+    def __init__(self, stream: int | None = None, use_torch_stream: bool = True):
+        h = C.c_void_p()
+        if stream is None and use_torch_stream:
+            torch = _torch()
+            if not torch.cuda.is_available():
+                raise RuntimeError("bundletrack_amd needs a GPU: torch.cuda.is_available() is False (no CPU fallback)")
+            stream = torch.cuda.current_stream().cuda_stream
+        check(lib().btba_workspace_create(C.byref(h), C.c_void_p(stream) if stream else None), "btba_workspace_create")
+        self._h = h
+
+    @property
+    def handle(self):
+        return self._h
+
+    def sync(self):
+        check(lib().btba_workspace_sync(self._h), "btba_workspace_sync")
+
+    def collect_stats(self) -> dict:
+        s = Stats()
+        check(lib().btba_collect_stats(self._h, C.byref(s)), "btba_collect_stats")
+        return s.as_dict()
+
+    def close(self):
+        if self._h:
+            lib().btba_workspace_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for k, t in enumerate(tensors):
+        arr[k] = t.data_ptr()
+    return arr
+
+
+class OptimizerGpu:
+    """Drop-in for the reference class of the same name (src/cuda/LossGPU.h:40-52).
+
+    The reference reads its parameters from a YAML node by string key at every use site;
+    here `yml` may be a nested dict with the same keys (bundle.num_iter_outter, ...,
+    p2p.max_dist, p2p.max_normal_angle) or None for the shipping defaults."""
+
+    def __init__(self, yml: dict | None = None, workspace: Workspace | None = None, **overrides):
+        self.params = default_params()
+        if yml:
+            b, p = yml.get("bundle", {}), yml.get("p2p", {})
+            if "num_iter_outter" in b: self.params.n_gn_iters = int(b["num_iter_outter"])
+            if "num_iter_inner" in b: self.params.n_pcg_iters = int(b["num_iter_inner"])
+            if "robust_delta" in b: self.params.robust_delta = float(b["robust_delta"])
+            if "image_downscale" in b: self.params.image_downscale = float(b["image_downscale"])
+            if "max_dist" in p: self.params.dense_dist_thresh = float(p["max_dist"])
+            if "max_normal_angle" in p:
+                self.params.dense_normal_thresh = float(np.cos(float(p["max_normal_angle"]) / 180.0 * np.pi))
+        for k, v in overrides.items():
+            setattr(self.params, k, v)
+        self.workspace = workspace
+        self.last_stats: dict | None = None
+
+    def optimizeFrames(self, global_corres, n_match_per_pair, n_frames, H, W, depths_gpu, colors_gpu, normals_gpu, poses, K,
+                       dense_pairs=None):
+        """global_corres: ENTRYJ_DTYPE array; depths_gpu[k]: CUDA float32 [H,W]; normals_gpu[k]: CUDA float32
+        [H,W,4]; colors_gpu: ignored (weight 0 in the reference, SBA.cpp:32); poses: float32 [n_frames,4,4]
+        camera->model, updated IN PLACE like the reference's non-const reference argument; K: [3,3]."""
+        del colors_gpu
+        corr = np.ascontiguousarray(global_corres, ENTRYJ_DTYPE)
+        if len(depths_gpu) != n_frames or len(normals_gpu) != n_frames:
+            raise ValueError("need one depth and one normal buffer per frame")
+        for d, n in zip(depths_gpu, normals_gpu):
+            if not (d.is_cuda and n.is_cuda and d.dtype == _torch().float32 and n.dtype == _torch().float32 and d.is_contiguous() and n.is_contiguous()):
+                raise ValueError("depth/normal buffers must be contiguous float32 CUDA tensors")
+            if d.numel() != H * W or n.numel() != 4 * H * W:
+                raise ValueError("depth must hold H*W floats and normals H*W float4")
+        Kf = np.ascontiguousarray(K, np.float32).reshape(9)
+        nm = None if n_match_per_pair is None else np.ascontiguousarray(n_match_per_pair, np.int32)
+        P = np.ascontiguousarray(poses, np.float32).reshape(n_frames, 16).copy()
+        dp = None
+        if dense_pairs is not None:
+            dp = np.ascontiguousarray(dense_pairs, np.int32).reshape(-1, 2)
+        st = Stats()
+        dptr, nptr = _ptr_array(depths_gpu), _ptr_array(normals_gpu)
+        rc = lib().btba_optimize_frames(
+            self.workspace.handle if self.workspace else None, C.byref(self.params), n_frames, H, W, Kf.ctypes.data,
+            corr.ctypes.data if corr.shape[0] else None, corr.shape[0], nm.ctypes.data if nm is not None else None,
+            C.cast(dptr, C.c_void_p), C.cast(nptr, C.c_void_p),
+            dp.ctypes.data if dp is not None else None, dp.shape[0] if dp is not None else 0,
+            P.ctypes.data, C.byref(st))
+        check(rc, "btba_optimize_frames")
+        self.last_stats = st.as_dict()
+        np.asarray(poses)[...] = P.reshape(n_frames, 4, 4)
+        return poses
+
+
+def build_cache(ws: Workspace, depths_gpu, normals_gpu, H, W, K, image_downscale=4.0):
+    """CUDACache::storeFrame for all frames in one launch.  Returns (campos, normals, n_valid, intr):
+    CUDA tensors [N,Hd,Wd,4], [N,Hd,Wd,4], int32 [N] and a float32 numpy (fx,fy,cx,cy)."""
+    torch = _torch()
+    N = len(depths_gpu)
+    Wd, Hd = int(W / image_downscale), int(H / image_downscale)
+    dev = depths_gpu[0].device
+    campos = torch.empty((N, Hd, Wd, 4), dtype=torch.float32, device=dev)
+    normals = torch.empty((N, Hd, Wd, 4), dtype=torch.float32, device=dev)
+    nvalid = torch.zeros((N,), dtype=torch.int32, device=dev)
+    intr = np.zeros(4, np.float32)
+    Kf = np.ascontiguousarray(K, np.float32).reshape(9)
+    dptr, nptr = _ptr_array(depths_gpu), _ptr_array(normals_gpu)
+    check(lib().btba_build_cache(ws.handle, N, H, W, Kf.ctypes.data, float(image_downscale), C.cast(dptr, C.c_void_p), C.cast(nptr, C.c_void_p),
+                                 campos.data_ptr(), normals.data_ptr(), nvalid.data_ptr(), intr.ctypes.data), "btba_build_cache")
+    return campos, normals, nvalid, intr
+
+
+@dataclass
+class TraceView:
+    layout: TraceLayout
+    data: np.ndarray       # [B, n_gn, record]
+    n_frames: int
+    n_dense_pairs: int
+    n_pcg: int
+
+    def _get(self, off, size, shape):
+        return self.data[..., off:off + size].reshape(self.data.shape[:2] + shape)
+
+    @property
+    def x_after(self): return self._get(self.layout.off_x, 6 * self.n_frames, (self.n_frames, 6))
+    @property
+    def T_after(self): return self._get(self.layout.off_T, 16 * self.n_frames, (self.n_frames, 4, 4))
+    @property
+    def rhs(self): return self._get(self.layout.off_rhs, 6 * self.n_frames, (self.n_frames, 6))
+    @property
+    def precond(self): return self._get(self.layout.off_precond, 6 * self.n_frames, (self.n_frames, 6))
+    @property
+    def pcg_scalars(self): return self._get(self.layout.off_pcg, 4 * self.n_pcg, (self.n_pcg, 4))
+    @property
+    def delta(self): return self._get(self.layout.off_delta, 6 * self.n_frames, (self.n_frames, 6))
+    @property
+    def dense_pair(self): return self._get(self.layout.off_dense_pair, 28 * self.n_dense_pairs, (self.n_dense_pairs, 28))
+    @property
+    def A(self):
+        n = 6 * self.n_frames
+        return self._get(self.layout.off_A, n * n, (n, n))
+
+
+class BatchSolver:
+    """Batched, device-resident solve: many independent tracking instances in one grid
+    (btba_solve_batch; the solveBundlingStub seam of the reference, SolverBundling.cu:931)."""
+
+    def __init__(self, workspace: Workspace | None = None, **param_overrides):
+        self.ws = workspace or Workspace()
+        self.params = default_params(**param_overrides)
+
+    @staticmethod
+    def pack_correspondences(corr_list, n_frames):
+        """Host: bucket each instance's EntryJ pair-major; returns (corr [B, stride] ENTRYJ, offsets [B,P+1] u32, max_per_pair)."""
+        P = n_frames * (n_frames - 1) // 2
+        packed = [_lib.bucket_correspondences(c, n_frames) for c in corr_list]
+        stride = max(1, max(p[0].shape[0] for p in packed))
+        corr = np.zeros((len(packed), stride), ENTRYJ_DTYPE)
+        corr["imgIdx_i"] = 0xFFFFFFFF
+        corr["imgIdx_j"] = 0xFFFFFFFF
+        offs = np.zeros((len(packed), P + 1), np.uint32)
+        mx = 0
+        for b, (c, o) in enumerate(packed):
+            corr[b, : c.shape[0]] = c
+            offs[b] = o
+            if P:
+                mx = max(mx, int(np.diff(o.astype(np.int64)).max()))
+        return corr, offs, mx
+
+    def solve(self, campos, normals, intr, corr_dev, pair_offsets_dev, max_corr_per_pair, poses_dev, dense_pairs=None, trace=False):
+        """campos/normals: CUDA float32 [B,N,Hd,Wd,4]; corr_dev: CUDA uint8 view of EntryJ [B,stride,32];
+        pair_offsets_dev: CUDA int32/uint32 [B,P+1]; poses_dev: CUDA float32 [B,N,4,4] updated in place.
+        Asynchronous; call .ws.sync() / .ws.collect_stats().  Returns a device trace tensor or None."""
+        torch = _torch()
+        B, N, Hd, Wd = campos.shape[:4]
+        intr = np.ascontiguousarray(intr, np.float32)
+        stride = corr_dev.shape[1] if corr_dev is not None else 0
+        dp = None
+        npd = N * (N - 1) // 2
+        if dense_pairs is not None:
+            dp = np.ascontiguousarray(dense_pairs, np.int32).reshape(-1, 2)
+            npd = dp.shape[0]
+        tr = None
+        L = TraceLayout()
+        lib().btba_trace_layout_get(N, npd if self.params.weight_dense_depth > 0 else 0, self.params.n_pcg_iters, C.byref(L))
+        if trace:
+            self.params.flags |= _lib.FLAG_TRACE
+            tr = torch.zeros((B, self.params.n_gn_iters, L.record_floats), dtype=torch.float32, device=campos.device)
+        else:
+            self.params.flags &= ~_lib.FLAG_TRACE
+        rc = lib().btba_solve_batch(
+            self.ws.handle, C.byref(self.params), B, N, Hd, Wd, intr.ctypes.data,
+            campos.data_ptr(), normals.data_ptr(),
+            corr_dev.data_ptr() if corr_dev is not None else None, stride,
+            pair_offsets_dev.data_ptr() if pair_offsets_dev is not None else None, int(max_corr_per_pair),
+            dp.ctypes.data if dp is not None else None, dp.shape[0] if dp is not None else 0,
+            poses_dev.data_ptr(), tr.data_ptr() if tr is not None else None)
+        check(rc, "btba_solve_batch")
+        self._last_layout = (L, N, npd if self.params.weight_dense_depth > 0 else 0)
+        return tr
+
+    def trace_view(self, tr) -> TraceView:
+        L, N, npd = self._last_layout
+        self.ws.sync()
+        return TraceView(L, tr.cpu().numpy(), N, npd, self.params.n_pcg_iters)

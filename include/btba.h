@@ -1,0 +1,199 @@
+/*
+ * btba.h -- C ABI of the MI355X-native pose-graph bundle adjustment (libbtba.so).
+ *
+ * Drop-in boundary for BundleTrack's  OptimizerGpu::optimizeFrames
+ *   (/root/reference/src/cuda/LossGPU.h:40-52, LossGPU.cu:53-139; call site src/Bundler.cpp:350-351)
+ * and for the C-linkage seams underneath it
+ *   (solveBundlingStub, buildVariablesToCorrespondencesTableCUDA, convertLiePosesToMatricesCU:
+ *    src/cuda/Solver/CUDASolverBundling.cpp:8-16; convertMatricesToPosesCU / convertPosesToMatricesCU:
+ *    src/cuda/SBA.cpp:10-13).
+ *
+ * Plain C: pointers, sizes, PODs.  No torch / Eigen / YAML types.  Device pointers are raw HIP
+ * device addresses; `stream` arguments are hipStream_t passed as void*.  No entry point ever
+ * exits, aborts or spins (the reference does all three: cutil_inline_runtime.h:261-269,
+ * SolverBundling.cu:621-625): errors come back as an int status.
+ */
+#ifndef BTBA_H_
+#define BTBA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BTBA_VERSION 100
+
+#if defined(__GNUC__)
+#define BTBA_API __attribute__((visibility("default")))
+#else
+#define BTBA_API
+#endif
+
+/* ---- status codes ---------------------------------------------------------------------- */
+enum {
+    BTBA_OK       = 0,
+    BTBA_EINVAL   = 1,   /* bad argument (n_frames < 2, null pointer, unsorted batch correspondences, ...) */
+    BTBA_EHIP     = 2,   /* a HIP runtime call failed; btba_last_hip_error() has the hipError_t */
+    BTBA_ENUMERIC = 3,   /* a non-finite value reached the output poses */
+    BTBA_ENOMEM   = 4
+};
+
+/* ---- wire formats ---------------------------------------------------------------------- */
+/* struct EntryJ, src/cuda/SIFTImageManager.h:44-59: 32 bytes; invalid <=> imgIdx_i == 0xFFFFFFFF.
+ * pos_i / pos_j are the matched 3-D points in the camera frames of frame i / frame j
+ * (Bundler.cpp:311-316: i < j, pos_i = _ptB_cam, pos_j = _ptA_cam). */
+typedef struct btba_entryj {
+    uint32_t imgIdx_i;
+    uint32_t imgIdx_j;
+    float pos_i[3];
+    float pos_j[3];
+} btba_entryj;
+
+/* Dense pair orientation (the reference derives it from device
+ * allocation addresses, SolverBundling.cu:25-33, so it must be an explicit choice here). */
+enum {
+    BTBA_PAIRS_TARGET_LOWER      = 0,  /* every i<j once, target = i (BundleFusion behaviour; default) */
+    BTBA_PAIRS_TARGET_MORE_VALID = 1,  /* target = frame with more valid depth pixels, ties i<j; literal
+                                          FlipJtJ semantics: the cross block vanishes when target > source */
+    BTBA_PAIRS_EXPLICIT          = 2   /* caller passes the ordered (target, source) list */
+};
+
+enum {
+    BTBA_FLAG_TRACE        = 1,   /* record per-GN-iterate trace (btba_trace_layout)                    */
+    BTBA_FLAG_TIME_KERNELS = 2,   /* bracket every sweep / solve launch with hipEvents (btba_stats)    */
+    BTBA_FLAG_NO_GRAPH     = 4    /* launch kernels eagerly instead of replaying the captured hipGraph */
+};
+
+/* Solver parameters.  Defaults = shipping config of the reference:
+ *   config_ycbineoat.yml:23-31,63-65; SBA.cpp:27-32; CUDASolverBundling.cpp:93-98. */
+typedef struct btba_params {
+    int32_t n_gn_iters;           /* bundle.num_iter_outter      7      */
+    int32_t n_pcg_iters;          /* bundle.num_iter_inner       5      */
+    float   robust_delta;         /* bundle.robust_delta         0.005  */
+    float   dense_dist_thresh;    /* p2p.max_dist                0.02   */
+    float   dense_normal_thresh;  /* cos(p2p.max_normal_angle)   cos 45 deg */
+    float   depth_min;            /* denseDepthMin               0.1    */
+    float   depth_max;            /* denseDepthMax               9999   */
+    float   weight_sparse;        /* m_localWeightsSparse        1      */
+    float   weight_dense_depth;   /* m_localWeightsDenseDepth    1  (0 disables the dense term)       */
+    float   image_downscale;      /* bundle.image_downscale      4      */
+    int32_t pair_policy;          /* BTBA_PAIRS_*                                                       */
+    int32_t dense_tiles;          /* workgroups per dense frame pair (0 = auto)                        */
+    int32_t sparse_chunks;        /* workgroups per correspondence segment (0 = auto)                  */
+    int32_t flags;                /* BTBA_FLAG_*                                                        */
+} btba_params;
+
+/* Timing / diagnostics filled by the solve entry points (all times in milliseconds, measured
+ * with hipEvents on the workspace stream; per-kernel fields need BTBA_FLAG_TIME_KERNELS). */
+typedef struct btba_stats {
+    int32_t n_instances, n_frames, n_pairs, n_dense_pairs;
+    int64_t n_corr;               /* total correspondences over all instances                          */
+    int32_t dense_tiles, sparse_chunks;
+    float ms_total;               /* whole call, host wall clock                                       */
+    float ms_upload;              /* H2D of EntryJ + poses (optimize_frames only)                      */
+    float ms_cache;               /* frame cache build (A3)                                            */
+    float ms_solve;               /* pose-in -> pose-out region on the stream                          */
+    float ms_dense_sweep;         /* sum over GN iterations of the dense Jacobian sweep kernel         */
+    float ms_sparse_sweep;        /* ... of the sparse sweep kernel                                    */
+    float ms_system_solve;        /* ... of the assemble + PCG + update kernel                         */
+    int32_t n_dense_launches, n_sparse_launches, n_solve_launches;
+    int64_t bytes_dense_alg;      /* algorithmic bytes of ONE dense sweep launch  (64 * Pd * npix * B) */
+    int64_t bytes_sparse_alg;     /* algorithmic bytes of ONE sparse sweep launch (32 * C)             */
+} btba_stats;
+
+/* Per-instance, per-GN-iteration trace record (floats), written when BTBA_FLAG_TRACE is set.
+ * Record r = instance * n_gn_iters + iteration; record size = btba_trace_floats(...).
+ *   x_after     [N][6]   (rot, trans) after the update
+ *   T_after     [N][16]  Exp(x_after), row-major
+ *   rhs         [N][6]   (rRot, rTrans): PCG right-hand side  (frame 0 = 0)
+ *   precond     [N][6]   (precRot, precTrans)                 (frame 0 = 0)
+ *   pcg         [n_pcg][4]  pAp, alpha, rz_new, beta
+ *   delta       [N][6]   PCG solution (deltaRot, deltaTrans)
+ *   dense_pair  [Pd][28] S (21, upper triangle row-major of the 6x6 in [trans,rot] order), g (6), count
+ *   A           [6N][6N] assembled normal matrix (sparse + dense), reference dense layout
+ */
+typedef struct btba_trace_layout {
+    int64_t record_floats;
+    int64_t off_x, off_T, off_rhs, off_precond, off_pcg, off_delta, off_dense_pair, off_A;
+} btba_trace_layout;
+
+typedef struct btba_workspace btba_workspace;
+
+/* ---- API -------------------------------------------------------------------------------- */
+BTBA_API void btba_params_default(btba_params *p);
+BTBA_API const char *btba_strerror(int status);
+BTBA_API int btba_last_hip_error(void);
+BTBA_API int btba_version(void);
+
+/* One workspace = one HIP stream + reusable device scratch.  `stream` may be NULL (the
+ * workspace then creates and owns a non-blocking stream).  Re-entrant across workspaces. */
+BTBA_API int btba_workspace_create(btba_workspace **out, void *stream);
+BTBA_API void btba_workspace_destroy(btba_workspace *ws);
+BTBA_API int btba_workspace_sync(btba_workspace *ws);
+
+/* Drop-in for OptimizerGpu::optimizeFrames (LossGPU.cu:53-139).
+ *   corres_host       : n_corres EntryJ on the host (any order; pair-major order as produced by
+ *                       Bundler::optimizeGPU is used as is, anything else is bucketed by frame pair).
+ *   n_match_per_pair  : may be NULL (the reference stores it and never reads it, SBA.cpp:85).
+ *   depth_dev[k]      : device float[H*W], metres, 0 = invalid          (Frame.h:73)
+ *   normal_dev[k]     : device float4[H*W], xyz unit, w = 0, zeros = invalid (Frame.h:75)
+ *   poses_rowmajor    : host float[n_frames*16], camera->model, in/out  (LossGPU.cu:88-97,121-130)
+ *   K_rowmajor        : host float[9] full-resolution intrinsics
+ *   dense_pairs       : BTBA_PAIRS_EXPLICIT only: n_dense_pairs (target, source) int32 pairs, host.
+ * ws may be NULL: like the reference, everything is then allocated and freed inside the call.
+ * Synchronous: poses are valid on return. */
+BTBA_API int btba_optimize_frames(btba_workspace *ws, const btba_params *params,
+                         int n_frames, int H, int W, const float *K_rowmajor,
+                         const btba_entryj *corres_host, uint32_t n_corres, const int *n_match_per_pair,
+                         const float *const *depth_dev, const float *const *normal_dev,
+                         const int32_t *dense_pairs, int n_dense_pairs,
+                         float *poses_rowmajor, btba_stats *stats);
+
+/* Frame cache build alone (CUDACache::CUDACache + storeFrame, CUDACache.cpp:14-38,76-88).
+ * Outputs (device): campos float4[n_frames][Hd*Wd], normals float4[n_frames][Hd*Wd],
+ * n_valid int32[n_frames] (may be NULL); intr_out (host) = downscaled (fx, fy, cx, cy).
+ * Asynchronous on the workspace stream. */
+BTBA_API int btba_build_cache(btba_workspace *ws, int n_frames, int H, int W, const float *K_rowmajor,
+                     float image_downscale, const float *const *depth_dev, const float *const *normal_dev,
+                     float *campos_dev, float *normals_dev, int32_t *n_valid_dev, float *intr_out);
+
+/* Batched solve over device-resident instances that share n_frames and the cache resolution
+ * (the solveBundlingStub seam, SolverBundling.cu:931-1003, for many independent trackers).
+ *   campos_dev / normals_dev : float4 [n_instances][n_frames][Hd*Wd]
+ *   corr_dev                 : EntryJ [n_instances][corr_stride], each instance pair-major over the
+ *                              canonical pair order (0,1),(0,2)..(N-2,N-1)
+ *   pair_offsets_dev         : uint32 [n_instances][P+1] segment starts inside the instance's block
+ *   max_corr_per_pair        : upper bound of any segment length (sizes the launch)
+ *   poses_dev                : float [n_instances][n_frames][16] in/out
+ *   dense_pairs (host)       : ordered (target, source) list or NULL for TARGET_LOWER
+ *   trace_dev                : NULL or float [n_instances*n_gn_iters*record_floats]
+ * Asynchronous on the workspace stream; stats (if non-NULL) are complete after
+ * btba_workspace_sync() and a following btba_collect_stats(). */
+BTBA_API int btba_solve_batch(btba_workspace *ws, const btba_params *params,
+                     int n_instances, int n_frames, int Hd, int Wd, const float *intr,
+                     const float *campos_dev, const float *normals_dev,
+                     const btba_entryj *corr_dev, int64_t corr_stride,
+                     const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair,
+                     const int32_t *dense_pairs, int n_dense_pairs,
+                     float *poses_dev, float *trace_dev);
+BTBA_API int btba_collect_stats(btba_workspace *ws, btba_stats *stats);
+
+BTBA_API void btba_trace_layout_get(int n_frames, int n_dense_pairs, int n_pcg_iters, btba_trace_layout *out);
+
+/* Host helpers (A0/A6 side): bucket arbitrary EntryJ by canonical frame pair.
+ * out_sorted (n entries) and out_offsets (P+1) are host buffers.  Returns BTBA_EINVAL if an
+ * entry references a frame >= n_frames or has imgIdx_i >= imgIdx_j. Invalid entries are dropped
+ * (offsets[P] = number kept). */
+BTBA_API int btba_bucket_correspondences(const btba_entryj *in, uint32_t n, int n_frames,
+                                btba_entryj *out_sorted, uint32_t *out_offsets);
+
+/* SE(3) seams (convertMatricesToPosesCU / convertPosesToMatricesCU / convertLiePosesToMatricesCU)
+ * on device data; n transforms, x = (rot, trans) float[n][6]; any output may be NULL. */
+BTBA_API int btba_matrices_to_poses(btba_workspace *ws, int n, const float *T_dev, float *x_dev);
+BTBA_API int btba_poses_to_matrices(btba_workspace *ws, int n, const float *x_dev, float *T_dev, float *Tinv_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTBA_H_ */

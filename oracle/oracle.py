@@ -1,0 +1,224 @@
+"""ctypes binding of the CPU oracle (oracle/btba_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never from bundletrack_amd/.  PARITY UNPINNED: the
+reference has no golden vectors for this path; see the header of
+btba_oracle.c.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbtba_oracle.so")
+
+ENTRYJ_DTYPE = np.dtype(
+    [("imgIdx_i", "<u4"), ("imgIdx_j", "<u4"), ("pos_i", "<f4", (3,)), ("pos_j", "<f4", (3,))]
+)
+assert ENTRYJ_DTYPE.itemsize == 32
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("n_gn_iters", C.c_int32),
+        ("n_pcg_iters", C.c_int32),
+        ("robust_delta", C.c_float),
+        ("dense_dist_thresh", C.c_float),
+        ("dense_normal_thresh", C.c_float),
+        ("depth_min", C.c_float),
+        ("depth_max", C.c_float),
+        ("weight_sparse", C.c_float),
+        ("weight_dense_depth", C.c_float),
+        ("accum_mode", C.c_int32),
+        ("n_threads", C.c_int32),
+    ]
+
+
+class OrcTrace(C.Structure):
+    _fields_ = [
+        ("x_after", C.c_void_p),
+        ("T_after", C.c_void_p),
+        ("dense_JtJ", C.c_void_p),
+        ("dense_Jtr", C.c_void_p),
+        ("rhs", C.c_void_p),
+        ("precond", C.c_void_p),
+        ("pcg_scalars", C.c_void_p),
+        ("dense_count", C.c_void_p),
+        ("delta", C.c_void_p),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "btba_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_solve.restype = C.c_int
+        _lib.orc_build_cache.restype = C.c_int
+        _lib.orc_huber_weight.restype = C.c_float
+        _lib.orc_huber_weight.argtypes = [C.c_float, C.c_float]
+        _lib.orc_bilinear4.restype = C.c_int
+        _lib.orc_bilinear4.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**kw) -> OrcParams:
+    p = OrcParams()
+    lib().orc_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def pose_to_matrix(rot, trans) -> np.ndarray:
+    rot = np.ascontiguousarray(rot, np.float32)
+    trans = np.ascontiguousarray(trans, np.float32)
+    M = np.zeros(16, np.float32)
+    lib().orc_pose_to_matrix(_p(rot), _p(trans), _p(M))
+    return M.reshape(4, 4)
+
+
+def matrix_to_pose(M):
+    M = np.ascontiguousarray(M, np.float32).reshape(16)
+    r = np.zeros(3, np.float32)
+    t = np.zeros(3, np.float32)
+    lib().orc_matrix_to_pose(_p(M), _p(r), _p(t))
+    return r, t
+
+
+def mat4_inverse(M) -> np.ndarray:
+    M = np.ascontiguousarray(M, np.float32).reshape(16)
+    o = np.zeros(16, np.float32)
+    lib().orc_mat4_inverse(_p(M), _p(o))
+    return o.reshape(4, 4)
+
+
+def lie_update(dW, dT, cW, cT):
+    a = [np.ascontiguousarray(v, np.float32) for v in (dW, dT, cW, cT)]
+    nW = np.zeros(3, np.float32)
+    nT = np.zeros(3, np.float32)
+    lib().orc_lie_update(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(nW), _p(nT))
+    return nW, nT
+
+
+def lie_deriv(which: str, A, D, p) -> np.ndarray:
+    A = np.ascontiguousarray(A, np.float32).reshape(16)
+    D = np.ascontiguousarray(D, np.float32).reshape(16)
+    p = np.ascontiguousarray(p, np.float32)
+    jac = np.zeros(18, np.float32)
+    fn = lib().orc_lie_deriv_I if which == "I" else lib().orc_lie_deriv_J
+    fn(_p(A), _p(D), _p(p), _p(jac))
+    return jac.reshape(3, 6)
+
+
+def bilinear4(x, y, img) -> tuple[int, np.ndarray]:
+    img = np.ascontiguousarray(img, np.float32)
+    H, W = img.shape[:2]
+    out = np.zeros(4, np.float32)
+    ok = lib().orc_bilinear4(float(x), float(y), _p(img), W, H, _p(out))
+    return ok, out
+
+
+def huber_weight(e, delta) -> float:
+    return float(lib().orc_huber_weight(float(e), float(delta)))
+
+
+def build_cache(depth: np.ndarray, normals: np.ndarray, K: np.ndarray, downscale: float = 4.0):
+    """CUDACache::storeFrame for one frame.  depth [H,W] f32, normals [H,W,4] f32, K [3,3].
+    Returns dict(campos [Hd,Wd,4], normals [Hd,Wd,4], depth [Hd,Wd], n_valid, intr (fx,fy,cx,cy))."""
+    depth = np.ascontiguousarray(depth, np.float32)
+    normals = np.ascontiguousarray(normals, np.float32)
+    H, W = depth.shape
+    Wd, Hd = int(W / downscale), int(H / downscale)      # LossGPU.cu:56-57
+    Kf = np.ascontiguousarray(K, np.float32).reshape(9)
+    campos = np.zeros((Hd, Wd, 4), np.float32)
+    nrm = np.zeros((Hd, Wd, 4), np.float32)
+    dd = np.zeros((Hd, Wd), np.float32)
+    nv = C.c_int32(0)
+    intr = np.zeros(4, np.float32)
+    rc = lib().orc_build_cache(H, W, Hd, Wd, _p(Kf), _p(depth), _p(normals), _p(campos), _p(nrm), _p(dd), C.byref(nv), _p(intr))
+    if rc != 0:
+        raise ValueError("orc_build_cache failed")
+    return dict(campos=campos, normals=nrm, depth=dd, n_valid=int(nv.value), intr=intr)
+
+
+@dataclass
+class Trace:
+    x_after: np.ndarray
+    T_after: np.ndarray
+    dense_JtJ: np.ndarray
+    dense_Jtr: np.ndarray
+    rhs: np.ndarray
+    precond: np.ndarray
+    pcg_scalars: np.ndarray
+    dense_count: np.ndarray
+    delta: np.ndarray
+    poses: np.ndarray = field(default=None)
+
+
+def target_lower_pairs(n_frames: int) -> np.ndarray:
+    """TARGET_LOWER dense pair policy: every i<j once, target = i."""
+    return np.array([(i, j) for i in range(n_frames) for j in range(i + 1, n_frames)], np.int32).reshape(-1, 2)
+
+
+def solve(campos, normals, intr, corr, poses, pairs=None, params: OrcParams | None = None, want_trace=True) -> Trace:
+    """campos/normals [N,Hd,Wd,4]; intr (fx,fy,cx,cy) downscaled; corr ENTRYJ_DTYPE[C];
+    poses [N,4,4] row-major camera->model.  Returns Trace with .poses = optimised poses."""
+    campos = np.ascontiguousarray(campos, np.float32)
+    normals = np.ascontiguousarray(normals, np.float32)
+    N, Hd, Wd = campos.shape[:3]
+    prm = params or default_params()
+    corr = np.ascontiguousarray(corr, ENTRYJ_DTYPE)
+    if pairs is None:
+        pairs = target_lower_pairs(N)
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    P = pairs.shape[0]
+    poses_io = np.ascontiguousarray(poses, np.float32).reshape(N, 16).copy()
+    intr = np.ascontiguousarray(intr, np.float32)
+    G, L, dim = prm.n_gn_iters, prm.n_pcg_iters, 6 * N
+    t = Trace(
+        x_after=np.zeros((G, N, 6), np.float32), T_after=np.zeros((G, N, 4, 4), np.float32),
+        dense_JtJ=np.zeros((G, dim, dim), np.float32), dense_Jtr=np.zeros((G, dim), np.float32),
+        rhs=np.zeros((G, N, 6), np.float32), precond=np.zeros((G, N, 6), np.float32),
+        pcg_scalars=np.zeros((G, L, 4), np.float32), dense_count=np.zeros((G, max(P, 1)), np.int32),
+        delta=np.zeros((G, N, 6), np.float32),
+    )
+    ct = OrcTrace(*[_p(getattr(t, f[0])) for f in OrcTrace._fields_]) if want_trace else None
+    rc = lib().orc_solve(C.byref(prm), N, Wd, Hd, _p(intr), _p(campos), _p(normals), _p(corr), int(corr.shape[0]),
+                         _p(pairs), P, _p(poses_io), C.byref(ct) if ct is not None else None)
+    if rc != 0:
+        raise ValueError(f"orc_solve failed rc={rc}")
+    t.poses = poses_io.reshape(N, 4, 4)
+    return t
+
+
+def sparse_apply(corr, T, p, params: OrcParams | None = None) -> np.ndarray:
+    """Matrix-free sparse J^T J p exactly as PCGStep_Kernel0 + PCGStep_Kernel1a apply it."""
+    prm = params or default_params()
+    corr = np.ascontiguousarray(corr, ENTRYJ_DTYPE)
+    T = np.ascontiguousarray(T, np.float32)
+    N = T.shape[0]
+    p = np.ascontiguousarray(p, np.float32).reshape(N, 6)
+    out = np.zeros((N, 6), np.float32)
+    lib().orc_sparse_apply(C.byref(prm), N, _p(corr), int(corr.shape[0]), _p(T.reshape(N, 16)), _p(p), _p(out))
+    return out
