@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- Gauss-Newton iterations/s of the bundle-adjustment hot path on MI355X.
+
+A "step" = one pass of the hot path over one batch of synthetic input: `--instances` (default 32)
+independent tracking instances per GPU, each a BASELINE.json configs[2] problem (K=15 keyframes, 2 000
+correspondences per frame pair, feature + dense point-to-plane ICP residuals with Huber, 160x120 dense
+images, 7 Gauss-Newton x 5 PCG iterations), resident in HBM before the timed region.  32 per GPU is
+configs[4]'s share (256 instances over 8 GPUs): per-GPU work is fixed as N grows (weak scaling); the data
+path has no collective, one all-gather of {seconds, iterations} closes the run (RCCL via backend nccl).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+METRIC = "Gauss-Newton iters/sec (K=15, 2k corr/frame-pair) + achieved HBM GB/s"
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
+CONFIGS = {
+    "c2": dict(K=10, m=1000, w_dense=0.0, config=2, desc="K=10, 1k corr/pair, feature residuals only"),
+    "c3": dict(K=15, m=2000, w_dense=1.0, config=3, desc="K=15, 2k corr/pair, feature + dense point-to-plane ICP + Huber"),
+    "c4": dict(K=30, m=4000, w_dense=1.0, config=4, desc="K=30, 4k corr/pair, feature + dense point-to-plane ICP + Huber"),
+}
+
+
+def _gen(args):
+    from bundletrack_amd import synthetic as S
+    K, m, seed, masked = args
+    pb = S.make_problem(K, m, seed, background=not masked, full_res=False)
+    campos, normals, intr = S.analytic_cache(pb)
+    return dict(campos=campos, normals=normals, intr=intr, corr=pb.corr, poses=pb.poses_init)
+
+
+def generate_instances(cfg, ids, masked=False):
+    """Synthetic instances with seeds 1234 + 1000*config + instance, generated in parallel."""
+    from bundletrack_amd import synthetic as S
+    jobs = [(cfg["K"], cfg["m"], S.config_seed(5 if cfg["config"] == 3 else cfg["config"], i), masked) for i in ids]
+    nproc = min(len(jobs), max(1, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    if nproc > 1:
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            return pool.map(_gen, jobs)
+    return [_gen(j) for j in jobs]
+
+
+def cpu_baseline(cfg, inst, budget_s=20.0):
+    """The CPU oracle (a port: the reference has no CPU path) timed on this box's host cores on a bounded
+    sample of the same workload: whole solves of ONE instance, single-thread and all-threads."""
+    from oracle import oracle as O
+    ncpu = os.cpu_count() or 1
+    out = {}
+    for label, nt, share in (("1t", 1, 0.4), ("all", ncpu, 0.6)):
+        prm = O.default_params(weight_dense_depth=cfg["w_dense"], n_threads=nt)
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            O.solve(inst["campos"], inst["normals"], inst["intr"], inst["corr"], inst["poses"], params=prm, want_trace=False)
+            n += 1
+            if time.perf_counter() - t0 > budget_s * share or n >= 8:
+                break
+        dt = time.perf_counter() - t0
+        out[label] = (7.0 * n / dt, n, dt, nt)
+    best = max(out.values(), key=lambda v: v[0])
+    return {"value": round(best[0], 3), "unit": "GN iterations/s", "cores": best[3], "kind": "port",
+            "sample": f"{best[1]} full solves (7 GN x 5 PCG) of one {cfg['desc']} instance in {best[2]:.1f} s; "
+                      f"1 thread: {out['1t'][0]:.2f} it/s, {ncpu} threads: {out['all'][0]:.2f} it/s (gcc -O3 AVX2 + OpenMP, oracle/btba_oracle.c)",
+            "host_cpus": ncpu}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--instances", type=int, default=32, help="instances per GPU")
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic instances generated per GPU (tiled to --instances)")
+    ap.add_argument("--masked", action="store_true", help="realistic ~5%%-valid object mask instead of the 100%%-valid roofline variant")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--latency", action="store_true", help="also measure single-instance latency mode (extra field)")
+    args = ap.parse_args()
+
+    import torch
+    from bundletrack_amd import _lib, sharding
+    from bundletrack_amd.optimizer import BatchSolver, Workspace
+
+    rank, world, local = sharding.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    cfg = CONFIGS[args.config]
+    B, K = args.instances, cfg["K"]
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    n_distinct = max(1, min(args.distinct, B))
+    ids = [rank * B + i for i in range(n_distinct)]       # global instance ids of this rank's distinct seeds
+    inst = generate_instances(cfg, ids, args.masked)
+    pick = [inst[b % n_distinct] for b in range(B)]
+    ws = Workspace()
+    bs = BatchSolver(ws, weight_dense_depth=cfg["w_dense"])
+    if not args.no_kernel_timing:
+        bs.params.flags |= _lib.FLAG_TIME_KERNELS
+    corr, offs, mx = bs.pack_correspondences([p["corr"] for p in pick], K)
+    cam_d = torch.from_numpy(np.stack([p["campos"] for p in pick])).to(dev)
+    nrm_d = torch.from_numpy(np.stack([p["normals"] for p in pick])).to(dev)
+    corr_d = torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(dev)
+    offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
+    poses0 = torch.from_numpy(np.stack([p["poses"] for p in pick])).to(dev)
+    poses_d = poses0.clone()
+    intr = pick[0]["intr"]
+    n_corr = int(sum(len(p["corr"]) for p in pick))
+
+    def step():
+        poses_d.copy_(poses0)                               # pose in ...
+        bs.solve(cam_d, nrm_d, intr, corr_d, offs_d, mx, poses_d)   # ... pose out (7 GN iterations per instance)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if not args.no_kernel_timing:
+        ws.collect_stats()                                  # drop warm-up events
+    sharding.barrier(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    sharding.barrier(dev)
+    t1 = time.perf_counter()
+    seconds = t1 - t0
+    st = ws.collect_stats()
+    out_poses = poses_d.cpu().numpy()
+    assert np.isfinite(out_poses).all(), "non-finite poses"
+
+    gn_iters = float(B * bs.params.n_gn_iters * args.steps)
+    per_rank = sharding.gather_throughput(seconds, gn_iters, device=dev if world > 1 else "cpu")
+    value, slowest = sharding.aggregate(per_rank)
+
+    if rank == 0:
+        npix = cam_d.shape[2] * cam_d.shape[3]
+        P = K * (K - 1) // 2
+        res = {
+            "metric": METRIC, "value": round(value, 1), "unit": "GN iterations/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * slowest / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config} x {B} instances/GPU: {cfg['desc']}, 160x120 dense images, "
+                                   f"{'~5%-valid object mask' if args.masked else '100%-valid (object + background)'}, 7 GN x 5 PCG, pair policy TARGET_LOWER",
+                       "keyframes": K, "corr_per_pair": cfg["m"], "instances_per_gpu": B, "distinct_instances_per_gpu": n_distinct,
+                       "gn_iters": int(bs.params.n_gn_iters), "pcg_iters": int(bs.params.n_pcg_iters),
+                       "dense_tiles": st["dense_tiles"], "sparse_chunks": st["sparse_chunks"], "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+            "per_rank": [{"seconds": round(s, 6), "gn_iters": g} for s, g in per_rank],
+        }
+        if not args.no_kernel_timing and st["n_dense_launches"] > 0:
+            # dominant kernel = dense Jacobian sweep: algorithmic bytes per launch = 64 B x pairs x pixels x instances
+            # (source camPos+normal 32 B + target camPos+normal 32 B per pixel pair)
+            avg_ms = st["ms_dense_sweep"] / st["n_dense_launches"]
+            bytes_alg = 64 * P * npix * B
+            achieved = bytes_alg / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "dense_sweep_traffic.json")
+            if os.path.exists(tp):
+                try:
+                    tj = json.load(open(tp))
+                    if tj.get("instances") == B and tj.get("config") == args.config:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            res["roofline"] = {"bound": "hbm", "kernel": "k_dense_sweep", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_dense_launches"]}
+            res["kernels_ms_per_step"] = {
+                "dense_sweep": round(st["ms_dense_sweep"] / args.steps, 4), "sparse_sweep": round(st["ms_sparse_sweep"] / args.steps, 4),
+                "system_solve": round(st["ms_system_solve"] / args.steps, 4), "solve_region": round(st["ms_solve"] / args.steps, 4),
+                "sparse_alg_GBps": round(32 * n_corr / max(st["ms_sparse_sweep"] / max(st["n_sparse_launches"], 1), 1e-9) / 1e6, 1)}
+        elif cfg["w_dense"] == 0.0 and not args.no_kernel_timing and st["n_sparse_launches"] > 0:
+            avg_ms = st["ms_sparse_sweep"] / st["n_sparse_launches"]
+            achieved = 32 * n_corr / (avg_ms * 1e-3) / 1e9
+            res["roofline"] = {"bound": "hbm", "kernel": "k_sparse_sweep", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": 32 * n_corr,
+                               "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_sparse_launches"]}
+        if args.latency:
+            bs1 = BatchSolver(ws, weight_dense_depth=cfg["w_dense"])
+            c1, o1, m1 = bs1.pack_correspondences([pick[0]["corr"]], K)
+            c1d = torch.from_numpy(c1.view(np.uint8).reshape(1, -1, 32)).to(dev)
+            o1d = torch.from_numpy(o1.astype(np.int32)).to(dev)
+            p1 = poses0[:1].clone()
+            for _ in range(5):
+                p1.copy_(poses0[:1]); bs1.solve(cam_d[:1], nrm_d[:1], intr, c1d, o1d, m1, p1)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            reps = 50
+            for _ in range(reps):
+                p1.copy_(poses0[:1]); bs1.solve(cam_d[:1], nrm_d[:1], intr, c1d, o1d, m1, p1)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            res["single_instance"] = {"gn_iters_per_s": round(7 * reps / (tb - ta), 1), "ms_per_solve": round(1e3 * (tb - ta) / reps, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, inst[0])
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -143,7 +143,7 @@ def declared_symbols() -> list[str]:
     """Function names declared in include/btba.h (used by the ABI test)."""
     import re
     txt = open(HEADER).read()
-    return sorted(set(re.findall(r"\b(btba_[a-z_0-9]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"^BTBA_API[^;]*?\b(btba_[a-z_0-9]+)\s*\(", txt, flags=re.M)))
 
 
 def bucket_correspondences(corr: np.ndarray, n_frames: int):

@@ -59,10 +59,12 @@ struct btba_workspace {
     DevBuf x, T, Tinv, sparse_part, dense_part, pairsum, dense_pairs, ptrs;
     DevBuf corr, offsets, poses, campos, normals, nvalid;   // optimize_frames staging
     std::vector<int32_t> dense_pairs_host;                  // what dense_pairs currently holds
+    int dense_pairs_frames = -1;
     std::vector<EventPair> events;                          // pending timed regions
     std::vector<hipEvent_t> event_pool;
     btba_stats stats{};
     bool lds_attr_set = false;
+    bool always_time_region = false;   // optimize_frames: ms_solve is part of its stats contract
 
     hipEvent_t get_event()
     {
@@ -215,7 +217,7 @@ static int pick_chunks(const btba_params *prm, int B, int P, uint32_t max_corr_p
     if (prm->sparse_chunks > 0) return prm->sparse_chunks;
     if (max_corr_per_pair == 0) return 1;
     const long blocks = (long)B * P;
-    int want = (int)((1024 + blocks - 1) / blocks);
+    int want = (int)((512 + blocks - 1) / blocks);
     const int cap = (int)((max_corr_per_pair + kBlock - 1) / kBlock);
     if (want > cap) want = cap;
     if (want < 1) want = 1;
@@ -227,7 +229,7 @@ static int pick_tiles(const btba_params *prm, int B, int Pd, int npix)
     if (prm->dense_tiles > 0) return prm->dense_tiles;
     if (Pd == 0) return 1;
     const long blocks = (long)B * Pd;
-    int want = (int)((4096 + blocks - 1) / blocks);
+    int want = (int)((2048 + blocks - 1) / blocks);
     const int cap = (npix + kBlock - 1) / kBlock;
     if (want > cap) want = cap;
     if (want < 2) want = 2;
@@ -269,12 +271,25 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     if ((rc = ws->Tinv.ensure(sizeof(float) * 16 * (size_t)B * N))) return rc;
     if ((rc = ws->sparse_part.ensure(sizeof(float) * (size_t)B * P * chunks * kSparseVals))) return rc;
     if ((rc = ws->dense_part.ensure(sizeof(float) * (size_t)B * (Pd > 0 ? Pd : 1) * tiles * kDenseVals))) return rc;
-    if (Pd > 0 && pairs != ws->dense_pairs_host) {
-        if ((rc = ws->dense_pairs.ensure(sizeof(int32_t) * pairs.size()))) return rc;
-        HIP_TRY(hipMemcpyAsync(ws->dense_pairs.p, pairs.data(), sizeof(int32_t) * pairs.size(), hipMemcpyHostToDevice, ws->stream));
-        HIP_TRY(hipStreamSynchronize(ws->stream));         // `pairs` is a local; copy must land before it dies
+    // device table: [Pd x (target, source)] [N+1 adjacency offsets] [2 Pd adjacency entries = pair << 1 | is_source],
+    // adjacency of a frame listed in pair order (fixed summation order)
+    if (Pd > 0 && (pairs != ws->dense_pairs_host || ws->dense_pairs_frames != N)) {
+        std::vector<int32_t> tab(pairs);
+        std::vector<int32_t> off(N + 1, 0);
+        for (int q = 0; q < Pd; q++) { off[pairs[2 * q] + 1]++; off[pairs[2 * q + 1] + 1]++; }
+        for (int k = 0; k < N; k++) off[k + 1] += off[k];
+        std::vector<int32_t> adj(2 * (size_t)Pd), cur(off.begin(), off.end() - 1);
+        for (int q = 0; q < Pd; q++) { adj[cur[pairs[2 * q]]++] = (q << 1); adj[cur[pairs[2 * q + 1]]++] = (q << 1) | 1; }
+        tab.insert(tab.end(), off.begin(), off.end());
+        tab.insert(tab.end(), adj.begin(), adj.end());
+        if ((rc = ws->dense_pairs.ensure(sizeof(int32_t) * tab.size()))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws->dense_pairs.p, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice, ws->stream));
+        HIP_TRY(hipStreamSynchronize(ws->stream));         // `tab` is a local; the copy must land before it dies
         ws->dense_pairs_host = pairs;
+        ws->dense_pairs_frames = N;
     }
+    const int32_t *d_adj_off = ws->dense_pairs.as<int32_t>() + 2 * (size_t)Pd;
+    const int32_t *d_adj = d_adj_off + (N + 1);
 
     SolveDims D{};
     D.n_frames = N; D.n_pairs = P; D.n_dense_pairs = use_dense ? Pd : 0;
@@ -309,14 +324,14 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
 
     // stats bookkeeping (collected after sync)
     btba_stats &S = ws->stats;
-    std::memset(&S, 0, sizeof S);
+    if (ws->events.empty() || !timing) std::memset(&S, 0, sizeof S);     // new accumulation window
     S.n_instances = B; S.n_frames = N; S.n_pairs = P; S.n_dense_pairs = D.n_dense_pairs;
     S.dense_tiles = tiles; S.sparse_chunks = chunks;
     S.bytes_dense_alg = use_dense ? (int64_t)64 * D.n_dense_pairs * npix * B : 0;
     S.bytes_sparse_alg = 0;   // filled by callers that know C (optimize_frames) or from offsets on request
 
     size_t reg;
-    if ((rc = time_begin(ws, true, 3, &reg))) return rc;
+    if ((rc = time_begin(ws, timing || ws->always_time_region, 3, &reg))) return rc;
     // Log, Exp, inverse of the incoming matrices
     {
         const int total = B * N;
@@ -331,12 +346,12 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         }
         if (use_dense) {
             if ((rc = time_begin(ws, timing, 0, &slot))) return rc;
-            k_dense_sweep<<<dim3(tiles, D.n_dense_pairs, B), kBlock, 0, ws->stream>>>(D, reinterpret_cast<const float4 *>(campos), reinterpret_cast<const float4 *>(normals),
+            k_dense_sweep<<<dim3((unsigned)tiles * D.n_dense_pairs * B), kBlock, 0, ws->stream>>>(D, reinterpret_cast<const float4 *>(campos), reinterpret_cast<const float4 *>(normals),
                                                                                      ws->dense_pairs.as<int2>(), ws->T.as<float>(), ws->Tinv.as<float>(), ws->dense_part.as<float>());
             if ((rc = time_end(ws, slot))) return rc;
         }
         if ((rc = time_begin(ws, timing, 2, &slot))) return rc;
-        k_system_solve<<<B, kBlock, lds_bytes, ws->stream>>>(D, it, ws->sparse_part.as<float>(), ws->dense_part.as<float>(), ws->dense_pairs.as<int2>(),
+        k_system_solve<<<B, kBlock, lds_bytes, ws->stream>>>(D, it, ws->sparse_part.as<float>(), ws->dense_part.as<float>(), ws->dense_pairs.as<int2>(), d_adj_off, d_adj,
                                                              ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>(), ws->pairsum.as<float>(), trace);
         if ((rc = time_end(ws, slot))) return rc;
     }
@@ -372,6 +387,8 @@ int btba_collect_stats(btba_workspace *ws, btba_stats *stats)
     }
     ws->events.clear();
     if (stats) *stats = S;
+    S.ms_dense_sweep = S.ms_sparse_sweep = S.ms_system_solve = S.ms_solve = S.ms_cache = 0.0f;
+    S.n_dense_launches = S.n_sparse_launches = S.n_solve_launches = 0;
     return BTBA_OK;
 }
 
@@ -381,9 +398,12 @@ int btba_solve_batch(btba_workspace *ws, const btba_params *params, int n_instan
                      float *poses_dev, float *trace_dev)
 {
     if (!ws) return BTBA_EINVAL;
-    // drop stale timing events of a previous un-collected call
-    for (auto &ep : ws->events) { ws->event_pool.push_back(ep.a); ws->event_pool.push_back(ep.b); }
-    ws->events.clear();
+    // Timed regions accumulate over calls until btba_collect_stats(); without BTBA_FLAG_TIME_KERNELS nothing
+    // is recorded, so an un-collected caller does not grow the list.  A runaway list is recycled.
+    if (ws->events.size() > 65536) {
+        for (auto &ep : ws->events) { ws->event_pool.push_back(ep.a); ws->event_pool.push_back(ep.b); }
+        ws->events.clear();
+    }
     return solve_enqueue(ws, params, n_instances, n_frames, Hd, Wd, intr, campos_dev, normals_dev, corr_dev, corr_stride,
                          pair_offsets_dev, max_corr_per_pair, dense_pairs, dense_pairs ? n_dense_pairs : -1, poses_dev, trace_dev);
 }
@@ -514,9 +534,11 @@ int btba_optimize_frames(btba_workspace *ws_in, const btba_params *params_in, in
         return finish(BTBA_EINVAL);
     }
 
-    // keep cache-build timing event, then enqueue the solve (solve_enqueue resets stats)
+    // keep cache-build timing event, then enqueue the solve
+    ws->always_time_region = true;
     rc = solve_enqueue(ws, &prm, 1, N, Hd, Wd, intr, ws->campos.as<float>(), ws->normals.as<float>(), ws->corr.as<btba_entryj>(), (int64_t)(kept ? kept : 1),
                        ws->offsets.as<uint32_t>(), max_per_pair, pairs_ptr, n_pairs_dense, ws->poses.as<float>(), nullptr);
+    ws->always_time_region = false;
     if (rc) return finish(rc);
     std::vector<float> out(16 * (size_t)N);
     if ((e = hipMemcpyAsync(out.data(), ws->poses.p, sizeof(float) * 16 * N, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) return hip_fail(e);

@@ -124,6 +124,7 @@ __global__ void __launch_bounds__(kBlock) k_build_cache(int W, int H, int Wd, in
                                                        const float *const *__restrict__ depth, const float *const *__restrict__ normals,
                                                        float4 *__restrict__ campos_out, float4 *__restrict__ normals_out, int *__restrict__ n_valid)
 {
+#pragma clang fp contract(off)   // plain IEEE mul/add: the cache is bit-identical to the CPU oracle's
     const int f = blockIdx.y;
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     const int npix = Wd * Hd;
@@ -187,7 +188,8 @@ __global__ void __launch_bounds__(kBlock) k_sparse_sweep(SolveDims D, const floa
         xform_point(Ti, q0.z, q0.w, q1.x, wix, wiy, wiz);
         xform_point(Tj, q1.y, q1.z, q1.w, wjx, wjy, wjz);
         const float rx = wix - wjx, ry = wiy - wjy, rz = wiz - wjz;
-        const float rho = huber_weight(rx * rx + ry * ry + rz * rz, D.robust_delta);
+        const float e2 = rx * rx + ry * ry + rz * rz;
+        const float rho = (e2 <= D.robust_delta * D.robust_delta) ? 1.0f : D.robust_delta * __builtin_amdgcn_rsqf(e2);
         acc[0] += 1.0f;
         acc[1] += wix; acc[2] += wiy; acc[3] += wiz;
         acc[4] += wjx; acc[5] += wjy; acc[6] += wjz;
@@ -208,40 +210,59 @@ __global__ void __launch_bounds__(kBlock) k_sparse_sweep(SolveDims D, const floa
 }
 
 // ---- dense sweep ------------------------------------------------------------------------------
+// The reference is built with nvcc -use_fast_math (CMakeLists.txt:7): its divisions, sqrt and rsqrt are the
+// approximate hardware forms.  v_rcp_f32 / v_rsq_f32 (1 ulp) are the CDNA counterparts; an IEEE division
+// costs ~10 VALU instructions and this kernel had ~25 of them per pixel.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
 // bilinearInterpolationFloat4 (ICPUtil.h:83-110): out-of-image taps are skipped, zero (invalid)
-// taps are blended in, weights renormalised per row then per column.
-__device__ __forceinline__ bool bilinear4(const float4 *__restrict__ img, float x, float y, int W, int H, float4 &out)
+// taps are blended in, weights renormalised per row then per column.  xyz only: the w lane of the
+// cached float4s never reaches the residual (camPos.w is unused, normal.w is 0).
+__device__ __forceinline__ bool bilinear3(const float4 *__restrict__ img, float x, float y, int W, int H, float &ox, float &oy, float &oz, float &ow)
 {
     const float fx0 = floorf(x), fy0 = floorf(y);
     const int x0 = (int)fx0, y0 = (int)fy0;
-    const float alpha = x - (float)x0, beta = y - (float)y0;
+    const float alpha = x - fx0, beta = y - fy0;
     const bool okx0 = (unsigned)x0 < (unsigned)W, okx1 = (unsigned)(x0 + 1) < (unsigned)W;
     const bool oky0 = (unsigned)y0 < (unsigned)H, oky1 = (unsigned)(y0 + 1) < (unsigned)H;
     const float ninf = -INFINITY;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    float w0 = 0.f, w1 = 0.f;
-    if (okx0 && oky0) { const float4 v = img[y0 * W + x0]; if (v.x != ninf) { const float a = 1.0f - alpha; s0.x += a * v.x; s0.y += a * v.y; s0.z += a * v.z; s0.w += a * v.w; w0 += a; } }
-    if (okx1 && oky0) { const float4 v = img[y0 * W + x0 + 1]; if (v.x != ninf) { s0.x += alpha * v.x; s0.y += alpha * v.y; s0.z += alpha * v.z; s0.w += alpha * v.w; w0 += alpha; } }
-    if (okx0 && oky1) { const float4 v = img[(y0 + 1) * W + x0]; if (v.x != ninf) { const float a = 1.0f - alpha; s1.x += a * v.x; s1.y += a * v.y; s1.z += a * v.z; s1.w += a * v.w; w1 += a; } }
-    if (okx1 && oky1) { const float4 v = img[(y0 + 1) * W + x0 + 1]; if (v.x != ninf) { s1.x += alpha * v.x; s1.y += alpha * v.y; s1.z += alpha * v.z; s1.w += alpha * v.w; w1 += alpha; } }
-    float4 ss = make_float4(0.f, 0.f, 0.f, 0.f);
-    float ww = 0.f;
-    if (w0 > 0.0f) { const float bb = 1.0f - beta; ss.x += bb * (s0.x / w0); ss.y += bb * (s0.y / w0); ss.z += bb * (s0.z / w0); ss.w += bb * (s0.w / w0); ww += bb; }
-    if (w1 > 0.0f) { ss.x += beta * (s1.x / w1); ss.y += beta * (s1.y / w1); ss.z += beta * (s1.z / w1); ss.w += beta * (s1.w / w1); ww += beta; }
-    if (ww > 0.0f) { out = make_float4(ss.x / ww, ss.y / ww, ss.z / ww, ss.w / ww); return true; }
-    out = make_float4(ninf, ninf, ninf, ninf);
+    const float a0 = 1.0f - alpha;
+    float s0x = 0.f, s0y = 0.f, s0z = 0.f, s0w = 0.f, s1x = 0.f, s1y = 0.f, s1z = 0.f, s1w = 0.f, w0 = 0.f, w1 = 0.f;
+    const float4 *r0 = img + y0 * W + x0, *r1 = r0 + W;
+    if (okx0 && oky0) { const float4 v = r0[0]; if (v.x != ninf) { s0x += a0 * v.x; s0y += a0 * v.y; s0z += a0 * v.z; s0w += a0 * v.w; w0 += a0; } }
+    if (okx1 && oky0) { const float4 v = r0[1]; if (v.x != ninf) { s0x += alpha * v.x; s0y += alpha * v.y; s0z += alpha * v.z; s0w += alpha * v.w; w0 += alpha; } }
+    if (okx0 && oky1) { const float4 v = r1[0]; if (v.x != ninf) { s1x += a0 * v.x; s1y += a0 * v.y; s1z += a0 * v.z; s1w += a0 * v.w; w1 += a0; } }
+    if (okx1 && oky1) { const float4 v = r1[1]; if (v.x != ninf) { s1x += alpha * v.x; s1y += alpha * v.y; s1z += alpha * v.z; s1w += alpha * v.w; w1 += alpha; } }
+    float ssx = 0.f, ssy = 0.f, ssz = 0.f, ssw = 0.f, ww = 0.f;
+    if (w0 > 0.0f) { const float k = (1.0f - beta) * fast_rcp(w0); ssx += k * s0x; ssy += k * s0y; ssz += k * s0z; ssw += k * s0w; ww += 1.0f - beta; }
+    if (w1 > 0.0f) { const float k = beta * fast_rcp(w1); ssx += k * s1x; ssy += k * s1y; ssz += k * s1z; ssw += k * s1w; ww += beta; }
+    if (ww > 0.0f) { const float k = fast_rcp(ww); ox = ssx * k; oy = ssy * k; oz = ssz * k; ow = ssw * k; return true; }
+    ox = oy = oz = ow = ninf;
     return false;
 }
 
-// grid (dense_tiles, Pd, B).  Lane = consecutive source pixel (coalesced float4 loads of the
-// source camPos / normal); the four target taps are gathers that stay in L1/L2 because
-// neighbouring source pixels project to neighbouring target pixels.
+// XCD-aware remap of a 1-D grid: the dispatcher places block L on XCD L % 8 (observed, used for speed only),
+// so logical work item L' = (contiguous range per XCD) keeps one instance's frames in ONE XCD's L2 instead of
+// replicating them into all eight.
+__device__ __forceinline__ unsigned xcd_remap(unsigned L, unsigned n)
+{
+    const unsigned q = n >> 3, r = n & 7u, xcd = L & 7u, slot = L >> 3;
+    return xcd < r ? xcd * (q + 1) + slot : r * (q + 1) + (xcd - r) * q + slot;
+}
+
+// 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).  Lane = consecutive source pixel (coalesced
+// float4 loads of the source camPos / normal, next pixel prefetched); the four target taps are gathers that
+// stay in L1/L2 because neighbouring source pixels project to neighbouring target pixels.
 __global__ void __launch_bounds__(kBlock) k_dense_sweep(SolveDims D, const float4 *__restrict__ campos, const float4 *__restrict__ normals,
                                                        const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
                                                        float *__restrict__ partials)
 {
     __shared__ float red[4 * kDenseVals];
-    const int tile = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = (int)(L % (unsigned)D.dense_tiles);
+    const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
+    const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
     const int2 ij = dense_pairs[p];
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
@@ -253,14 +274,18 @@ __global__ void __launch_bounds__(kBlock) k_dense_sweep(SolveDims D, const float
     const float4 *cam_s = campos + (fb + fj) * (size_t)D.npix, *nrm_s = normals + (fb + fj) * (size_t)D.npix;
     const int per = (D.npix + D.dense_tiles - 1) / D.dense_tiles;
     const int lo = min(D.npix, per * tile), hi = min(D.npix, per * (tile + 1));
+    const float dist2_thresh = D.dist_thresh * D.dist_thresh;
     float acc[kDenseVals];
 #pragma unroll
     for (int k = 0; k < kDenseVals; k++) acc[k] = 0.0f;
 
-    for (int s = lo + threadIdx.x; s < hi; s += kBlock) {
-        const float4 cs = cam_s[s];
+    int s = lo + (int)threadIdx.x;
+    float4 cs_n = make_float4(0.f, 0.f, 0.f, 0.f), ns_n = cs_n;
+    if (s < hi) { cs_n = cam_s[s]; ns_n = nrm_s[s]; }
+    for (; s < hi; s += kBlock) {
+        const float4 cs = cs_n, ns = ns_n;
+        if (s + kBlock < hi) { cs_n = cam_s[s + kBlock]; ns_n = nrm_s[s + kBlock]; }
         if (!(cs.z > D.depth_min && cs.z < D.depth_max)) continue;
-        const float4 ns = nrm_s[s];
         if (!(ns.x != -INFINITY)) continue;
         // n' = Tij * float4(ns) (w = 0 for valid data -> rotation only), q = Tij * cs.xyz
         const float nqx = Tij.m[0] * ns.x + Tij.m[1] * ns.y + Tij.m[2] * ns.z + Tij.m[3] * ns.w;
@@ -269,27 +294,29 @@ __global__ void __launch_bounds__(kBlock) k_dense_sweep(SolveDims D, const float
         const float nqw = Tij.m[12] * ns.x + Tij.m[13] * ns.y + Tij.m[14] * ns.z + Tij.m[15] * ns.w;
         float qx, qy, qz;
         xform_point(Tij, cs.x, cs.y, cs.z, qx, qy, qz);
-        const float u = qx * D.fx / qz + D.cx;
-        const float v = qy * D.fy / qz + D.cy;
+        const float rqz = fast_rcp(qz);
+        const float u = qx * D.fx * rqz + D.cx;
+        const float v = qy * D.fy * rqz + D.cy;
         const int sx = (int)roundf(u), sy = (int)roundf(v);
         if (!(sx >= 0 && sy >= 0 && sx < D.width && sy < D.height)) continue;
-        float4 ci, ni;
-        bilinear4(cam_t, u, v, D.width, D.height, ci);
-        if (!(ci.z > D.depth_min && ci.z < D.depth_max)) continue;
-        bilinear4(nrm_t, u, v, D.width, D.height, ni);
-        if (!(ni.x != -INFINITY)) continue;
-        const float dx = qx - ci.x, dy = qy - ci.y, dz = qz - ci.z;
-        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float dn = nqx * ni.x + nqy * ni.y + nqz * ni.z + nqw * ni.w;
-        if (!(dn >= D.normal_thresh && dist <= D.dist_thresh)) continue;
-        const float res = (ci.x - qx) * ni.x + (ci.y - qy) * ni.y + (ci.z - qz) * ni.z;
-        const float wgt = D.w_dense * huber_weight(res * res, D.robust_delta);
+        float cix, ciy, ciz, ciw, nix, niy, niz, niw;
+        bilinear3(cam_t, u, v, D.width, D.height, cix, ciy, ciz, ciw);
+        if (!(ciz > D.depth_min && ciz < D.depth_max)) continue;
+        bilinear3(nrm_t, u, v, D.width, D.height, nix, niy, niz, niw);
+        if (!(nix != -INFINITY)) continue;
+        const float dx = qx - cix, dy = qy - ciy, dz = qz - ciz;
+        const float dist2 = dx * dx + dy * dy + dz * dz;
+        const float dn = nqx * nix + nqy * niy + nqz * niz + nqw * niw;
+        if (!(dn >= D.normal_thresh && dist2 <= dist2_thresh)) continue;
+        const float res = -(dx * nix + dy * niy + dz * niz);
+        const float e = res * res;
+        const float wgt = D.w_dense * ((e <= D.robust_delta * D.robust_delta) ? 1.0f : D.robust_delta * fast_rsq(e));
         // row_j = [-n_w ; n_w x w],  w = T_j c_j (model frame),  n_w = R_i n_i
         float wx, wy, wz;
         xform_point(Tj, cs.x, cs.y, cs.z, wx, wy, wz);
-        const float nx = Ti.m[0] * ni.x + Ti.m[1] * ni.y + Ti.m[2] * ni.z;
-        const float ny = Ti.m[4] * ni.x + Ti.m[5] * ni.y + Ti.m[6] * ni.z;
-        const float nz = Ti.m[8] * ni.x + Ti.m[9] * ni.y + Ti.m[10] * ni.z;
+        const float nx = Ti.m[0] * nix + Ti.m[1] * niy + Ti.m[2] * niz;
+        const float ny = Ti.m[4] * nix + Ti.m[5] * niy + Ti.m[6] * niz;
+        const float nz = Ti.m[8] * nix + Ti.m[9] * niy + Ti.m[10] * niz;
         const float a[6] = { -nx, -ny, -nz, ny * wz - nz * wy, nz * wx - nx * wz, nx * wy - ny * wx };
         int k = 0;
 #pragma unroll
@@ -297,9 +324,8 @@ __global__ void __launch_bounds__(kBlock) k_dense_sweep(SolveDims D, const float
             const float wa = wgt * a[r];
 #pragma unroll
             for (int c = r; c < 6; c++) acc[k++] += wa * a[c];
+            acc[21 + r] += wa * res;
         }
-#pragma unroll
-        for (int r = 0; r < 6; r++) acc[21 + r] += wgt * a[r] * res;
         acc[27] += 1.0f;
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
@@ -359,11 +385,24 @@ __device__ __forceinline__ float block_sum(float v, float *scratch)
     return t;
 }
 
+// sum of q[0], q[stride], ... (count terms) in index order, four loads issued before the adds
+__device__ __forceinline__ float strided_sum(const float *__restrict__ q, int count, int stride)
+{
+    float s = 0.0f;
+    int c = 0;
+    for (; c + 4 <= count; c += 4) {
+        const float a0 = q[(size_t)c * stride], a1 = q[(size_t)(c + 1) * stride], a2 = q[(size_t)(c + 2) * stride], a3 = q[(size_t)(c + 3) * stride];
+        s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; c < count; c++) s += q[(size_t)c * stride];
+    return s;
+}
+
 // grid (B); dynamic LDS: A[n*ld] + 7 vectors[n] + scratch + (optionally) reduced pair sums.
 // cross_ok[p] (dense) = 1 when the dense cross block survives FlipJtJ (target < source).
 __global__ void __launch_bounds__(kBlock) k_system_solve(SolveDims D, int iter,
                                                         const float *__restrict__ sparse_partials, const float *__restrict__ dense_partials,
-                                                        const int2 *__restrict__ dense_pairs,
+                                                        const int2 *__restrict__ dense_pairs, const int *__restrict__ adj_off, const int *__restrict__ adj,
                                                         float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv,
                                                         float *__restrict__ pairsum_global, float *__restrict__ trace)
 {
@@ -378,15 +417,12 @@ __global__ void __launch_bounds__(kBlock) k_system_solve(SolveDims D, int iter,
     float *pd = ps + (size_t)D.n_pairs * kSparseVals;
     float *tr = D.trace_on ? trace + ((size_t)b * D.n_gn + iter) * D.trace_record : nullptr;
 
-    // Phase A: fixed-order reduction of the sweep partials
+    // Phase A: fixed-order reduction of the sweep partials (4 independent loads in flight per lane)
     if (D.use_sparse) {
         const float *src = sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals;
         for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) {
             const int p = e / kSparseVals, k = e % kSparseVals;
-            const float *q = src + (size_t)p * D.sparse_chunks * kSparseVals + k;
-            float s = q[0];
-            for (int c = 1; c < D.sparse_chunks; c++) s += q[(size_t)c * kSparseVals];
-            ps[e] = s;
+            ps[e] = strided_sum(src + (size_t)p * D.sparse_chunks * kSparseVals + k, D.sparse_chunks, kSparseVals);
         }
     } else {
         for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) ps[e] = 0.0f;
@@ -395,10 +431,7 @@ __global__ void __launch_bounds__(kBlock) k_system_solve(SolveDims D, int iter,
         const float *src = dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals;
         for (int e = tid; e < D.n_dense_pairs * kDenseVals; e += nthr) {
             const int p = e / kDenseVals, k = e % kDenseVals;
-            const float *q = src + (size_t)p * D.dense_tiles * kDenseVals + k;
-            float s = q[0];
-            for (int c = 1; c < D.dense_tiles; c++) s += q[(size_t)c * kDenseVals];
-            pd[e] = s;
+            pd[e] = strided_sum(src + (size_t)p * D.dense_tiles * kDenseVals + k, D.dense_tiles, kDenseVals);
         }
     }
     for (int e = tid; e < n * ld; e += nthr) A[e] = 0.0f;
@@ -442,10 +475,8 @@ __global__ void __launch_bounds__(kBlock) k_system_solve(SolveDims D, int iter,
             }
         }
         if (D.use_dense) {
-            for (int p = 0; p < D.n_dense_pairs; p++) {
-                const int2 ij = dense_pairs[p];
-                if (ij.x == k || ij.y == k) v += pd[(size_t)p * kDenseVals + tri21(r, c)];
-            }
+            const int t21 = tri21(r, c);
+            for (int q = adj_off[k]; q < adj_off[k + 1]; q++) v += pd[(size_t)(adj[q] >> 1) * kDenseVals + t21];
         }
         A[(6 * k + r) * ld + 6 * k + c] = v;
     }
@@ -470,11 +501,10 @@ __global__ void __launch_bounds__(kBlock) k_system_solve(SolveDims D, int iter,
             }
             if (D.use_dense) {
                 float jtr = 0.0f;
-                for (int p = 0; p < D.n_dense_pairs; p++) {
-                    const int2 ij = dense_pairs[p];
-                    const float g = pd[(size_t)p * kDenseVals + 21 + r];
-                    if (ij.y == k) jtr += g;            // row_j = a
-                    else if (ij.x == k) jtr -= g;       // row_i = -a
+                for (int q = adj_off[k]; q < adj_off[k + 1]; q++) {
+                    const int a = adj[q];
+                    const float g = pd[(size_t)(a >> 1) * kDenseVals + 21 + r];
+                    jtr += (a & 1) ? g : -g;            // source frame: row_j = a;  target frame: row_i = -a
                 }
                 rhs -= jtr;
             }

@@ -1,0 +1,68 @@
+"""Multi-GPU scaling of the hot path: independent tracking instances sharded over ranks.
+
+One bundle-adjustment problem is tiny (<= 75 MB input, <= 174 unknowns) and its PCG is
+latency-bound, so it is never split.  Instances share nothing: instance n runs on
+rank n mod G, every rank keeps its instances resident in its own HBM and calls btba_solve_batch;
+the ONLY collective is an all-gather of {seconds, gn_iterations} per rank after the timed region
+(RCCL over xGMI on GPUs via backend "nccl"; gloo in the CPU tests).  The reference has no
+distributed code at all ("Parallelism strategies").
+"""
+from __future__ import annotations
+
+import os
+
+
+def instances_for_rank(n_instances: int, rank: int, world_size: int) -> list[int]:
+    """Instance n -> rank n mod G."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    return list(range(rank, n_instances, world_size))
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun).
+    Returns (rank, world_size, local_rank); world_size 1 needs no process group."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def barrier(device=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        if device is not None and str(device).startswith("cuda"):
+            dist.barrier(device_ids=[int(str(device).split(":")[1])] if ":" in str(device) else None)
+        else:
+            dist.barrier()
+
+
+def gather_throughput(seconds: float, gn_iters: float, device="cpu"):
+    """All-gather {seconds, gn_iters} of every rank (16 bytes per rank -- latency only).
+    Returns a list of (seconds, gn_iters) indexed by rank."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([float(seconds), float(gn_iters)], dtype=torch.float64, device=device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return [(float(mine[0]), float(mine[1]))]
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [(float(t[0]), float(t[1])) for t in out]
+
+
+def aggregate(per_rank):
+    """Whole-job throughput: total GN iterations / slowest rank's time."""
+    total = sum(g for _, g in per_rank)
+    slowest = max(s for s, _ in per_rank)
+    return total / slowest if slowest > 0 else float("nan"), slowest

@@ -239,3 +239,22 @@ def pose_error(Ta: np.ndarray, Tb: np.ndarray) -> tuple[float, float]:
     Ta = np.asarray(Ta, np.float64)
     Tb = np.asarray(Tb, np.float64)
     return rotation_angle(Ta[:3, :3], Tb[:3, :3]), float(np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]))
+
+
+def analytic_cache(pb: Problem):
+    """Frame cache (camPos float4, normals float4, downscaled intrinsics) computed on the host from the
+    depth/normals rendered at the cache's source pixels -- for benchmarks and property tests that do not
+    need the full-resolution frames.  Same formulas as CUDACache (CUDACache.cpp:20-24,
+    CUDAImageUtil.cu:310-327) in fp32; not guaranteed bit-identical to the device cache build."""
+    Hd, Wd = pb.cache_depth.shape[1:]
+    xi, yi = cache_source_pixels(pb.H, pb.W, Hd, Wd)
+    K = pb.K.astype(np.float32)
+    d = pb.cache_depth.astype(np.float32)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    x = (xi[None, None, :].astype(np.float32) * d) / fx - (cx / fx) * d
+    y = (yi[None, :, None].astype(np.float32) * d) / fy - (cy / fy) * d
+    campos = np.stack([x, y, d, np.ones_like(d)], -1).astype(np.float32)
+    campos[d < 0.1] = 0
+    intr = np.array([fx * (np.float32(Wd) / np.float32(pb.W)), fy * (np.float32(Hd) / np.float32(pb.H)),
+                     cx * (np.float32(Wd - 1) / np.float32(pb.W - 1)), cy * (np.float32(Hd - 1) / np.float32(pb.H - 1))], np.float32)
+    return campos, pb.cache_normals.astype(np.float32), intr

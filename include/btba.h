@@ -103,7 +103,7 @@ typedef struct btba_stats {
 } btba_stats;
 
 /* Per-instance, per-GN-iteration trace record (floats), written when BTBA_FLAG_TRACE is set.
- * Record r = instance * n_gn_iters + iteration; record size = btba_trace_floats(...).
+ * Record r = instance * n_gn_iters + iteration; record size = btba_trace_layout.record_floats.
  *   x_after     [N][6]   (rot, trans) after the update
  *   T_after     [N][16]  Exp(x_after), row-major
  *   rhs         [N][6]   (rRot, rTrans): PCG right-hand side  (frame 0 = 0)

@@ -1,0 +1,49 @@
+"""Generates tests/golden/*.npz.
+
+SELF-DERIVED fixtures: the reference repository contains no golden vectors, recorded solver I/O or
+tests for this path and cannot be executed here, so these files are outputs of THIS
+repo's CPU oracle (oracle/btba_oracle.c, accum_mode=1) on seeded synthetic problems.  They pin the
+oracle against regressions and give the GPU tests a fixed target; they do NOT pin parity with the
+reference -- parity stays "unpinned" (DESIGN.md section 3).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from bundletrack_amd import synthetic as S  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+CASES = {
+    # name: (n_frames, corr/pair, seed, background, weight_dense, weight_sparse)
+    "k3_sparse_dense_bg": (3, 80, 101, True, 1.0, 1.0),
+    "k4_sparse_dense_masked": (4, 60, 102, False, 1.0, 1.0),
+    "k4_sparse_only": (4, 100, 103, True, 0.0, 1.0),
+}
+
+
+def make(name):
+    n, m, seed, bg, wd, ws = CASES[name]
+    pb = S.make_problem(n, m, seed, background=bg, H=120, W=160, downscale=4,
+                        K=S.NOCS_K * np.array([[0.25], [0.25], [1.0]]))
+    caches = [O.build_cache(pb.depth[k], pb.normals[k], pb.K, 4.0) for k in range(n)]
+    campos = np.stack([c["campos"] for c in caches])
+    normals = np.stack([c["normals"] for c in caches])
+    prm = O.default_params(weight_dense_depth=wd, weight_sparse=ws, n_threads=1)
+    tr = O.solve(campos, normals, caches[0]["intr"], pb.corr, pb.poses_init, params=prm)
+    return dict(depth=pb.depth, normals_full=pb.normals, K=pb.K, campos=campos, normals=normals, intr=caches[0]["intr"],
+                corr=pb.corr.view(np.uint8).reshape(-1, 32), n_match_per_pair=pb.n_match_per_pair, poses_init=pb.poses_init,
+                weight_dense=np.float32(wd), weight_sparse=np.float32(ws),
+                T_after=tr.T_after, x_after=tr.x_after, dense_count=tr.dense_count, pcg_scalars=tr.pcg_scalars,
+                rhs=tr.rhs, precond=tr.precond, poses_out=tr.poses)
+
+
+if __name__ == "__main__":
+    for name in CASES:
+        d = make(name)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print(name, {k: v.shape for k, v in d.items() if hasattr(v, "shape") and v.ndim}, os.path.getsize(os.path.join(HERE, name + ".npz")) // 1024, "KiB")

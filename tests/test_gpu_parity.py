@@ -1,0 +1,346 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Tolerance: BASELINE.json's north star -- poses within 1e-4 rad / 1e-4 m of the reference arithmetic PER
+Gauss-Newton iterate (fp32 everywhere).  Index/byte work (frame cache, bucketing, match counts) is exact.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from bundletrack_amd import _lib, synthetic as S
+
+pytestmark = pytest.mark.gpu
+TOL_R, TOL_T = 1e-4, 1e-4
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available()
+    from bundletrack_amd.optimizer import BatchSolver, OptimizerGpu, Workspace, build_cache
+    ws = Workspace()
+
+    class G:
+        pass
+    g = G()
+    g.torch, g.ws, g.dev = torch, ws, torch.device("cuda:0")
+    g.BatchSolver, g.OptimizerGpu, g.build_cache = BatchSolver, OptimizerGpu, build_cache
+    # the native extension must be what runs: libbtba.so is loaded in-process
+    assert os.path.exists(_lib.LIB_PATH)
+    return g
+
+
+def upload_frames(g, pb):
+    d = [g.torch.from_numpy(pb.depth[k]).to(g.dev) for k in range(pb.n_frames)]
+    n = [g.torch.from_numpy(pb.normals[k]).to(g.dev) for k in range(pb.n_frames)]
+    return d, n
+
+
+def oracle_cache(oracle, pb):
+    caches = [oracle.build_cache(pb.depth[k], pb.normals[k], pb.K, pb.downscale) for k in range(pb.n_frames)]
+    return np.stack([c["campos"] for c in caches]), np.stack([c["normals"] for c in caches]), caches[0]["intr"], caches
+
+
+def batch_inputs(g, bs, campos, normals, corr_list, poses_list):
+    N = campos.shape[1]
+    corr, offs, mx = bs.pack_correspondences(corr_list, N)
+    B = len(corr_list)
+    corr_d = g.torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(g.dev)
+    offs_d = g.torch.from_numpy(offs.astype(np.int32)).to(g.dev)
+    poses_d = g.torch.from_numpy(np.stack(poses_list).astype(np.float32)).to(g.dev)
+    return corr_d, offs_d, mx, poses_d
+
+
+def assert_iterates_close(got_T, ref_T, tol_r=TOL_R, tol_t=TOL_T):
+    worst = (0.0, 0.0)
+    for it in range(ref_T.shape[0]):
+        for k in range(ref_T.shape[1]):
+            r, t = S.pose_error(got_T[it, k], ref_T[it, k])
+            worst = (max(worst[0], r), max(worst[1], t))
+            assert r < tol_r and t < tol_t, f"GN iterate {it} frame {k}: rot {r:.3e} trans {t:.3e}"
+    return worst
+
+
+def test_frame_cache_bit_exact(gpu, oracle, small_problem, small_problem_masked):
+    for pb in (small_problem, small_problem_masked):
+        d, n = upload_frames(gpu, pb)
+        campos, nrm, nvalid, intr = gpu.build_cache(gpu.ws, d, n, pb.H, pb.W, pb.K, 4.0)
+        gpu.ws.sync()
+        ocam, onrm, ointr, caches = oracle_cache(oracle, pb)
+        assert np.array_equal(intr.view(np.uint32), ointr.view(np.uint32))
+        assert np.array_equal(campos.cpu().numpy().view(np.uint32), ocam.view(np.uint32))
+        assert np.array_equal(nrm.cpu().numpy().view(np.uint32), onrm.view(np.uint32))
+        assert nvalid.cpu().numpy().tolist() == [c["n_valid"] for c in caches]
+
+
+def test_frame_cache_other_downscale_and_invalid_depth(gpu, oracle):
+    rng = np.random.default_rng(0)
+    H, W = 96, 128
+    depth = rng.uniform(0.05, 1.5, (2, H, W)).astype(np.float32)          # some below the 0.1 threshold
+    depth[:, :10] = 0
+    normals = rng.normal(size=(2, H, W, 4)).astype(np.float32); normals[..., 3] = 0
+    d = [gpu.torch.from_numpy(depth[k]).to(gpu.dev) for k in range(2)]
+    n = [gpu.torch.from_numpy(normals[k]).to(gpu.dev) for k in range(2)]
+    for ds in (2.0, 4.0, 8.0):
+        campos, nrm, nvalid, intr = gpu.build_cache(gpu.ws, d, n, H, W, S.NOCS_K, ds)
+        gpu.ws.sync()
+        for k in range(2):
+            c = oracle.build_cache(depth[k], normals[k], S.NOCS_K.astype(np.float32), ds)
+            assert np.array_equal(campos[k].cpu().numpy().view(np.uint32), c["campos"].view(np.uint32))
+            assert np.array_equal(nrm[k].cpu().numpy().view(np.uint32), c["normals"].view(np.uint32))
+            assert int(nvalid[k]) == c["n_valid"]
+
+
+def test_se3_seams(gpu, oracle):
+    """convertMatricesToPosesCU / convertPosesToMatricesCU / convertLiePosesToMatricesCU on the device."""
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    n = 64
+    x = np.concatenate([rng.normal(size=(n, 3)) * rng.uniform(1e-5, 3.0, (n, 1)) / 1.7, rng.uniform(-1, 1, (n, 3))], 1).astype(np.float32)
+    x[0, :3] = 0; x[1, :3] = [5e-5, 0, 0]; x[2, :3] = [5e-4, 1e-4, 0]     # series branches
+    x_d = gpu.torch.from_numpy(x).to(gpu.dev)
+    T_d = gpu.torch.zeros((n, 16), device=gpu.dev); Ti_d = gpu.torch.zeros((n, 16), device=gpu.dev); x2_d = gpu.torch.zeros((n, 6), device=gpu.dev)
+    L = _lib.lib()
+    _lib.check(L.btba_poses_to_matrices(gpu.ws.handle, n, x_d.data_ptr(), T_d.data_ptr(), Ti_d.data_ptr()), "p2m")
+    _lib.check(L.btba_matrices_to_poses(gpu.ws.handle, n, T_d.data_ptr(), x2_d.data_ptr()), "m2p")
+    gpu.ws.sync()
+    T, Ti, x2 = T_d.cpu().numpy().reshape(n, 4, 4), Ti_d.cpu().numpy().reshape(n, 4, 4), x2_d.cpu().numpy()
+    for k in range(n):
+        Tref = oracle.pose_to_matrix(x[k, :3], x[k, 3:])
+        assert np.abs(T[k] - Tref).max() < 2e-5          # (1-cos t)/t^2 cancellation amplifies libm ulps (see test_oracle_math)
+        assert np.abs(Ti[k] - oracle.mat4_inverse(Tref)).max() < 4e-5
+        r, t = oracle.matrix_to_pose(T[k])
+        assert np.abs(x2[k, :3] - r).max() < 2e-5 * max(1.0, np.linalg.norm(r)) and np.abs(x2[k, 3:] - t).max() < 3e-5
+
+
+@pytest.mark.parametrize("case", [
+    dict(K=3, m=120, seed=21, bg=True, wd=1.0, ws=1.0),
+    dict(K=5, m=300, seed=22, bg=True, wd=1.0, ws=1.0),
+    dict(K=4, m=200, seed=23, bg=False, wd=1.0, ws=1.0),      # realistic mask: ~5 % valid pixels
+    dict(K=6, m=150, seed=24, bg=True, wd=0.0, ws=1.0),       # sparse only (BASELINE config 2 shape)
+    dict(K=4, m=0, seed=25, bg=True, wd=1.0, ws=1.0),         # no feature matches at all: dense only
+    dict(K=2, m=500, seed=26, bg=True, wd=1.0, ws=1.0),
+], ids=lambda c: f"K{c['K']}_m{c['m']}_{'bg' if c['bg'] else 'mask'}_wd{c['wd']:g}")
+def test_parity_per_gn_iterate(gpu, oracle, case):
+    pb = S.make_problem(case["K"], case["m"], case["seed"], background=case["bg"])
+    ocam, onrm, ointr, _ = oracle_cache(oracle, pb)
+    ref = oracle.solve(ocam, onrm, ointr, pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=case["wd"], weight_sparse=case["ws"]))
+    bs = gpu.BatchSolver(gpu.ws, weight_dense_depth=case["wd"], weight_sparse=case["ws"])
+    cam_d, nrm_d = gpu.torch.from_numpy(ocam[None]).to(gpu.dev), gpu.torch.from_numpy(onrm[None]).to(gpu.dev)
+    corr_d, offs_d, mx, poses_d = batch_inputs(gpu, bs, ocam[None], onrm[None], [pb.corr], [pb.poses_init])
+    tr = bs.solve(cam_d, nrm_d, ointr, corr_d, offs_d, mx, poses_d, trace=True)
+    tv = bs.trace_view(tr)
+    assert_iterates_close(tv.T_after[0], ref.T_after)
+    if case["wd"] > 0:
+        P = case["K"] * (case["K"] - 1) // 2
+        cnt = tv.dense_pair[0, :, :, 27].astype(np.int64)
+        assert np.abs(cnt - ref.dense_count[:, :P]).max() <= 2        # accept/reject ties at the thresholds
+    # first linearisation (identical inputs): rhs / preconditioner / first PCG scalars agree tightly
+    assert np.abs(tv.rhs[0, 0] - ref.rhs[0]).max() <= 2e-4 * max(1e-6, np.abs(ref.rhs[0]).max())
+    assert np.abs(tv.precond[0, 0] - ref.precond[0]).max() <= 1e-4 * np.abs(ref.precond[0]).max()
+    if ref.pcg_scalars[0, 0, 0] > 0:
+        assert abs(tv.pcg_scalars[0, 0, 0, 1] - ref.pcg_scalars[0, 0, 1]) <= 1e-3 * abs(ref.pcg_scalars[0, 0, 1])
+    fin = poses_d.cpu().numpy()[0]
+    assert np.array_equal(fin, tv.T_after[0, -1])                     # output = Exp(x) of the last iterate
+
+
+def test_assembled_matrix_equals_reference_operator(gpu, oracle, small_problem):
+    """A (sparse part built from moment sums + dense S blocks) applied to a vector equals the reference's
+    matrix-free applyJ/applyJT plus its dense JtJ mat-vec (SolverBundlingEquationsLie.h:140-211,
+    SolverBundlingDenseUtil.h:349-385)."""
+    pb = small_problem
+    N = pb.n_frames
+    ocam, onrm, ointr, _ = oracle_cache(oracle, pb)
+    ref = oracle.solve(ocam, onrm, ointr, pb.corr, pb.poses_init, params=oracle.default_params(n_gn_iters=1))
+    bs = gpu.BatchSolver(gpu.ws, n_gn_iters=1)
+    cam_d, nrm_d = gpu.torch.from_numpy(ocam[None]).to(gpu.dev), gpu.torch.from_numpy(onrm[None]).to(gpu.dev)
+    corr_d, offs_d, mx, poses_d = batch_inputs(gpu, bs, ocam[None], onrm[None], [pb.corr], [pb.poses_init])
+    tv = bs.trace_view(bs.solve(cam_d, nrm_d, ointr, corr_d, offs_d, mx, poses_d, trace=True))
+    A = tv.A[0, 0].astype(np.float64)
+    assert np.abs(A - A.T).max() <= 1e-6 * np.abs(A).max()
+    assert np.all(A[:6] == 0) and np.all(A[:, :6] == 0)               # frame 0 is fixed
+    rng = np.random.default_rng(3)
+    p = rng.normal(size=(N, 6)).astype(np.float32); p[0] = 0           # (rot, trans)
+    # T at the linearisation point = Exp(Log(poses_init)) like the reference
+    T0 = np.stack([oracle.pose_to_matrix(*oracle.matrix_to_pose(pb.poses_init[k])) for k in range(N)])
+    sp = oracle.sparse_apply(pb.corr, T0, p).astype(np.float64)        # (rot, trans)
+    pv = np.concatenate([p[:, 3:], p[:, :3]], 1).reshape(-1).astype(np.float64)   # [trans, rot]
+    dense = (ref.dense_JtJ[0].astype(np.float64) @ pv).reshape(N, 6)
+    want = np.concatenate([sp[:, 3:], sp[:, :3]], 1) + dense
+    got = (A @ pv).reshape(N, 6)
+    assert np.abs(got[1:] - want[1:]).max() <= 3e-4 * np.abs(want).max()
+
+
+def test_drop_in_boundary_matches_oracle(gpu, oracle, small_problem_masked):
+    """OptimizerGpu::optimizeFrames: full-resolution device frames + host EntryJ + host poses in/out."""
+    pb = small_problem_masked
+    d, n = upload_frames(gpu, pb)
+    ocam, onrm, ointr, _ = oracle_cache(oracle, pb)
+    ref = oracle.solve(ocam, onrm, ointr, pb.corr, pb.poses_init)
+    poses = pb.poses_init.copy()
+    opt = gpu.OptimizerGpu({"bundle": {"num_iter_outter": 7, "num_iter_inner": 5, "robust_delta": 0.005, "image_downscale": 4},
+                            "p2p": {"max_dist": 0.02, "max_normal_angle": 45}})
+    out = opt.optimizeFrames(pb.corr, pb.n_match_per_pair, pb.n_frames, pb.H, pb.W, d, None, n, poses, pb.K)
+    assert out is poses                                             # in/out like the reference's `poses&`
+    for k in range(pb.n_frames):
+        r, t = S.pose_error(poses[k], ref.poses[k])
+        assert r < TOL_R and t < TOL_T
+    st = opt.last_stats
+    assert st["n_corr"] == len(pb.corr) and st["n_frames"] == pb.n_frames and st["ms_solve"] > 0
+    # stateless variant (ws = NULL: allocate and free inside the call, like the reference) gives identical bits
+    poses2 = pb.poses_init.copy()
+    gpu.OptimizerGpu(workspace=None).optimizeFrames(pb.corr, None, pb.n_frames, pb.H, pb.W, d, None, n, poses2, pb.K)
+    assert np.array_equal(poses, poses2)
+    # shuffled (non pair-major) correspondences with invalid entries sprinkled in: same optimum within tolerance
+    rng = np.random.default_rng(5)
+    corr = np.concatenate([pb.corr, pb.corr[:37]])
+    corr["imgIdx_i"][-37:] = 0xFFFFFFFF
+    corr = corr[rng.permutation(len(corr))]
+    poses3 = pb.poses_init.copy()
+    opt.optimizeFrames(corr, None, pb.n_frames, pb.H, pb.W, d, None, n, poses3, pb.K)
+    for k in range(pb.n_frames):
+        r, t = S.pose_error(poses3[k], ref.poses[k])
+        assert r < TOL_R and t < TOL_T
+
+
+def test_error_codes_not_exits(gpu, small_problem):
+    pb = small_problem
+    d, n = upload_frames(gpu, pb)
+    opt = gpu.OptimizerGpu(workspace=gpu.ws)
+    with pytest.raises(_lib.BtbaError) as e:                         # n_frames < 2: MLIB_ASSERT in the reference
+        opt.optimizeFrames(pb.corr[:0], None, 1, pb.H, pb.W, d[:1], None, n[:1], pb.poses_init[:1].copy(), pb.K)
+    assert e.value.status == _lib.BTBA_EINVAL
+    bad = pb.corr.copy(); bad["imgIdx_j"][3] = 99
+    with pytest.raises(_lib.BtbaError) as e:
+        opt.optimizeFrames(bad, None, pb.n_frames, pb.H, pb.W, d, None, n, pb.poses_init.copy(), pb.K)
+    assert e.value.status == _lib.BTBA_EINVAL
+    poses = pb.poses_init.copy(); poses[1, 0, 0] = np.nan
+    with pytest.raises(_lib.BtbaError) as e:
+        opt.optimizeFrames(pb.corr, None, pb.n_frames, pb.H, pb.W, d, None, n, poses, pb.K)
+    assert e.value.status == _lib.BTBA_ENUMERIC
+    assert np.isnan(poses[1, 0, 0])                                  # caller's buffer untouched on failure
+
+
+def test_pair_policies(gpu, oracle, small_problem_masked):
+    """TARGET_MORE_VALID / EXPLICIT orientation incl. the literal FlipJtJ erasure when target > source."""
+    pb = small_problem_masked
+    N = pb.n_frames
+    d, n = upload_frames(gpu, pb)
+    ocam, onrm, ointr, caches = oracle_cache(oracle, pb)
+    nv = [c["n_valid"] for c in caches]
+    pairs = np.array([(i, j) if nv[i] >= nv[j] else (j, i) for i in range(N) for j in range(i + 1, N)], np.int32)
+    ref = oracle.solve(ocam, onrm, ointr, pb.corr, pb.poses_init, pairs=pairs)
+    for policy, kw in ((_lib.PAIRS_TARGET_MORE_VALID, {}), (_lib.PAIRS_EXPLICIT, dict(dense_pairs=pairs))):
+        poses = pb.poses_init.copy()
+        opt = gpu.OptimizerGpu(workspace=gpu.ws, pair_policy=policy)
+        opt.optimizeFrames(pb.corr, None, N, pb.H, pb.W, d, None, n, poses, pb.K, **kw)
+        for k in range(N):
+            r, t = S.pose_error(poses[k], ref.poses[k])
+            assert r < TOL_R and t < TOL_T
+    # a reversed list (every target > source) must lose its cross blocks, exactly like the oracle's flip
+    rev = np.array([(j, i) for i in range(N) for j in range(i + 1, N)], np.int32)
+    ref2 = oracle.solve(ocam, onrm, ointr, pb.corr, pb.poses_init, pairs=rev)
+    poses = pb.poses_init.copy()
+    gpu.OptimizerGpu(workspace=gpu.ws, pair_policy=_lib.PAIRS_EXPLICIT).optimizeFrames(pb.corr, None, N, pb.H, pb.W, d, None, n, poses, pb.K, dense_pairs=rev)
+    for k in range(N):
+        r, t = S.pose_error(poses[k], ref2.poses[k])
+        assert r < TOL_R and t < TOL_T
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_golden_fixtures(gpu, path):
+    """Committed fixtures (self-derived, see tests/golden/make_golden.py): no oracle call at run time."""
+    gd = np.load(path)
+    corr = gd["corr"].view(_lib.ENTRYJ_DTYPE).reshape(-1)
+    bs = gpu.BatchSolver(gpu.ws, weight_dense_depth=float(gd["weight_dense"]), weight_sparse=float(gd["weight_sparse"]))
+    cam_d, nrm_d = gpu.torch.from_numpy(gd["campos"][None]).to(gpu.dev), gpu.torch.from_numpy(gd["normals"][None]).to(gpu.dev)
+    corr_d, offs_d, mx, poses_d = batch_inputs(gpu, bs, gd["campos"][None], gd["normals"][None], [corr], [gd["poses_init"]])
+    tv = bs.trace_view(bs.solve(cam_d, nrm_d, gd["intr"], corr_d, offs_d, mx, poses_d, trace=True))
+    assert_iterates_close(tv.T_after[0], gd["T_after"])
+    # full boundary on the stored full-resolution frames
+    N = gd["depth"].shape[0]
+    d = [gpu.torch.from_numpy(gd["depth"][k]).to(gpu.dev) for k in range(N)]
+    n = [gpu.torch.from_numpy(gd["normals_full"][k]).to(gpu.dev) for k in range(N)]
+    poses = gd["poses_init"].copy()
+    gpu.OptimizerGpu(workspace=gpu.ws, weight_dense_depth=float(gd["weight_dense"]), weight_sparse=float(gd["weight_sparse"])).optimizeFrames(
+        corr, gd["n_match_per_pair"], N, gd["depth"].shape[1], gd["depth"].shape[2], d, None, n, poses, gd["K"])
+    for k in range(N):
+        r, t = S.pose_error(poses[k], gd["poses_out"][k])
+        assert r < TOL_R and t < TOL_T
+
+
+def test_batch_equals_single_and_is_deterministic(gpu, oracle):
+    """Instances in one grid do not interact; repeated runs are bit-identical (no float atomics)."""
+    pbs = [S.make_problem(4, 180 + 20 * b, seed=40 + b, background=(b % 2 == 0)) for b in range(5)]   # ragged corr counts
+    cams, nrms, intr = [], [], None
+    for pb in pbs:
+        c, n_, intr, _ = oracle_cache(oracle, pb)
+        cams.append(c); nrms.append(n_)
+    bs = gpu.BatchSolver(gpu.ws)
+    cam_d, nrm_d = gpu.torch.from_numpy(np.stack(cams)).to(gpu.dev), gpu.torch.from_numpy(np.stack(nrms)).to(gpu.dev)
+    corr_d, offs_d, mx, poses_d = batch_inputs(gpu, bs, None if False else np.stack(cams), None, [pb.corr for pb in pbs], [pb.poses_init for pb in pbs])
+    p0 = poses_d.clone()
+    bs.solve(cam_d, nrm_d, intr, corr_d, offs_d, mx, poses_d)
+    gpu.ws.sync()
+    batch = poses_d.cpu().numpy()
+    poses_d2 = p0.clone()
+    bs.solve(cam_d, nrm_d, intr, corr_d, offs_d, mx, poses_d2)
+    gpu.ws.sync()
+    assert np.array_equal(batch, poses_d2.cpu().numpy())
+    for b, pb in enumerate(pbs):
+        ref = oracle.solve(cams[b], nrms[b], intr, pb.corr, pb.poses_init)
+        for k in range(4):
+            r, t = S.pose_error(batch[b, k], ref.poses[k])
+            assert r < TOL_R and t < TOL_T, (b, k, r, t)
+    # single-instance launch of instance 3 uses different tile/chunk counts -> same result within fp32 noise
+    one = p0[3:4].clone()
+    bs.solve(cam_d[3:4], nrm_d[3:4], intr, corr_d[3:4], offs_d[3:4], mx, one)
+    gpu.ws.sync()
+    for k in range(4):
+        r, t = S.pose_error(one.cpu().numpy()[0, k], batch[3, k])
+        assert r < 2e-5 and t < 2e-5
+
+
+def test_correspondence_order_invariance(gpu, oracle, small_problem):
+    """Property: shuffling correspondences inside their pair segments changes nothing beyond fp32 noise."""
+    pb = small_problem
+    ocam, onrm, ointr, _ = oracle_cache(oracle, pb)
+    bs = gpu.BatchSolver(gpu.ws)
+    cam_d, nrm_d = gpu.torch.from_numpy(ocam[None]).to(gpu.dev), gpu.torch.from_numpy(onrm[None]).to(gpu.dev)
+    rng = np.random.default_rng(7)
+    outs = []
+    for trial in range(3):
+        corr = pb.corr.copy()
+        if trial:
+            o = 0
+            for m in pb.n_match_per_pair:
+                corr[o:o + m] = corr[o:o + m][rng.permutation(m)]
+                o += m
+        corr_d, offs_d, mx, poses_d = batch_inputs(gpu, bs, ocam[None], onrm[None], [corr], [pb.poses_init])
+        bs.solve(cam_d, nrm_d, ointr, corr_d, offs_d, mx, poses_d)
+        gpu.ws.sync()
+        outs.append(poses_d.cpu().numpy()[0])
+    for o in outs[1:]:
+        for k in range(pb.n_frames):
+            r, t = S.pose_error(o[k], outs[0][k])
+            assert r < 2e-5 and t < 2e-5
+
+
+def test_tile_and_chunk_counts_do_not_change_the_result(gpu, oracle, small_problem):
+    pb = small_problem
+    ocam, onrm, ointr, _ = oracle_cache(oracle, pb)
+    cam_d, nrm_d = gpu.torch.from_numpy(ocam[None]).to(gpu.dev), gpu.torch.from_numpy(onrm[None]).to(gpu.dev)
+    outs = []
+    for tiles, chunks in ((1, 1), (3, 2), (25, 1), (75, 4)):
+        bs = gpu.BatchSolver(gpu.ws, dense_tiles=tiles, sparse_chunks=chunks)
+        corr_d, offs_d, mx, poses_d = batch_inputs(gpu, bs, ocam[None], onrm[None], [pb.corr], [pb.poses_init])
+        bs.solve(cam_d, nrm_d, ointr, corr_d, offs_d, mx, poses_d)
+        gpu.ws.sync()
+        outs.append(poses_d.cpu().numpy()[0])
+    for o in outs[1:]:
+        for k in range(pb.n_frames):
+            r, t = S.pose_error(o[k], outs[0][k])
+            assert r < 2e-5 and t < 2e-5

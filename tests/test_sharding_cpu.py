@@ -1,0 +1,65 @@
+"""world_size-2 gloo test of the N>1 path (instance sharding + the single throughput all-gather).
+The data path itself has no collective; on the GPU box the same code runs with backend nccl (= RCCL)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from bundletrack_amd import sharding
+
+
+def test_instances_for_rank_partitions_exactly():
+    for n, g in ((256, 8), (33, 4), (3, 8), (0, 2)):
+        got = [sharding.instances_for_rank(n, r, g) for r in range(g)]
+        flat = sorted(i for part in got for i in part)
+        assert flat == list(range(n))
+        assert max(len(p) for p in got) - min(len(p) for p in got) <= 1
+        for r, part in enumerate(got):
+            assert all(i % g == r for i in part)
+    with pytest.raises(ValueError):
+        sharding.instances_for_rank(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = sharding.init_from_env(backend="gloo")
+    mine = sharding.instances_for_rank(10, r, w)
+    sharding.barrier()
+    seconds = 0.5 + 0.25 * r                      # rank 1 is the slow one
+    per_rank = sharding.gather_throughput(seconds, 7.0 * len(mine))
+    total, slowest = sharding.aggregate(per_rank)
+    q.put((r, mine, per_rank, total, slowest))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4, 6, 8] and res[1][1] == [1, 3, 5, 7, 9]
+    for r in res:
+        assert r[2] == [(0.5, 35.0), (0.75, 35.0)]          # every rank sees every rank's numbers
+        assert abs(r[3] - 70.0 / 0.75) < 1e-9 and r[4] == 0.75   # whole-job rate = total work / slowest rank
+
+
+def test_single_process_needs_no_group():
+    assert sharding.gather_throughput(2.0, 14.0) == [(2.0, 14.0)]
+    assert sharding.aggregate([(2.0, 14.0)]) == (7.0, 2.0)
