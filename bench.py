@@ -47,7 +47,8 @@ def generate_instances(cfg, ids, masked=False):
     """Synthetic instances with seeds 1234 + 1000*config + instance, generated in parallel."""
     from bundletrack_amd import synthetic as S
     jobs = [(cfg["K"], cfg["m"], S.config_seed(5 if cfg["config"] == 3 else cfg["config"], i), masked) for i in ids]
-    nproc = min(len(jobs), max(1, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    nproc = min(len(jobs), 8, max(1, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    nproc = int(os.environ.get("BTBA_BENCH_NPROC", nproc))      # 1 under rocprofv3 --pmc (no child processes)
     if nproc > 1:
         import multiprocessing as mp
         with mp.get_context("spawn").Pool(nproc) as pool:

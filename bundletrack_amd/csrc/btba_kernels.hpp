@@ -216,32 +216,6 @@ __global__ void __launch_bounds__(kBlock) k_sparse_sweep(SolveDims D, const floa
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
-// bilinearInterpolationFloat4 (ICPUtil.h:83-110): out-of-image taps are skipped, zero (invalid)
-// taps are blended in, weights renormalised per row then per column.  xyz only: the w lane of the
-// cached float4s never reaches the residual (camPos.w is unused, normal.w is 0).
-__device__ __forceinline__ bool bilinear3(const float4 *__restrict__ img, float x, float y, int W, int H, float &ox, float &oy, float &oz, float &ow)
-{
-    const float fx0 = floorf(x), fy0 = floorf(y);
-    const int x0 = (int)fx0, y0 = (int)fy0;
-    const float alpha = x - fx0, beta = y - fy0;
-    const bool okx0 = (unsigned)x0 < (unsigned)W, okx1 = (unsigned)(x0 + 1) < (unsigned)W;
-    const bool oky0 = (unsigned)y0 < (unsigned)H, oky1 = (unsigned)(y0 + 1) < (unsigned)H;
-    const float ninf = -INFINITY;
-    const float a0 = 1.0f - alpha;
-    float s0x = 0.f, s0y = 0.f, s0z = 0.f, s0w = 0.f, s1x = 0.f, s1y = 0.f, s1z = 0.f, s1w = 0.f, w0 = 0.f, w1 = 0.f;
-    const float4 *r0 = img + y0 * W + x0, *r1 = r0 + W;
-    if (okx0 && oky0) { const float4 v = r0[0]; if (v.x != ninf) { s0x += a0 * v.x; s0y += a0 * v.y; s0z += a0 * v.z; s0w += a0 * v.w; w0 += a0; } }
-    if (okx1 && oky0) { const float4 v = r0[1]; if (v.x != ninf) { s0x += alpha * v.x; s0y += alpha * v.y; s0z += alpha * v.z; s0w += alpha * v.w; w0 += alpha; } }
-    if (okx0 && oky1) { const float4 v = r1[0]; if (v.x != ninf) { s1x += a0 * v.x; s1y += a0 * v.y; s1z += a0 * v.z; s1w += a0 * v.w; w1 += a0; } }
-    if (okx1 && oky1) { const float4 v = r1[1]; if (v.x != ninf) { s1x += alpha * v.x; s1y += alpha * v.y; s1z += alpha * v.z; s1w += alpha * v.w; w1 += alpha; } }
-    float ssx = 0.f, ssy = 0.f, ssz = 0.f, ssw = 0.f, ww = 0.f;
-    if (w0 > 0.0f) { const float k = (1.0f - beta) * fast_rcp(w0); ssx += k * s0x; ssy += k * s0y; ssz += k * s0z; ssw += k * s0w; ww += 1.0f - beta; }
-    if (w1 > 0.0f) { const float k = beta * fast_rcp(w1); ssx += k * s1x; ssy += k * s1y; ssz += k * s1z; ssw += k * s1w; ww += beta; }
-    if (ww > 0.0f) { const float k = fast_rcp(ww); ox = ssx * k; oy = ssy * k; oz = ssz * k; ow = ssw * k; return true; }
-    ox = oy = oz = ow = ninf;
-    return false;
-}
-
 // XCD-aware remap of a 1-D grid: the dispatcher places block L on XCD L % 8 (observed, used for speed only),
 // so logical work item L' = (contiguous range per XCD) keeps one instance's frames in ONE XCD's L2 instead of
 // replicating them into all eight.
@@ -251,10 +225,129 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned L, unsigned n)
     return xcd < r ? xcd * (q + 1) + slot : r * (q + 1) + (xcd - r) * q + slot;
 }
 
+// ---- per-pixel work of the dense sweep, branch-free so that all ten loads of a pixel (and of the second
+// pixel a lane handles in the same trip) are independent and in flight together -----------------------
+struct DenseCtx {
+    Mat4 Ti, Tj, Tij;
+    const float4 *cam_t, *nrm_t;
+    float fx, fy, cx, cy, depth_min, depth_max, normal_thresh, dist2_thresh, delta, delta2, w_dense;
+    int W, H;
+};
+
+struct Taps {                       // addresses and weights of the four bilinear taps (ICPUtil.h:83-110)
+    int i00, i10, i01, i11;
+    float a0, a1, b0, b1;           // (1-alpha), alpha with out-of-image taps zeroed; row weights (1-beta), beta
+    bool r0, r1;                    // row y0 / y0+1 inside the image
+};
+
+__device__ __forceinline__ Taps make_taps(float u, float v, int W, int H)
+{
+    Taps t;
+    const float fx0 = floorf(u), fy0 = floorf(v);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float alpha = u - fx0, beta = v - fy0;
+    const bool okx0 = (unsigned)x0 < (unsigned)W, okx1 = (unsigned)(x0 + 1) < (unsigned)W;
+    t.r0 = (unsigned)y0 < (unsigned)H; t.r1 = (unsigned)(y0 + 1) < (unsigned)H;
+    const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
+    const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
+    t.i00 = ya * W + xa; t.i10 = ya * W + xb; t.i01 = yb * W + xa; t.i11 = yb * W + xb;
+    t.a0 = okx0 ? 1.0f - alpha : 0.0f; t.a1 = okx1 ? alpha : 0.0f;
+    t.b0 = 1.0f - beta; t.b1 = beta;
+    return t;
+}
+
+// blend of four fetched taps; -inf-tagged taps are skipped like the reference does (never present in
+// practice: invalid data is zeros, which is blended in -- SURVEY.md appendix A.4 step 4)
+__device__ __forceinline__ bool blend4(const Taps &t, const float4 &v00, const float4 &v10, const float4 &v01, const float4 &v11,
+                                       float &ox, float &oy, float &oz, float &ow)
+{
+    const float ninf = -INFINITY;
+    const float w00 = (t.r0 && v00.x != ninf) ? t.a0 : 0.0f, w10 = (t.r0 && v10.x != ninf) ? t.a1 : 0.0f;
+    const float w01 = (t.r1 && v01.x != ninf) ? t.a0 : 0.0f, w11 = (t.r1 && v11.x != ninf) ? t.a1 : 0.0f;
+    const float w0 = w00 + w10, w1 = w01 + w11;
+    const float k0 = (w0 > 0.0f) ? t.b0 * fast_rcp(w0) : 0.0f, k1 = (w1 > 0.0f) ? t.b1 * fast_rcp(w1) : 0.0f;
+    const float ww = ((w0 > 0.0f) ? t.b0 : 0.0f) + ((w1 > 0.0f) ? t.b1 : 0.0f);
+    const float c00 = k0 * w00, c10 = k0 * w10, c01 = k1 * w01, c11 = k1 * w11;
+    const float kk = (ww > 0.0f) ? fast_rcp(ww) : 0.0f;
+    // zero-weight taps may hold anything finite (clamped re-reads) -> multiply is safe; data is finite by contract
+    ox = kk * (c00 * v00.x + c10 * v10.x + c01 * v01.x + c11 * v11.x);
+    oy = kk * (c00 * v00.y + c10 * v10.y + c01 * v01.y + c11 * v11.y);
+    oz = kk * (c00 * v00.z + c10 * v10.z + c01 * v01.z + c11 * v11.z);
+    ow = kk * (c00 * v00.w + c10 * v10.w + c01 * v01.w + c11 * v11.w);
+    return ww > 0.0f;
+}
+
+struct PixelGeom {                  // stage 1: everything that does not need the target taps
+    float qx, qy, qz, nqx, nqy, nqz, nqw, u, v;
+    bool valid;
+    Taps t;
+};
+
+__device__ __forceinline__ PixelGeom pixel_geom(const DenseCtx &C, bool in_range, const float4 &cs, const float4 &ns)
+{
+    PixelGeom g;
+    g.valid = in_range && (cs.z > C.depth_min && cs.z < C.depth_max) && (ns.x != -INFINITY);
+    const Mat4 &M = C.Tij;
+    g.nqx = M.m[0] * ns.x + M.m[1] * ns.y + M.m[2] * ns.z + M.m[3] * ns.w;
+    g.nqy = M.m[4] * ns.x + M.m[5] * ns.y + M.m[6] * ns.z + M.m[7] * ns.w;
+    g.nqz = M.m[8] * ns.x + M.m[9] * ns.y + M.m[10] * ns.z + M.m[11] * ns.w;
+    g.nqw = M.m[12] * ns.x + M.m[13] * ns.y + M.m[14] * ns.z + M.m[15] * ns.w;
+    xform_point(M, cs.x, cs.y, cs.z, g.qx, g.qy, g.qz);
+    const float rqz = fast_rcp(g.qz);
+    float u = g.qx * C.fx * rqz + C.cx, v = g.qy * C.fy * rqz + C.cy;
+    // NaN / inf / huge coordinates of rejected pixels must not reach the int conversion
+    const bool finite_uv = (fabsf(u) < 1.0e6f) && (fabsf(v) < 1.0e6f);
+    g.valid = g.valid && finite_uv;
+    u = g.valid ? u : 0.0f; v = g.valid ? v : 0.0f;
+    const int sx = (int)roundf(u), sy = (int)roundf(v);
+    g.valid = g.valid && (sx >= 0 && sy >= 0 && sx < C.W && sy < C.H);
+    g.u = u; g.v = v;
+    g.t = make_taps(u, v, C.W, C.H);
+    return g;
+}
+
+__device__ __forceinline__ void pixel_accumulate(const DenseCtx &C, const PixelGeom &g, const float4 &cs,
+                                                 const float4 &c00, const float4 &c10, const float4 &c01, const float4 &c11,
+                                                 const float4 &n00, const float4 &n10, const float4 &n01, const float4 &n11,
+                                                 float (&acc)[kDenseVals])
+{
+    float cix, ciy, ciz, ciw, nix, niy, niz, niw;
+    const bool okc = blend4(g.t, c00, c10, c01, c11, cix, ciy, ciz, ciw);
+    const bool okn = blend4(g.t, n00, n10, n01, n11, nix, niy, niz, niw);
+    (void)ciw;
+    bool ok = g.valid && okc && okn && (ciz > C.depth_min && ciz < C.depth_max);
+    const float dx = g.qx - cix, dy = g.qy - ciy, dz = g.qz - ciz;
+    const float dist2 = dx * dx + dy * dy + dz * dz;
+    const float dn = g.nqx * nix + g.nqy * niy + g.nqz * niz + g.nqw * niw;
+    ok = ok && (dn >= C.normal_thresh) && (dist2 <= C.dist2_thresh);
+    const float res = ok ? -(dx * nix + dy * niy + dz * niz) : 0.0f;
+    const float e = res * res;
+    const float wgt = ok ? C.w_dense * ((e <= C.delta2) ? 1.0f : C.delta * fast_rsq(e)) : 0.0f;
+    // row_j = [-n_w ; n_w x w],  w = T_j c_j (model frame),  n_w = R_i n_i
+    float wx, wy, wz;
+    xform_point(C.Tj, cs.x, cs.y, cs.z, wx, wy, wz);
+    const float nx = C.Ti.m[0] * nix + C.Ti.m[1] * niy + C.Ti.m[2] * niz;
+    const float ny = C.Ti.m[4] * nix + C.Ti.m[5] * niy + C.Ti.m[6] * niz;
+    const float nz = C.Ti.m[8] * nix + C.Ti.m[9] * niy + C.Ti.m[10] * niz;
+    float a[6] = { -nx, -ny, -nz, ny * wz - nz * wy, nz * wx - nx * wz, nx * wy - ny * wx };
+#pragma unroll
+    for (int r = 0; r < 6; r++) a[r] = ok ? a[r] : 0.0f;        // 0 * NaN would poison the sums
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const float wa = wgt * a[r];
+#pragma unroll
+        for (int c = r; c < 6; c++) acc[k++] += wa * a[c];
+        acc[21 + r] += wa * res;
+    }
+    acc[27] += ok ? 1.0f : 0.0f;
+}
+
 // 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).  Lane = consecutive source pixel (coalesced
-// float4 loads of the source camPos / normal, next pixel prefetched); the four target taps are gathers that
-// stay in L1/L2 because neighbouring source pixels project to neighbouring target pixels.
-__global__ void __launch_bounds__(kBlock) k_dense_sweep(SolveDims D, const float4 *__restrict__ campos, const float4 *__restrict__ normals,
+// float4 loads of the source camPos / normal); two pixels per lane per trip, sixteen target-tap gathers in
+// flight; the taps stay in L1/L2 because neighbouring source pixels project to neighbouring target pixels.
+template <int PIX, int WAVES>
+__global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, const float4 *__restrict__ campos, const float4 *__restrict__ normals,
                                                        const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
                                                        float *__restrict__ partials)
 {
@@ -266,67 +359,48 @@ __global__ void __launch_bounds__(kBlock) k_dense_sweep(SolveDims D, const float
     const int2 ij = dense_pairs[p];
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
-    const Mat4 Ti = load_mat4(T + 16 * (fb + fi));
-    const Mat4 Tj = load_mat4(T + 16 * (fb + fj));
-    const Mat4 Tii = load_mat4(Tinv + 16 * (fb + fi));
-    const Mat4 Tij = mat_mul(Tii, Tj);                    // source camera -> target camera
-    const float4 *cam_t = campos + (fb + fi) * (size_t)D.npix, *nrm_t = normals + (fb + fi) * (size_t)D.npix;
+    DenseCtx C;
+    C.Ti = load_mat4(T + 16 * (fb + fi));
+    C.Tj = load_mat4(T + 16 * (fb + fj));
+    C.Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), C.Tj);      // source camera -> target camera
+    C.cam_t = campos + (fb + fi) * (size_t)D.npix; C.nrm_t = normals + (fb + fi) * (size_t)D.npix;
+    C.fx = D.fx; C.fy = D.fy; C.cx = D.cx; C.cy = D.cy; C.depth_min = D.depth_min; C.depth_max = D.depth_max;
+    C.normal_thresh = D.normal_thresh; C.dist2_thresh = D.dist_thresh * D.dist_thresh;
+    C.delta = D.robust_delta; C.delta2 = D.robust_delta * D.robust_delta; C.w_dense = D.w_dense;
+    C.W = D.width; C.H = D.height;
     const float4 *cam_s = campos + (fb + fj) * (size_t)D.npix, *nrm_s = normals + (fb + fj) * (size_t)D.npix;
     const int per = (D.npix + D.dense_tiles - 1) / D.dense_tiles;
     const int lo = min(D.npix, per * tile), hi = min(D.npix, per * (tile + 1));
-    const float dist2_thresh = D.dist_thresh * D.dist_thresh;
     float acc[kDenseVals];
 #pragma unroll
     for (int k = 0; k < kDenseVals; k++) acc[k] = 0.0f;
 
-    int s = lo + (int)threadIdx.x;
-    float4 cs_n = make_float4(0.f, 0.f, 0.f, 0.f), ns_n = cs_n;
-    if (s < hi) { cs_n = cam_s[s]; ns_n = nrm_s[s]; }
-    for (; s < hi; s += kBlock) {
-        const float4 cs = cs_n, ns = ns_n;
-        if (s + kBlock < hi) { cs_n = cam_s[s + kBlock]; ns_n = nrm_s[s + kBlock]; }
-        if (!(cs.z > D.depth_min && cs.z < D.depth_max)) continue;
-        if (!(ns.x != -INFINITY)) continue;
-        // n' = Tij * float4(ns) (w = 0 for valid data -> rotation only), q = Tij * cs.xyz
-        const float nqx = Tij.m[0] * ns.x + Tij.m[1] * ns.y + Tij.m[2] * ns.z + Tij.m[3] * ns.w;
-        const float nqy = Tij.m[4] * ns.x + Tij.m[5] * ns.y + Tij.m[6] * ns.z + Tij.m[7] * ns.w;
-        const float nqz = Tij.m[8] * ns.x + Tij.m[9] * ns.y + Tij.m[10] * ns.z + Tij.m[11] * ns.w;
-        const float nqw = Tij.m[12] * ns.x + Tij.m[13] * ns.y + Tij.m[14] * ns.z + Tij.m[15] * ns.w;
-        float qx, qy, qz;
-        xform_point(Tij, cs.x, cs.y, cs.z, qx, qy, qz);
-        const float rqz = fast_rcp(qz);
-        const float u = qx * D.fx * rqz + D.cx;
-        const float v = qy * D.fy * rqz + D.cy;
-        const int sx = (int)roundf(u), sy = (int)roundf(v);
-        if (!(sx >= 0 && sy >= 0 && sx < D.width && sy < D.height)) continue;
-        float cix, ciy, ciz, ciw, nix, niy, niz, niw;
-        bilinear3(cam_t, u, v, D.width, D.height, cix, ciy, ciz, ciw);
-        if (!(ciz > D.depth_min && ciz < D.depth_max)) continue;
-        bilinear3(nrm_t, u, v, D.width, D.height, nix, niy, niz, niw);
-        if (!(nix != -INFINITY)) continue;
-        const float dx = qx - cix, dy = qy - ciy, dz = qz - ciz;
-        const float dist2 = dx * dx + dy * dy + dz * dz;
-        const float dn = nqx * nix + nqy * niy + nqz * niz + nqw * niw;
-        if (!(dn >= D.normal_thresh && dist2 <= dist2_thresh)) continue;
-        const float res = -(dx * nix + dy * niy + dz * niz);
-        const float e = res * res;
-        const float wgt = D.w_dense * ((e <= D.robust_delta * D.robust_delta) ? 1.0f : D.robust_delta * fast_rsq(e));
-        // row_j = [-n_w ; n_w x w],  w = T_j c_j (model frame),  n_w = R_i n_i
-        float wx, wy, wz;
-        xform_point(Tj, cs.x, cs.y, cs.z, wx, wy, wz);
-        const float nx = Ti.m[0] * nix + Ti.m[1] * niy + Ti.m[2] * niz;
-        const float ny = Ti.m[4] * nix + Ti.m[5] * niy + Ti.m[6] * niz;
-        const float nz = Ti.m[8] * nix + Ti.m[9] * niy + Ti.m[10] * niz;
-        const float a[6] = { -nx, -ny, -nz, ny * wz - nz * wy, nz * wx - nx * wz, nx * wy - ny * wx };
-        int k = 0;
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-            const float wa = wgt * a[r];
-#pragma unroll
-            for (int c = r; c < 6; c++) acc[k++] += wa * a[c];
-            acc[21 + r] += wa * res;
+    if (PIX == 2) {
+        for (int s = lo + (int)threadIdx.x; s < hi; s += 2 * kBlock) {
+            const int s2 = s + kBlock;
+            const bool in2 = s2 < hi;
+            const int s2c = in2 ? s2 : s;
+            const float4 csA = cam_s[s], nsA = nrm_s[s], csB = cam_s[s2c], nsB = nrm_s[s2c];
+            const PixelGeom gA = pixel_geom(C, true, csA, nsA), gB = pixel_geom(C, in2, csB, nsB);
+            const float4 cA00 = C.cam_t[gA.t.i00], cA10 = C.cam_t[gA.t.i10], cA01 = C.cam_t[gA.t.i01], cA11 = C.cam_t[gA.t.i11];
+            const float4 nA00 = C.nrm_t[gA.t.i00], nA10 = C.nrm_t[gA.t.i10], nA01 = C.nrm_t[gA.t.i01], nA11 = C.nrm_t[gA.t.i11];
+            const float4 cB00 = C.cam_t[gB.t.i00], cB10 = C.cam_t[gB.t.i10], cB01 = C.cam_t[gB.t.i01], cB11 = C.cam_t[gB.t.i11];
+            const float4 nB00 = C.nrm_t[gB.t.i00], nB10 = C.nrm_t[gB.t.i10], nB01 = C.nrm_t[gB.t.i01], nB11 = C.nrm_t[gB.t.i11];
+            pixel_accumulate(C, gA, csA, cA00, cA10, cA01, cA11, nA00, nA10, nA01, nA11, acc);
+            pixel_accumulate(C, gB, csB, cB00, cB10, cB01, cB11, nB00, nB10, nB01, nB11, acc);
         }
-        acc[27] += 1.0f;
+    } else {
+        int s = lo + (int)threadIdx.x;
+        float4 cs_n = make_float4(0.f, 0.f, 0.f, 0.f), ns_n = cs_n;
+        if (s < hi) { cs_n = cam_s[s]; ns_n = nrm_s[s]; }
+        for (; s < hi; s += kBlock) {
+            const float4 cs = cs_n, ns = ns_n;
+            if (s + kBlock < hi) { cs_n = cam_s[s + kBlock]; ns_n = nrm_s[s + kBlock]; }      // next pixel's stream loads
+            const PixelGeom g = pixel_geom(C, true, cs, ns);
+            const float4 c00 = C.cam_t[g.t.i00], c10 = C.cam_t[g.t.i10], c01 = C.cam_t[g.t.i01], c11 = C.cam_t[g.t.i11];
+            const float4 n00 = C.nrm_t[g.t.i00], n10 = C.nrm_t[g.t.i10], n01 = C.nrm_t[g.t.i01], n11 = C.nrm_t[g.t.i11];
+            pixel_accumulate(C, g, cs, c00, c10, c01, c11, n00, n10, n01, n11, acc);
+        }
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
     block_reduce_store<kDenseVals, 4>(acc, red, out);

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Profiles the bench workload on the GPU box with rocprofv3.  Writes under gpurun_out/prof_<tag>/ :
+#   stats/   --kernel-trace --stats            (per-kernel durations)
+#   fetch/   --kernel-trace --pmc FETCH_SIZE   (separate pass, as MI355X_MICROARCH.md prescribes)
+#   write/   --kernel-trace --pmc WRITE_SIZE
+# Usage: scripts/profile_bench.sh <tag> [bench args...]
+set -u
+TAG=${1:-r01}; shift || true
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+export BTBA_BENCH_NPROC=1
+ARGS="--steps 3 --warmup 1 --distinct 4 --no-cpu-baseline $*"
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$REPO/bench.py" $ARGS > "$OUT/stats.log" 2>&1
+echo "stats rc=$?" >> "$OUT/stats.log"
+timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o bench -- python "$REPO/bench.py" $ARGS --no-kernel-timing > "$OUT/fetch.log" 2>&1
+echo "fetch rc=$?" >> "$OUT/fetch.log"
+timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o bench -- python "$REPO/bench.py" $ARGS --no-kernel-timing > "$OUT/write.log" 2>&1
+echo "write rc=$?" >> "$OUT/write.log"
+# keep the merge small: drop the raw per-dispatch kernel traces of the PMC passes (the counter CSVs carry the kernel names)
+find "$OUT" -name "*kernel_trace.csv" -path "*fetch*" -delete
+find "$OUT" -name "*kernel_trace.csv" -path "*write*" -delete
+find "$OUT" -type f | head -50
+du -sh "$OUT"
