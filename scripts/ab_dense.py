@@ -6,32 +6,37 @@ from bundletrack_amd import _lib
 from bundletrack_amd.optimizer import BatchSolver, Workspace
 import bench
 
-cfg = bench.CONFIGS["c3"]
-os.environ.setdefault("BTBA_BENCH_NPROC", "4")
-inst = bench.generate_instances(cfg, [0, 1, 2, 3])
-dev = torch.device("cuda:0")
-ws = Workspace()
-for B in (int(a) for a in (sys.argv[1:] or ["32", "1"])):
-    pick = [inst[b % 4] for b in range(B)]
-    bs0 = BatchSolver(ws)
-    corr, offs, mx = bs0.pack_correspondences([p["corr"] for p in pick], 15)
-    cam_d = torch.from_numpy(np.stack([p["campos"] for p in pick])).to(dev); nrm_d = torch.from_numpy(np.stack([p["normals"] for p in pick])).to(dev)
-    corr_d = torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(dev); offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
-    poses0 = torch.from_numpy(np.stack([p["poses"] for p in pick])).to(dev)
-    ref = None
-    for name, flag in (("1pix/4wave", 0), ("1pix/3wave", 16), ("2pix/2wave", 8)):
-        for tiles in ((2, 3, 5) if B > 1 else (8, 15, 25, 40)):
-            bs = BatchSolver(ws, dense_tiles=tiles)
-            bs.params.flags |= _lib.FLAG_TIME_KERNELS | flag
-            poses_d = poses0.clone()
-            for _ in range(2):
-                poses_d.copy_(poses0); bs.solve(cam_d, nrm_d, pick[0]["intr"], corr_d, offs_d, mx, poses_d)
-            ws.sync(); ws.collect_stats()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                poses_d.copy_(poses0); bs.solve(cam_d, nrm_d, pick[0]["intr"], corr_d, offs_d, mx, poses_d)
-            ws.sync(); dt = (time.perf_counter() - t0) / 5
-            st = ws.collect_stats()
-            out = poses_d.cpu().numpy()
-            if ref is None: ref = out
-            print(f"B={B} {name} tiles={tiles}: step {dt*1e3:.3f} ms  dense {st['ms_dense_sweep']/st['n_dense_launches']*1e3:.1f} us/launch  sparse {st['ms_sparse_sweep']/st['n_sparse_launches']*1e3:.1f}  sys {st['ms_system_solve']/st['n_solve_launches']*1e3:.1f}  maxdiff {np.abs(out-ref).max():.2e}", flush=True)
+def main():
+    cfg = bench.CONFIGS["c3"]
+    os.environ["BTBA_BENCH_NPROC"] = "1"
+    inst = bench.generate_instances(cfg, [0, 1, 2, 3])
+    dev = torch.device("cuda:0")
+    ws = Workspace()
+    for B in (int(a) for a in (sys.argv[1:] or ["32", "1"])):
+        pick = [inst[b % 4] for b in range(B)]
+        bs0 = BatchSolver(ws)
+        corr, offs, mx = bs0.pack_correspondences([p["corr"] for p in pick], 15)
+        cam_d = torch.from_numpy(np.stack([p["campos"] for p in pick])).to(dev); nrm_d = torch.from_numpy(np.stack([p["normals"] for p in pick])).to(dev)
+        corr_d = torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(dev); offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
+        poses0 = torch.from_numpy(np.stack([p["poses"] for p in pick])).to(dev)
+        ref = None
+        for name, flag in (("1pix/4wave", 0), ("1pix/3wave", 16), ("2pix/2wave", 8)):
+            for tiles in ((2, 3, 5) if B > 1 else (8, 15, 25, 40)):
+                bs = BatchSolver(ws, dense_tiles=tiles)
+                bs.params.flags |= _lib.FLAG_TIME_KERNELS | flag
+                poses_d = poses0.clone()
+                for _ in range(2):
+                    poses_d.copy_(poses0); bs.solve(cam_d, nrm_d, pick[0]["intr"], corr_d, offs_d, mx, poses_d)
+                ws.sync(); ws.collect_stats()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    poses_d.copy_(poses0); bs.solve(cam_d, nrm_d, pick[0]["intr"], corr_d, offs_d, mx, poses_d)
+                ws.sync(); dt = (time.perf_counter() - t0) / 5
+                st = ws.collect_stats()
+                out = poses_d.cpu().numpy()
+                if ref is None: ref = out
+                print(f"B={B} {name} tiles={tiles}: step {dt*1e3:.3f} ms  dense {st['ms_dense_sweep']/st['n_dense_launches']*1e3:.1f} us/launch  sparse {st['ms_sparse_sweep']/st['n_sparse_launches']*1e3:.1f}  sys {st['ms_system_solve']/st['n_solve_launches']*1e3:.1f}  maxdiff {np.abs(out-ref).max():.2e}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
