@@ -64,7 +64,7 @@ enum {
     BTBA_FLAG_TIME_KERNELS = 2,   /* bracket every sweep / solve launch with hipEvents (btba_stats)    */
     BTBA_FLAG_NO_GRAPH     = 4,   /* launch kernels eagerly instead of replaying the captured hipGraph */
     BTBA_FLAG_DENSE_2PIX   = 8,   /* tuning: dense sweep variant with two pixels per lane per trip     */
-    BTBA_FLAG_DENSE_3WAVE  = 16   /* tuning: one pixel per trip, register budget for 3 waves per SIMD  */
+    BTBA_FLAG_DENSE_4WAVE  = 16   /* tuning: one pixel per trip, registers capped for 4 waves per SIMD (spills) */
 };
 
 /* Solver parameters.  Defaults = shipping config of the reference:

@@ -20,7 +20,7 @@ def main():
         corr_d = torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(dev); offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
         poses0 = torch.from_numpy(np.stack([p["poses"] for p in pick])).to(dev)
         ref = None
-        for name, flag in (("1pix/4wave", 0), ("1pix/3wave", 16), ("2pix/2wave", 8)):
+        for name, flag in (("1pix/3wave", 0), ("1pix/4wave", 16), ("2pix/2wave", 8)):
             for tiles in ((2, 3, 5) if B > 1 else (8, 15, 25, 40)):
                 bs = BatchSolver(ws, dense_tiles=tiles)
                 bs.params.flags |= _lib.FLAG_TIME_KERNELS | flag
