@@ -355,7 +355,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             if ((rc = time_end(ws, slot))) return rc;
         }
         if ((rc = time_begin(ws, timing, 2, &slot))) return rc;
-        k_system_solve<<<B, kBlock, lds_bytes, ws->stream>>>(D, it, ws->sparse_part.as<float>(), ws->dense_part.as<float>(), ws->dense_pairs.as<int2>(), d_adj_off, d_adj,
+        k_system_solve<<<B, kSolveBlock, lds_bytes, ws->stream>>>(D, it, ws->sparse_part.as<float>(), ws->dense_part.as<float>(), ws->dense_pairs.as<int2>(), d_adj_off, d_adj,
                                                              ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>(), ws->pairsum.as<float>(), trace);
         if ((rc = time_end(ws, slot))) return rc;
     }

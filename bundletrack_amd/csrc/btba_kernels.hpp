@@ -27,7 +27,8 @@
 
 namespace btba {
 
-constexpr int kBlock = 256;          // 4 waves
+constexpr int kBlock = 256;          // 4 waves (sweeps)
+constexpr int kSolveBlock = 1024;    // 16 waves: the per-instance solve is latency-bound serial phases, so go wide
 constexpr int kSparseVals = 44;      // per-pair sparse partial record
 constexpr int kDenseVals = 28;       // per-pair dense partial record: S(21) g(6) count(1)
 constexpr float kEps = 0.000001f;    // FLOAT_EPSILON, SolverUtil.h:10
@@ -474,7 +475,7 @@ __device__ __forceinline__ float strided_sum(const float *__restrict__ q, int co
 
 // grid (B); dynamic LDS: A[n*ld] + 7 vectors[n] + scratch + (optionally) reduced pair sums.
 // cross_ok[p] (dense) = 1 when the dense cross block survives FlipJtJ (target < source).
-__global__ void __launch_bounds__(kBlock) k_system_solve(SolveDims D, int iter,
+__global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int iter,
                                                         const float *__restrict__ sparse_partials, const float *__restrict__ dense_partials,
                                                         const int2 *__restrict__ dense_pairs, const int *__restrict__ adj_off, const int *__restrict__ adj,
                                                         float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv,
@@ -607,16 +608,17 @@ __global__ void __launch_bounds__(kBlock) k_system_solve(SolveDims D, int iter,
     }
     for (int li = 0; li < D.n_pcg; li++) {
         __syncthreads();
-        // Ap = A p : 4 lanes per row
+        // Ap = A p : 8 lanes per row (128 rows per pass)
         {
-            const int seg = tid & 3;
+            const int seg = tid & 7;
             float part_pAp = 0.0f;
-            for (int row = tid >> 2; row < n; row += nthr >> 2) {
+            for (int row = tid >> 3; row < n; row += nthr >> 3) {
                 const float *ar = A + (size_t)row * ld;
                 float s = 0.0f;
-                for (int c = seg; c < n; c += 4) s += ar[c] * vp[c];
+                for (int c = seg; c < n; c += 8) s += ar[c] * vp[c];
                 s = dpp_add<0xB1, 0xf>(s);
                 s = dpp_add<0x4E, 0xf>(s);
+                s = dpp_add<0x141, 0xf>(s);
                 if (seg == 0) { vAp[row] = s; part_pAp += vp[row] * s; }
             }
             const float pAp = block_sum(part_pAp, scratch);
