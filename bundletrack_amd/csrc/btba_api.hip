@@ -310,7 +310,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
 
     const size_t n = 6 * (size_t)N, ld = n | 1;
     const size_t lds_core = (n * ld + 6 * n + 16) * sizeof(float);
-    const size_t lds_pairs = ((size_t)P * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals) * sizeof(float);
+    const size_t lds_pairs = ((size_t)P * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals) * sizeof(float);
     const size_t lds_limit = 160 * 1024;
     D.pairsum_in_lds = (lds_core + lds_pairs <= 64 * 1024) ? 1 : 0;   // keep two workgroups per CU when it fits
     if (!D.pairsum_in_lds && lds_core + lds_pairs <= lds_limit && B <= 256) D.pairsum_in_lds = 1;

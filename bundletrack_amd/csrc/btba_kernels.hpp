@@ -226,113 +226,89 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned L, unsigned n)
     return xcd < r ? xcd * (q + 1) + slot : r * (q + 1) + (xcd - r) * q + slot;
 }
 
-// ---- per-pixel work of the dense sweep, branch-free so that all ten loads of a pixel (and of the second
-// pixel a lane handles in the same trip) are independent and in flight together -----------------------
+// ---- per-pixel work of the dense sweep, branch-free so that all ten loads of a pixel are independent and
+// in flight together.  The kernel is VALU-bound (PMC: VALU pipe ~87 % busy at 283 instructions per pixel),
+// so the per-pixel arithmetic is kept minimal:
+//   * the Jacobian row is accumulated in the TARGET CAMERA frame, a' = [-n_i ; n_i x q]; the model-frame row
+//     of the reference is a = M a' with the constant per-pair 6x6  M = [[R_i, 0], [[t_i]x R_i, R_i]]
+//     (n_w = R_i n_i, w = R_i q + t_i  =>  n_w x w = R_i (n_i x q) + [t_i]x R_i (-n_i)), so
+//     S = M S' M^T and g = M g' are applied once per pair in k_system_solve instead of 18 FMAs per pixel;
+//   * one set of bilinear tap coefficients serves camPos and normals (same taps, same in-image tests);
+//   * the -inf sentinel tests of ICPUtil.h:96-102 are dropped: the cache never contains -inf (invalid data is
+//     zeros and is blended in -- SURVEY.md appendix A.4 step 4; the reference notes the test never fires);
+//   * the w lanes are not fetched: camPos.w is never used and normal.w is 0 by the wire format (Frame.h:75).
 struct DenseCtx {
-    Mat4 Ti, Tj, Tij;
+    Mat4 Tij;
     const float4 *cam_t, *nrm_t;
     float fx, fy, cx, cy, depth_min, depth_max, normal_thresh, dist2_thresh, delta, delta2, w_dense;
     int W, H;
 };
 
-struct Taps {                       // addresses and weights of the four bilinear taps (ICPUtil.h:83-110)
-    int i00, i10, i01, i11;
-    float a0, a1, b0, b1;           // (1-alpha), alpha with out-of-image taps zeroed; row weights (1-beta), beta
-    bool r0, r1;                    // row y0 / y0+1 inside the image
-};
-
-__device__ __forceinline__ Taps make_taps(float u, float v, int W, int H)
-{
-    Taps t;
-    const float fx0 = floorf(u), fy0 = floorf(v);
-    const int x0 = (int)fx0, y0 = (int)fy0;
-    const float alpha = u - fx0, beta = v - fy0;
-    const bool okx0 = (unsigned)x0 < (unsigned)W, okx1 = (unsigned)(x0 + 1) < (unsigned)W;
-    t.r0 = (unsigned)y0 < (unsigned)H; t.r1 = (unsigned)(y0 + 1) < (unsigned)H;
-    const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
-    const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
-    t.i00 = ya * W + xa; t.i10 = ya * W + xb; t.i01 = yb * W + xa; t.i11 = yb * W + xb;
-    t.a0 = okx0 ? 1.0f - alpha : 0.0f; t.a1 = okx1 ? alpha : 0.0f;
-    t.b0 = 1.0f - beta; t.b1 = beta;
-    return t;
-}
-
-// blend of four fetched taps; -inf-tagged taps are skipped like the reference does (never present in
-// practice: invalid data is zeros, which is blended in -- SURVEY.md appendix A.4 step 4)
-__device__ __forceinline__ bool blend4(const Taps &t, const float4 &v00, const float4 &v10, const float4 &v01, const float4 &v11,
-                                       float &ox, float &oy, float &oz, float &ow)
-{
-    const float ninf = -INFINITY;
-    const float w00 = (t.r0 && v00.x != ninf) ? t.a0 : 0.0f, w10 = (t.r0 && v10.x != ninf) ? t.a1 : 0.0f;
-    const float w01 = (t.r1 && v01.x != ninf) ? t.a0 : 0.0f, w11 = (t.r1 && v11.x != ninf) ? t.a1 : 0.0f;
-    const float w0 = w00 + w10, w1 = w01 + w11;
-    const float k0 = (w0 > 0.0f) ? t.b0 * fast_rcp(w0) : 0.0f, k1 = (w1 > 0.0f) ? t.b1 * fast_rcp(w1) : 0.0f;
-    const float ww = ((w0 > 0.0f) ? t.b0 : 0.0f) + ((w1 > 0.0f) ? t.b1 : 0.0f);
-    const float c00 = k0 * w00, c10 = k0 * w10, c01 = k1 * w01, c11 = k1 * w11;
-    const float kk = (ww > 0.0f) ? fast_rcp(ww) : 0.0f;
-    // zero-weight taps may hold anything finite (clamped re-reads) -> multiply is safe; data is finite by contract
-    ox = kk * (c00 * v00.x + c10 * v10.x + c01 * v01.x + c11 * v11.x);
-    oy = kk * (c00 * v00.y + c10 * v10.y + c01 * v01.y + c11 * v11.y);
-    oz = kk * (c00 * v00.z + c10 * v10.z + c01 * v01.z + c11 * v11.z);
-    ow = kk * (c00 * v00.w + c10 * v10.w + c01 * v01.w + c11 * v11.w);
-    return ww > 0.0f;
-}
-
 struct PixelGeom {                  // stage 1: everything that does not need the target taps
-    float qx, qy, qz, nqx, nqy, nqz, nqw, u, v;
+    float qx, qy, qz, nqx, nqy, nqz;
+    float c00, c10, c01, c11;       // final bilinear coefficients (row/column renormalisation folded in)
+    int i00, i10, i01, i11;
     bool valid;
-    Taps t;
 };
 
-__device__ __forceinline__ PixelGeom pixel_geom(const DenseCtx &C, bool in_range, const float4 &cs, const float4 &ns)
+__device__ __forceinline__ PixelGeom pixel_geom(const DenseCtx &C, const float4 &cs, const float4 &ns)
 {
     PixelGeom g;
-    g.valid = in_range && (cs.z > C.depth_min && cs.z < C.depth_max) && (ns.x != -INFINITY);
+    g.valid = (cs.z > C.depth_min && cs.z < C.depth_max);
     const Mat4 &M = C.Tij;
-    g.nqx = M.m[0] * ns.x + M.m[1] * ns.y + M.m[2] * ns.z + M.m[3] * ns.w;
-    g.nqy = M.m[4] * ns.x + M.m[5] * ns.y + M.m[6] * ns.z + M.m[7] * ns.w;
-    g.nqz = M.m[8] * ns.x + M.m[9] * ns.y + M.m[10] * ns.z + M.m[11] * ns.w;
-    g.nqw = M.m[12] * ns.x + M.m[13] * ns.y + M.m[14] * ns.z + M.m[15] * ns.w;
+    g.nqx = M.m[0] * ns.x + M.m[1] * ns.y + M.m[2] * ns.z;
+    g.nqy = M.m[4] * ns.x + M.m[5] * ns.y + M.m[6] * ns.z;
+    g.nqz = M.m[8] * ns.x + M.m[9] * ns.y + M.m[10] * ns.z;
     xform_point(M, cs.x, cs.y, cs.z, g.qx, g.qy, g.qz);
     const float rqz = fast_rcp(g.qz);
     float u = g.qx * C.fx * rqz + C.cx, v = g.qy * C.fy * rqz + C.cy;
     // NaN / inf / huge coordinates of rejected pixels must not reach the int conversion
-    const bool finite_uv = (fabsf(u) < 1.0e6f) && (fabsf(v) < 1.0e6f);
-    g.valid = g.valid && finite_uv;
+    g.valid = g.valid && (fabsf(u) < 1.0e6f) && (fabsf(v) < 1.0e6f);
     u = g.valid ? u : 0.0f; v = g.valid ? v : 0.0f;
     const int sx = (int)roundf(u), sy = (int)roundf(v);
     g.valid = g.valid && (sx >= 0 && sy >= 0 && sx < C.W && sy < C.H);
-    g.u = u; g.v = v;
-    g.t = make_taps(u, v, C.W, C.H);
+    // bilinear taps (ICPUtil.h:83-110): out-of-image taps get weight 0, weights renormalised per row, then per column
+    const float fx0 = floorf(u), fy0 = floorf(v);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float alpha = u - fx0, beta = v - fy0;
+    const bool okx0 = (unsigned)x0 < (unsigned)C.W, okx1 = (unsigned)(x0 + 1) < (unsigned)C.W;
+    const bool oky0 = (unsigned)y0 < (unsigned)C.H, oky1 = (unsigned)(y0 + 1) < (unsigned)C.H;
+    const int xa = min(max(x0, 0), C.W - 1), xb = min(max(x0 + 1, 0), C.W - 1);
+    const int ya = min(max(y0, 0), C.H - 1), yb = min(max(y0 + 1, 0), C.H - 1);
+    g.i00 = ya * C.W + xa; g.i10 = ya * C.W + xb; g.i01 = yb * C.W + xa; g.i11 = yb * C.W + xb;
+    const float a0 = okx0 ? 1.0f - alpha : 0.0f, a1 = okx1 ? alpha : 0.0f;
+    const float wr = a0 + a1;                                   // same for both rows
+    const float b0 = (oky0 && wr > 0.0f) ? 1.0f - beta : 0.0f, b1 = (oky1 && wr > 0.0f) ? beta : 0.0f;
+    const float ww = b0 + b1;
+    const float k = (ww > 0.0f) ? fast_rcp(wr) * fast_rcp(ww) : 0.0f;
+    const float k0 = k * b0, k1 = k * b1;
+    g.c00 = k0 * a0; g.c10 = k0 * a1; g.c01 = k1 * a0; g.c11 = k1 * a1;
     return g;
 }
 
-__device__ __forceinline__ void pixel_accumulate(const DenseCtx &C, const PixelGeom &g, const float4 &cs,
+__device__ __forceinline__ void pixel_accumulate(const DenseCtx &C, const PixelGeom &g,
                                                  const float4 &c00, const float4 &c10, const float4 &c01, const float4 &c11,
                                                  const float4 &n00, const float4 &n10, const float4 &n01, const float4 &n11,
                                                  float (&acc)[kDenseVals])
 {
-    float cix, ciy, ciz, ciw, nix, niy, niz, niw;
-    const bool okc = blend4(g.t, c00, c10, c01, c11, cix, ciy, ciz, ciw);
-    const bool okn = blend4(g.t, n00, n10, n01, n11, nix, niy, niz, niw);
-    (void)ciw;
-    bool ok = g.valid && okc && okn && (ciz > C.depth_min && ciz < C.depth_max);
+    const float cix = g.c00 * c00.x + g.c10 * c10.x + g.c01 * c01.x + g.c11 * c11.x;
+    const float ciy = g.c00 * c00.y + g.c10 * c10.y + g.c01 * c01.y + g.c11 * c11.y;
+    const float ciz = g.c00 * c00.z + g.c10 * c10.z + g.c01 * c01.z + g.c11 * c11.z;
+    const float nix = g.c00 * n00.x + g.c10 * n10.x + g.c01 * n01.x + g.c11 * n11.x;
+    const float niy = g.c00 * n00.y + g.c10 * n10.y + g.c01 * n01.y + g.c11 * n11.y;
+    const float niz = g.c00 * n00.z + g.c10 * n10.z + g.c01 * n01.z + g.c11 * n11.z;
+    bool ok = g.valid && (ciz > C.depth_min && ciz < C.depth_max);
     const float dx = g.qx - cix, dy = g.qy - ciy, dz = g.qz - ciz;
     const float dist2 = dx * dx + dy * dy + dz * dz;
-    const float dn = g.nqx * nix + g.nqy * niy + g.nqz * niz + g.nqw * niw;
+    const float dn = g.nqx * nix + g.nqy * niy + g.nqz * niz;
     ok = ok && (dn >= C.normal_thresh) && (dist2 <= C.dist2_thresh);
     const float res = ok ? -(dx * nix + dy * niy + dz * niz) : 0.0f;
     const float e = res * res;
     const float wgt = ok ? C.w_dense * ((e <= C.delta2) ? 1.0f : C.delta * fast_rsq(e)) : 0.0f;
-    // row_j = [-n_w ; n_w x w],  w = T_j c_j (model frame),  n_w = R_i n_i
-    float wx, wy, wz;
-    xform_point(C.Tj, cs.x, cs.y, cs.z, wx, wy, wz);
-    const float nx = C.Ti.m[0] * nix + C.Ti.m[1] * niy + C.Ti.m[2] * niz;
-    const float ny = C.Ti.m[4] * nix + C.Ti.m[5] * niy + C.Ti.m[6] * niz;
-    const float nz = C.Ti.m[8] * nix + C.Ti.m[9] * niy + C.Ti.m[10] * niz;
-    float a[6] = { -nx, -ny, -nz, ny * wz - nz * wy, nz * wx - nx * wz, nx * wy - ny * wx };
+    // camera-frame row a' = [-n_i ; n_i x q]; rejected pixels contribute exact zeros (0 * NaN would poison the sums)
+    float a[6] = { -nix, -niy, -niz, niy * g.qz - niz * g.qy, niz * g.qx - nix * g.qz, nix * g.qy - niy * g.qx };
 #pragma unroll
-    for (int r = 0; r < 6; r++) a[r] = ok ? a[r] : 0.0f;        // 0 * NaN would poison the sums
+    for (int r = 0; r < 6; r++) a[r] = ok ? a[r] : 0.0f;
     int k = 0;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
@@ -361,9 +337,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, cons
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
     DenseCtx C;
-    C.Ti = load_mat4(T + 16 * (fb + fi));
-    C.Tj = load_mat4(T + 16 * (fb + fj));
-    C.Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), C.Tj);      // source camera -> target camera
+    C.Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), load_mat4(T + 16 * (fb + fj)));      // source camera -> target camera
     C.cam_t = campos + (fb + fi) * (size_t)D.npix; C.nrm_t = normals + (fb + fi) * (size_t)D.npix;
     C.fx = D.fx; C.fy = D.fy; C.cx = D.cx; C.cy = D.cy; C.depth_min = D.depth_min; C.depth_max = D.depth_max;
     C.normal_thresh = D.normal_thresh; C.dist2_thresh = D.dist_thresh * D.dist_thresh;
@@ -382,13 +356,15 @@ __global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, cons
             const bool in2 = s2 < hi;
             const int s2c = in2 ? s2 : s;
             const float4 csA = cam_s[s], nsA = nrm_s[s], csB = cam_s[s2c], nsB = nrm_s[s2c];
-            const PixelGeom gA = pixel_geom(C, true, csA, nsA), gB = pixel_geom(C, in2, csB, nsB);
-            const float4 cA00 = C.cam_t[gA.t.i00], cA10 = C.cam_t[gA.t.i10], cA01 = C.cam_t[gA.t.i01], cA11 = C.cam_t[gA.t.i11];
-            const float4 nA00 = C.nrm_t[gA.t.i00], nA10 = C.nrm_t[gA.t.i10], nA01 = C.nrm_t[gA.t.i01], nA11 = C.nrm_t[gA.t.i11];
-            const float4 cB00 = C.cam_t[gB.t.i00], cB10 = C.cam_t[gB.t.i10], cB01 = C.cam_t[gB.t.i01], cB11 = C.cam_t[gB.t.i11];
-            const float4 nB00 = C.nrm_t[gB.t.i00], nB10 = C.nrm_t[gB.t.i10], nB01 = C.nrm_t[gB.t.i01], nB11 = C.nrm_t[gB.t.i11];
-            pixel_accumulate(C, gA, csA, cA00, cA10, cA01, cA11, nA00, nA10, nA01, nA11, acc);
-            pixel_accumulate(C, gB, csB, cB00, cB10, cB01, cB11, nB00, nB10, nB01, nB11, acc);
+            const PixelGeom gA = pixel_geom(C, csA, nsA);
+            PixelGeom gB = pixel_geom(C, csB, nsB);
+            gB.valid = gB.valid && in2;
+            const float4 cA00 = C.cam_t[gA.i00], cA10 = C.cam_t[gA.i10], cA01 = C.cam_t[gA.i01], cA11 = C.cam_t[gA.i11];
+            const float4 nA00 = C.nrm_t[gA.i00], nA10 = C.nrm_t[gA.i10], nA01 = C.nrm_t[gA.i01], nA11 = C.nrm_t[gA.i11];
+            const float4 cB00 = C.cam_t[gB.i00], cB10 = C.cam_t[gB.i10], cB01 = C.cam_t[gB.i01], cB11 = C.cam_t[gB.i11];
+            const float4 nB00 = C.nrm_t[gB.i00], nB10 = C.nrm_t[gB.i10], nB01 = C.nrm_t[gB.i01], nB11 = C.nrm_t[gB.i11];
+            pixel_accumulate(C, gA, cA00, cA10, cA01, cA11, nA00, nA10, nA01, nA11, acc);
+            pixel_accumulate(C, gB, cB00, cB10, cB01, cB11, nB00, nB10, nB01, nB11, acc);
         }
     } else {
         int s = lo + (int)threadIdx.x;
@@ -397,10 +373,12 @@ __global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, cons
         for (; s < hi; s += kBlock) {
             const float4 cs = cs_n, ns = ns_n;
             if (s + kBlock < hi) { cs_n = cam_s[s + kBlock]; ns_n = nrm_s[s + kBlock]; }      // next pixel's stream loads
-            const PixelGeom g = pixel_geom(C, true, cs, ns);
-            const float4 c00 = C.cam_t[g.t.i00], c10 = C.cam_t[g.t.i10], c01 = C.cam_t[g.t.i01], c11 = C.cam_t[g.t.i11];
-            const float4 n00 = C.nrm_t[g.t.i00], n10 = C.nrm_t[g.t.i10], n01 = C.nrm_t[g.t.i01], n11 = C.nrm_t[g.t.i11];
-            pixel_accumulate(C, g, cs, c00, c10, c01, c11, n00, n10, n01, n11, acc);
+            const PixelGeom g = pixel_geom(C, cs, ns);
+            // a wave whose 64 source pixels are all rejected (masked scenes: ~95 % of the image) skips the gathers
+            if (__builtin_amdgcn_ballot_w64(g.valid) == 0ull) continue;
+            const float4 c00 = C.cam_t[g.i00], c10 = C.cam_t[g.i10], c01 = C.cam_t[g.i01], c11 = C.cam_t[g.i11];
+            const float4 n00 = C.nrm_t[g.i00], n10 = C.nrm_t[g.i10], n01 = C.nrm_t[g.i01], n11 = C.nrm_t[g.i11];
+            pixel_accumulate(C, g, c00, c10, c01, c11, n00, n10, n01, n11, acc);
         }
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
@@ -488,8 +466,9 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     float *vb = A + (size_t)n * ld;       // rhs / residual r
     float *vM = vb + n, *vz = vM + n, *vp = vz + n, *vAp = vp + n, *vd = vAp + n;
     float *scratch = vd + n;              // 16 floats
-    float *ps = D.pairsum_in_lds ? scratch + 16 : pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals);
-    float *pd = ps + (size_t)D.n_pairs * kSparseVals;
+    float *ps = D.pairsum_in_lds ? scratch + 16 : pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals);
+    float *pd = ps + (size_t)D.n_pairs * kSparseVals;          // model-frame dense pair sums (S, g, count)
+    float *pdr = pd + (size_t)D.n_dense_pairs * kDenseVals;     // camera-frame sums as the sweep produced them
     float *tr = D.trace_on ? trace + ((size_t)b * D.n_gn + iter) * D.trace_record : nullptr;
 
     // Phase A: fixed-order reduction of the sweep partials (4 independent loads in flight per lane)
@@ -506,11 +485,65 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
         const float *src = dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals;
         for (int e = tid; e < D.n_dense_pairs * kDenseVals; e += nthr) {
             const int p = e / kDenseVals, k = e % kDenseVals;
-            pd[e] = strided_sum(src + (size_t)p * D.dense_tiles * kDenseVals + k, D.dense_tiles, kDenseVals);
+            pdr[e] = strided_sum(src + (size_t)p * D.dense_tiles * kDenseVals + k, D.dense_tiles, kDenseVals);
         }
     }
     for (int e = tid; e < n * ld; e += nthr) A[e] = 0.0f;
     __syncthreads();
+    // Phase A2: camera-frame -> model-frame congruence of the dense pair sums, S = M S' M^T, g = M g',
+    // M = [[R_i, 0], [[t_i]x R_i, R_i]] with T_i the TARGET frame's pose of this iterate (one (pair,row) per lane)
+    if (D.use_dense) {
+        for (int e = tid; e < D.n_dense_pairs * 6; e += nthr) {
+            const int p = e / 6, r = e % 6;
+            const float *Tt = T + 16 * ((size_t)b * N + dense_pairs[p].x);
+            const float R0[3] = { Tt[0], Tt[1], Tt[2] }, R1[3] = { Tt[4], Tt[5], Tt[6] }, R2[3] = { Tt[8], Tt[9], Tt[10] };
+            const float t[3] = { Tt[3], Tt[7], Tt[11] };
+            float Mr[6];                                         // row r of M
+            if (r < 3) {
+                const float *Rr = (r == 0) ? R0 : (r == 1) ? R1 : R2;
+                Mr[0] = Rr[0]; Mr[1] = Rr[1]; Mr[2] = Rr[2]; Mr[3] = 0.f; Mr[4] = 0.f; Mr[5] = 0.f;
+            } else {
+                const int q = r - 3;
+                const float *Rq = (q == 0) ? R0 : (q == 1) ? R1 : R2;
+                // ([t]x R)[q][c] = t[(q+1)%3] R[(q+2)%3][c] - t[(q+2)%3] R[(q+1)%3][c]
+                const float *Ra = (q == 0) ? R2 : (q == 1) ? R0 : R1;      // R[(q+2)%3]
+                const float *Rb = (q == 0) ? R1 : (q == 1) ? R2 : R0;      // R[(q+1)%3]
+                const float ta = t[(q + 1) % 3], tb = t[(q + 2) % 3];
+                for (int c = 0; c < 3; c++) { Mr[c] = ta * Ra[c] - tb * Rb[c]; Mr[3 + c] = Rq[c]; }
+            }
+            const float *Sp = pdr + (size_t)p * kDenseVals;
+            float u[6];                                          // u = Mr S'   (row vector)
+            for (int c = 0; c < 6; c++) {
+                float acc = 0.0f;
+                for (int k2 = 0; k2 < 6; k2++) acc += Mr[k2] * Sp[tri21(k2, c)];
+                u[c] = acc;
+            }
+            float gr = 0.0f;
+            for (int k2 = 0; k2 < 6; k2++) gr += Mr[k2] * Sp[21 + k2];
+            // S[r][c] = u . (row c of M), c >= r
+            float *So = pd + (size_t)p * kDenseVals;
+            for (int c = r; c < 6; c++) {
+                float Mc[6];
+                if (c < 3) {
+                    const float *Rr = (c == 0) ? R0 : (c == 1) ? R1 : R2;
+                    Mc[0] = Rr[0]; Mc[1] = Rr[1]; Mc[2] = Rr[2]; Mc[3] = 0.f; Mc[4] = 0.f; Mc[5] = 0.f;
+                } else {
+                    const int q = c - 3;
+                    const float *Rq = (q == 0) ? R0 : (q == 1) ? R1 : R2;
+                    const float *Ra = (q == 0) ? R2 : (q == 1) ? R0 : R1;
+                    const float *Rb = (q == 0) ? R1 : (q == 1) ? R2 : R0;
+                    const float ta = t[(q + 1) % 3], tb = t[(q + 2) % 3];
+                    for (int cc = 0; cc < 3; cc++) { Mc[cc] = ta * Ra[cc] - tb * Rb[cc]; Mc[3 + cc] = Rq[cc]; }
+                }
+                float acc = 0.0f;
+                for (int k2 = 0; k2 < 6; k2++) acc += u[k2] * Mc[k2];
+                So[tri21(r, c)] = acc;
+            }
+            So[21 + r] = gr;
+            if (r == 0) So[27] = Sp[27];
+        }
+        __syncthreads();
+    }
     if (tr && D.use_dense) for (int e = tid; e < D.n_dense_pairs * kDenseVals; e += nthr) tr[D.tr_dpair + e] = pd[e];
 
     // Phase B1: off-diagonal 6x6 blocks, one canonical pair (i<j) each: A_ij = -(ws Ji^T Jj + S_dense)
