@@ -61,7 +61,7 @@ class Stats(C.Structure):
 
 class TraceLayout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
-                ("record_floats", "off_x", "off_T", "off_rhs", "off_precond", "off_pcg", "off_delta", "off_dense_pair", "off_A")]
+                ("record_floats", "off_x", "off_T", "off_rhs", "off_precond", "off_pcg", "off_delta", "off_dense_pair", "off_A", "off_clk")]
 
 
 class BtbaError(RuntimeError):

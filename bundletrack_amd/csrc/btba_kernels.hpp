@@ -57,7 +57,7 @@ struct SolveDims {
     int64_t corr_stride; // EntryJ per instance block
     int trace_on;
     int64_t trace_record; // floats per (instance, iteration) record
-    int64_t tr_x, tr_T, tr_rhs, tr_prec, tr_pcg, tr_delta, tr_dpair, tr_A;
+    int64_t tr_x, tr_T, tr_rhs, tr_prec, tr_pcg, tr_delta, tr_dpair, tr_A, tr_clk;
     int n_gn;
     int pairsum_in_lds;  // 1: stage reduced pair sums in LDS, 0: in global scratch
 };
@@ -181,17 +181,20 @@ __global__ void __launch_bounds__(kBlock) k_sparse_sweep(SolveDims D, const floa
 #pragma unroll
     for (int k = 0; k < kSparseVals; k++) acc[k] = 0.0f;
 
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += kBlock) {
-        const float4 q0 = cb[2 * (size_t)e], q1 = cb[2 * (size_t)e + 1];
-        if (__float_as_uint(q0.x) == 0xFFFFFFFFu) continue;   // EntryJ::isValid
+    const float delta2 = D.robust_delta * D.robust_delta;
+    auto accumulate = [&](const float4 &q0, const float4 &q1, bool live) {
         // q0 = (imgIdx_i, imgIdx_j, pos_i.x, pos_i.y)  q1 = (pos_i.z, pos_j.x, pos_j.y, pos_j.z)
+        const float m = (live && __float_as_uint(q0.x) != 0xFFFFFFFFu) ? 1.0f : 0.0f;      // EntryJ::isValid
         float wix, wiy, wiz, wjx, wjy, wjz;
         xform_point(Ti, q0.z, q0.w, q1.x, wix, wiy, wiz);
         xform_point(Tj, q1.y, q1.z, q1.w, wjx, wjy, wjz);
+        // an invalid / out-of-range slot contributes exact zeros (its payload may be anything, even NaN)
+        wix = m != 0.0f ? wix : 0.0f; wiy = m != 0.0f ? wiy : 0.0f; wiz = m != 0.0f ? wiz : 0.0f;
+        wjx = m != 0.0f ? wjx : 0.0f; wjy = m != 0.0f ? wjy : 0.0f; wjz = m != 0.0f ? wjz : 0.0f;
         const float rx = wix - wjx, ry = wiy - wjy, rz = wiz - wjz;
         const float e2 = rx * rx + ry * ry + rz * rz;
-        const float rho = (e2 <= D.robust_delta * D.robust_delta) ? 1.0f : D.robust_delta * __builtin_amdgcn_rsqf(e2);
-        acc[0] += 1.0f;
+        const float rho = m * ((e2 <= delta2) ? 1.0f : D.robust_delta * __builtin_amdgcn_rsqf(e2));
+        acc[0] += m;
         acc[1] += wix; acc[2] += wiy; acc[3] += wiz;
         acc[4] += wjx; acc[5] += wjy; acc[6] += wjz;
         acc[7] += wix * wix; acc[8] += wix * wiy; acc[9] += wix * wiz; acc[10] += wiy * wiy; acc[11] += wiy * wiz; acc[12] += wiz * wiz;
@@ -205,6 +208,15 @@ __global__ void __launch_bounds__(kBlock) k_sparse_sweep(SolveDims D, const floa
         acc[37] += rho;
         acc[38] += rho * (wiy * wiy + wiz * wiz); acc[39] += rho * (wix * wix + wiz * wiz); acc[40] += rho * (wix * wix + wiy * wiy);
         acc[41] += rho * (wjy * wjy + wjz * wjz); acc[42] += rho * (wjx * wjx + wjz * wjz); acc[43] += rho * (wjx * wjx + wjy * wjy);
+    };
+    // two correspondences per lane per trip: four independent 16-byte loads in flight
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += 2 * kBlock) {
+        const uint32_t e2 = e + kBlock;
+        const bool live2 = e2 < hi;
+        const uint32_t e2c = live2 ? e2 : e;
+        const float4 a0 = cb[2 * (size_t)e], a1 = cb[2 * (size_t)e + 1], b0 = cb[2 * (size_t)e2c], b1 = cb[2 * (size_t)e2c + 1];
+        accumulate(a0, a1, true);
+        accumulate(b0, b1, live2);
     }
     float *out = partials + (((size_t)b * D.n_pairs + p) * D.sparse_chunks + chunk) * kSparseVals;
     block_reduce_store<kSparseVals, 4>(acc, red, out);
@@ -471,6 +483,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     float *pdr = pd + (size_t)D.n_dense_pairs * kDenseVals;     // camera-frame sums as the sweep produced them
     float *tr = D.trace_on ? trace + ((size_t)b * D.n_gn + iter) * D.trace_record : nullptr;
 
+    const long long clk0 = tr ? (long long)clock64() : 0;
+#define BTBA_STAMP(slot) do { if (tr && tid == 0) tr[D.tr_clk + (slot)] = (float)((long long)clock64() - clk0); } while (0)
     // Phase A: fixed-order reduction of the sweep partials (4 independent loads in flight per lane)
     if (D.use_sparse) {
         const float *src = sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals;
@@ -490,6 +504,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     }
     for (int e = tid; e < n * ld; e += nthr) A[e] = 0.0f;
     __syncthreads();
+    BTBA_STAMP(0);
     // Phase A2: camera-frame -> model-frame congruence of the dense pair sums, S = M S' M^T, g = M g',
     // M = [[R_i, 0], [[t_i]x R_i, R_i]] with T_i the TARGET frame's pose of this iterate (one (pair,row) per lane)
     if (D.use_dense) {
@@ -546,6 +561,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     }
     if (tr && D.use_dense) for (int e = tid; e < D.n_dense_pairs * kDenseVals; e += nthr) tr[D.tr_dpair + e] = pd[e];
 
+    BTBA_STAMP(1);
     // Phase B1: off-diagonal 6x6 blocks, one canonical pair (i<j) each: A_ij = -(ws Ji^T Jj + S_dense)
     for (int e = tid; e < D.n_pairs * 36; e += nthr) {
         const int p = e / 36, r = (e % 36) / 6, c = e % 6;
@@ -632,6 +648,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
         for (int e = tid; e < n * n; e += nthr) tr[D.tr_A + e] = A[(e / n) * ld + (e % n)];
     }
 
+    BTBA_STAMP(2);
     // Phase C: Jacobi-preconditioned CG, SolverBundling.cu:575-818 (frame 0 entries stay 0)
     float rz;
     {
@@ -674,6 +691,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     }
     __syncthreads();
 
+    BTBA_STAMP(3);
     // Phase D: x_k <- Log(Exp(delta_k) Exp(x_k)); next iterate's T, T^-1  (SolverBundling.cu:805-815, 890-897)
     for (int k = tid; k < N; k += nthr) {
         float *xk = x + 6 * ((size_t)b * N + k);
@@ -694,6 +712,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             for (int q = 0; q < 3; q++) { tr[D.tr_delta + 6 * k + q] = vd[6 * k + 3 + q]; tr[D.tr_delta + 6 * k + 3 + q] = vd[6 * k + q]; }
         }
     }
+    BTBA_STAMP(4);
+#undef BTBA_STAMP
 }
 
 }  // namespace btba

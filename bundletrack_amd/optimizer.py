@@ -167,6 +167,8 @@ class TraceView:
     @property
     def dense_pair(self): return self._get(self.layout.off_dense_pair, 28 * self.n_dense_pairs, (self.n_dense_pairs, 28))
     @property
+    def clk(self): return self._get(self.layout.off_clk, 8, (8,))
+    @property
     def A(self):
         n = 6 * self.n_frames
         return self._get(self.layout.off_A, n * n, (n, n))

@@ -114,10 +114,11 @@ typedef struct btba_stats {
  *   delta       [N][6]   PCG solution (deltaRot, deltaTrans)
  *   dense_pair  [Pd][28] S (21, upper triangle row-major of the 6x6 in [trans,rot] order), g (6), count
  *   A           [6N][6N] assembled normal matrix (sparse + dense), reference dense layout
+ *   clk         [8]      shader-clock stamps of k_system_solve's phases (reduce, congruence, assemble, PCG, update)
  */
 typedef struct btba_trace_layout {
     int64_t record_floats;
-    int64_t off_x, off_T, off_rhs, off_precond, off_pcg, off_delta, off_dense_pair, off_A;
+    int64_t off_x, off_T, off_rhs, off_precond, off_pcg, off_delta, off_dense_pair, off_A, off_clk;
 } btba_trace_layout;
 
 typedef struct btba_workspace btba_workspace;

@@ -23,8 +23,8 @@ def test_struct_sizes_match_header():
     assert _lib.ENTRYJ_DTYPE.itemsize == 32          # struct EntryJ, SIFTImageManager.h:44-59
     L = _lib.TraceLayout()
     _lib.lib().btba_trace_layout_get(15, 105, 5, C.byref(L))
-    assert L.record_floats == 15 * 6 * 4 + 15 * 16 + 5 * 4 + 105 * 28 + 90 * 90
-    assert L.off_A + 90 * 90 == L.record_floats
+    assert L.record_floats == 15 * 6 * 4 + 15 * 16 + 5 * 4 + 105 * 28 + 90 * 90 + 8
+    assert L.off_A + 90 * 90 == L.off_clk and L.off_clk + 8 == L.record_floats
 
 
 def test_default_params_are_the_shipping_config():
