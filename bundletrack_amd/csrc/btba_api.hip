@@ -65,6 +65,8 @@ struct btba_workspace {
     btba_stats stats{};
     bool lds_attr_set = false;
     bool always_time_region = false;   // optimize_frames: ms_solve is part of its stats contract
+    hipStream_t aux_stream = nullptr;  // second half of a batch runs here (software pipelining across instances)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     hipEvent_t get_event()
     {
@@ -141,6 +143,9 @@ void btba_workspace_destroy(btba_workspace *ws)
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid };
     for (auto b : bufs) b->release();
+    if (ws->aux_stream) (void)hipStreamDestroy(ws->aux_stream);
+    if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
+    if (ws->ev_join) (void)hipEventDestroy(ws->ev_join);
     if (ws->owns_stream) (void)hipStreamDestroy(ws->stream);
     delete ws;
 }
@@ -195,21 +200,23 @@ int btba_bucket_correspondences(const btba_entryj *in, uint32_t n, int n_frames,
 }  // extern "C"
 
 // ---- internal: enqueue one batched solve on ws->stream ------------------------------------------
-static int time_begin(btba_workspace *ws, bool on, int kind, size_t *slot)
+static int time_begin(btba_workspace *ws, bool on, int kind, size_t *slot, hipStream_t st = nullptr)
 {
+    if (!st) st = ws->stream;
     *slot = (size_t)-1;
     if (!on) return BTBA_OK;
     EventPair ep{ ws->get_event(), ws->get_event(), kind };
     if (!ep.a || !ep.b) return BTBA_EHIP;
-    HIP_TRY(hipEventRecord(ep.a, ws->stream));
+    HIP_TRY(hipEventRecord(ep.a, st));
     ws->events.push_back(ep);
     *slot = ws->events.size() - 1;
     return BTBA_OK;
 }
-static int time_end(btba_workspace *ws, size_t slot)
+static int time_end(btba_workspace *ws, size_t slot, hipStream_t st = nullptr)
 {
+    if (!st) st = ws->stream;
     if (slot == (size_t)-1) return BTBA_OK;
-    HIP_TRY(hipEventRecord(ws->events[slot].b, ws->stream));
+    HIP_TRY(hipEventRecord(ws->events[slot].b, st));
     return BTBA_OK;
 }
 
@@ -338,27 +345,58 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         const int total = B * N;
         k_prepare<<<(total + 63) / 64, 64, 0, ws->stream>>>(total, poses, ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>());
     }
+    // Software pipelining across instances: the batch is split in two halves on two streams, so one half's
+    // latency-bound k_system_solve (B/2 workgroups on a 256-CU chip) and its sparse sweep overlap the other
+    // half's dense sweep.  Halves never touch each other's data; fork/join events keep the caller's stream
+    // ordering.  Small batches run as one piece.
+    const int n_halves = (B >= 8 && !(prm->flags & BTBA_FLAG_NO_OVERLAP)) ? 2 : 1;
+    if (n_halves == 2 && !ws->aux_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&ws->aux_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming));
+    }
+    struct Half { int b0, nb; hipStream_t st; } halves[2] = { { 0, n_halves == 2 ? B / 2 : B, ws->stream }, { B / 2, B - B / 2, ws->aux_stream } };
+    if (n_halves == 2) {
+        HIP_TRY(hipEventRecord(ws->ev_fork, ws->stream));
+        HIP_TRY(hipStreamWaitEvent(ws->aux_stream, ws->ev_fork, 0));
+    }
+    const size_t pairsum_floats = lds_pairs / sizeof(float);
     for (int it = 0; it < prm->n_gn_iters; it++) {
-        size_t slot;
-        if (use_sparse) {
-            if ((rc = time_begin(ws, timing, 1, &slot))) return rc;
-            k_sparse_sweep<<<dim3(chunks, P, B), kBlock, 0, ws->stream>>>(D, reinterpret_cast<const float4 *>(corr), pair_offsets, ws->T.as<float>(), ws->sparse_part.as<float>());
-            if ((rc = time_end(ws, slot))) return rc;
-        }
-        if (use_dense) {
-            if ((rc = time_begin(ws, timing, 0, &slot))) return rc;
-            const dim3 dgrid((unsigned)tiles * D.n_dense_pairs * B);
-#define BTBA_DENSE_ARGS D, reinterpret_cast<const float4 *>(campos), reinterpret_cast<const float4 *>(normals), ws->dense_pairs.as<int2>(), ws->T.as<float>(), ws->Tinv.as<float>(), ws->dense_part.as<float>()
-            if (prm->flags & BTBA_FLAG_DENSE_2PIX) k_dense_sweep<2, 2><<<dgrid, kBlock, 0, ws->stream>>>(BTBA_DENSE_ARGS);
-            else if (prm->flags & BTBA_FLAG_DENSE_4WAVE) k_dense_sweep<1, 4><<<dgrid, kBlock, 0, ws->stream>>>(BTBA_DENSE_ARGS);
-            else k_dense_sweep<1, 3><<<dgrid, kBlock, 0, ws->stream>>>(BTBA_DENSE_ARGS);   // measured best: 616 us vs 690 / 704 at c3 x 32
+        for (int h = 0; h < n_halves; h++) {
+            const Half &H = halves[h];
+            const size_t b0 = (size_t)H.b0;
+            const float *campos_h = campos ? campos + 4 * b0 * N * npix : nullptr, *normals_h = normals ? normals + 4 * b0 * N * npix : nullptr;
+            const float4 *corr_h = corr ? reinterpret_cast<const float4 *>(corr) + 2 * b0 * (size_t)corr_stride : nullptr;
+            const uint32_t *off_h = pair_offsets ? pair_offsets + b0 * (P + 1) : nullptr;
+            float *x_h = ws->x.as<float>() + 6 * b0 * N, *T_h = ws->T.as<float>() + 16 * b0 * N, *Ti_h = ws->Tinv.as<float>() + 16 * b0 * N;
+            float *sp_h = ws->sparse_part.as<float>() + b0 * P * chunks * kSparseVals;
+            float *dp_h = ws->dense_part.as<float>() + b0 * (size_t)(Pd > 0 ? Pd : 1) * tiles * kDenseVals;
+            float *ps_h = ws->pairsum.p ? ws->pairsum.as<float>() + b0 * pairsum_floats : nullptr;
+            float *tr_h = trace ? trace + b0 * (size_t)D.n_gn * D.trace_record : nullptr;
+            size_t slot;
+            if (use_sparse) {
+                if ((rc = time_begin(ws, timing, 1, &slot, H.st))) return rc;
+                k_sparse_sweep<<<dim3(chunks, P, H.nb), kBlock, 0, H.st>>>(D, corr_h, off_h, T_h, sp_h);
+                if ((rc = time_end(ws, slot, H.st))) return rc;
+            }
+            if (use_dense) {
+                if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
+                const dim3 dgrid((unsigned)tiles * D.n_dense_pairs * H.nb);
+#define BTBA_DENSE_ARGS D, reinterpret_cast<const float4 *>(campos_h), reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h
+                if (prm->flags & BTBA_FLAG_DENSE_2PIX) k_dense_sweep<2, 2><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
+                else if (prm->flags & BTBA_FLAG_DENSE_4WAVE) k_dense_sweep<1, 4><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
+                else k_dense_sweep<1, 3><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
 #undef BTBA_DENSE_ARGS
-            if ((rc = time_end(ws, slot))) return rc;
+                if ((rc = time_end(ws, slot, H.st))) return rc;
+            }
+            if ((rc = time_begin(ws, timing, 2, &slot, H.st))) return rc;
+            k_system_solve<<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h);
+            if ((rc = time_end(ws, slot, H.st))) return rc;
         }
-        if ((rc = time_begin(ws, timing, 2, &slot))) return rc;
-        k_system_solve<<<B, kSolveBlock, lds_bytes, ws->stream>>>(D, it, ws->sparse_part.as<float>(), ws->dense_part.as<float>(), ws->dense_pairs.as<int2>(), d_adj_off, d_adj,
-                                                             ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>(), ws->pairsum.as<float>(), trace);
-        if ((rc = time_end(ws, slot))) return rc;
+    }
+    if (n_halves == 2) {
+        HIP_TRY(hipEventRecord(ws->ev_join, ws->aux_stream));
+        HIP_TRY(hipStreamWaitEvent(ws->stream, ws->ev_join, 0));
     }
     // convertPosesToMatricesCU: T already holds Exp(x) of the final iterate
     HIP_TRY(hipMemcpyAsync(poses, ws->T.p, sizeof(float) * 16 * (size_t)B * N, hipMemcpyDeviceToDevice, ws->stream));

@@ -20,8 +20,8 @@ def main():
         corr_d = torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(dev); offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
         poses0 = torch.from_numpy(np.stack([p["poses"] for p in pick])).to(dev)
         ref = None
-        for name, flag in (("1pix/3wave", 0), ("1pix/4wave", 16), ("2pix/2wave", 8)):
-            for tiles in ((2, 3, 5) if B > 1 else (8, 15, 25, 40)):
+        for name, flag in (("overlap", 0), ("no-overlap", 32)):
+            for tiles in ((3, 5, 8) if B > 1 else (15, 25)):
                 bs = BatchSolver(ws, dense_tiles=tiles)
                 bs.params.flags |= _lib.FLAG_TIME_KERNELS | flag
                 poses_d = poses0.clone()
