@@ -351,7 +351,12 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // ordering.  Small batches run as one piece.
     const int n_halves = (B >= 8 && !(prm->flags & BTBA_FLAG_NO_OVERLAP)) ? 2 : 1;
     if (n_halves == 2 && !ws->aux_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&ws->aux_stream, hipStreamNonBlocking));
+        // LOWEST priority: two equal-priority streams with identical kernel sequences just time-share the chip in
+        // lockstep (measured: no gain); with a priority gap the main half is never held up and the low-priority
+        // half fills the CUs the main half's k_system_solve / sparse sweep leave idle.
+        int prio_least = 0, prio_greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&ws->aux_stream, hipStreamNonBlocking, prio_least));
         HIP_TRY(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming));
     }
