@@ -478,13 +478,17 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     float *vb = A + (size_t)n * ld;       // rhs / residual r
     float *vM = vb + n, *vz = vM + n, *vp = vz + n, *vAp = vp + n, *vd = vAp + n;
     float *scratch = vd + n;              // 16 floats
-    float *ps = D.pairsum_in_lds ? scratch + 16 : pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals);
+    float *vT = scratch + 16;             // this iterate's T[N][16]
+    int *dense_pairs_lds = reinterpret_cast<int *>(vT + 16 * N);   // target frame of every dense pair
+    float *ps = D.pairsum_in_lds ? reinterpret_cast<float *>(dense_pairs_lds + D.n_dense_pairs) : pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals);
     float *pd = ps + (size_t)D.n_pairs * kSparseVals;          // model-frame dense pair sums (S, g, count)
     float *pdr = pd + (size_t)D.n_dense_pairs * kDenseVals;     // camera-frame sums as the sweep produced them
     float *tr = D.trace_on ? trace + ((size_t)b * D.n_gn + iter) * D.trace_record : nullptr;
 
     const long long clk0 = tr ? (long long)clock64() : 0;
 #define BTBA_STAMP(slot) do { if (tr && tid == 0) tr[D.tr_clk + (slot)] = (float)((long long)clock64() - clk0); } while (0)
+    for (int e = tid; e < 16 * N; e += nthr) vT[e] = T[16 * (size_t)b * N + e];
+    for (int e = tid; e < D.n_dense_pairs; e += nthr) dense_pairs_lds[e] = dense_pairs[e].x;
     // Phase A: fixed-order reduction of the sweep partials (4 independent loads in flight per lane)
     if (D.use_sparse) {
         const float *src = sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals;
@@ -506,56 +510,52 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     __syncthreads();
     BTBA_STAMP(0);
     // Phase A2: camera-frame -> model-frame congruence of the dense pair sums, S = M S' M^T, g = M g',
-    // M = [[R_i, 0], [[t_i]x R_i, R_i]] with T_i the TARGET frame's pose of this iterate (one (pair,row) per lane)
+    // M = [[R_i, 0], [[t_i]x R_i, R_i]] with T_i the TARGET frame's pose of this iterate.
+    // One (pair, upper-triangle entry) per lane + one (pair, g row) per lane; S' held in registers.
     if (D.use_dense) {
-        for (int e = tid; e < D.n_dense_pairs * 6; e += nthr) {
-            const int p = e / 6, r = e % 6;
-            const float *Tt = T + 16 * ((size_t)b * N + dense_pairs[p].x);
-            const float R0[3] = { Tt[0], Tt[1], Tt[2] }, R1[3] = { Tt[4], Tt[5], Tt[6] }, R2[3] = { Tt[8], Tt[9], Tt[10] };
-            const float t[3] = { Tt[3], Tt[7], Tt[11] };
-            float Mr[6];                                         // row r of M
+        auto m_row = [&](const float *Tt, int r, float (&Mr)[6]) {
             if (r < 3) {
-                const float *Rr = (r == 0) ? R0 : (r == 1) ? R1 : R2;
-                Mr[0] = Rr[0]; Mr[1] = Rr[1]; Mr[2] = Rr[2]; Mr[3] = 0.f; Mr[4] = 0.f; Mr[5] = 0.f;
+                Mr[0] = Tt[4 * r]; Mr[1] = Tt[4 * r + 1]; Mr[2] = Tt[4 * r + 2]; Mr[3] = 0.f; Mr[4] = 0.f; Mr[5] = 0.f;
             } else {
-                const int q = r - 3;
-                const float *Rq = (q == 0) ? R0 : (q == 1) ? R1 : R2;
-                // ([t]x R)[q][c] = t[(q+1)%3] R[(q+2)%3][c] - t[(q+2)%3] R[(q+1)%3][c]
-                const float *Ra = (q == 0) ? R2 : (q == 1) ? R0 : R1;      // R[(q+2)%3]
-                const float *Rb = (q == 0) ? R1 : (q == 1) ? R2 : R0;      // R[(q+1)%3]
-                const float ta = t[(q + 1) % 3], tb = t[(q + 2) % 3];
-                for (int c = 0; c < 3; c++) { Mr[c] = ta * Ra[c] - tb * Rb[c]; Mr[3 + c] = Rq[c]; }
+                const int q = r - 3, qa = (q + 1) % 3, qb = (q + 2) % 3;     // ([t]x R)[q][c] = t[qa] R[qb][c] - t[qb] R[qa][c]
+                const float ta = Tt[4 * qa + 3], tb = Tt[4 * qb + 3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) { Mr[c] = ta * Tt[4 * qb + c] - tb * Tt[4 * qa + c]; Mr[3 + c] = Tt[4 * q + c]; }
             }
+        };
+        for (int e = tid; e < D.n_dense_pairs * 27; e += nthr) {
+            const int p = e / 27, idx = e % 27;
+            const float *Tt = vT + 16 * dense_pairs_lds[p];
             const float *Sp = pdr + (size_t)p * kDenseVals;
-            float u[6];                                          // u = Mr S'   (row vector)
-            for (int c = 0; c < 6; c++) {
-                float acc = 0.0f;
-                for (int k2 = 0; k2 < 6; k2++) acc += Mr[k2] * Sp[tri21(k2, c)];
-                u[c] = acc;
-            }
-            float gr = 0.0f;
-            for (int k2 = 0; k2 < 6; k2++) gr += Mr[k2] * Sp[21 + k2];
-            // S[r][c] = u . (row c of M), c >= r
             float *So = pd + (size_t)p * kDenseVals;
-            for (int c = r; c < 6; c++) {
-                float Mc[6];
-                if (c < 3) {
-                    const float *Rr = (c == 0) ? R0 : (c == 1) ? R1 : R2;
-                    Mc[0] = Rr[0]; Mc[1] = Rr[1]; Mc[2] = Rr[2]; Mc[3] = 0.f; Mc[4] = 0.f; Mc[5] = 0.f;
-                } else {
-                    const int q = c - 3;
-                    const float *Rq = (q == 0) ? R0 : (q == 1) ? R1 : R2;
-                    const float *Ra = (q == 0) ? R2 : (q == 1) ? R0 : R1;
-                    const float *Rb = (q == 0) ? R1 : (q == 1) ? R2 : R0;
-                    const float ta = t[(q + 1) % 3], tb = t[(q + 2) % 3];
-                    for (int cc = 0; cc < 3; cc++) { Mc[cc] = ta * Ra[cc] - tb * Rb[cc]; Mc[3 + cc] = Rq[cc]; }
-                }
+            if (idx < 21) {
+                int r = 0, rem = idx;
+                while (rem >= 6 - r) { rem -= 6 - r; r++; }
+                const int c = r + rem;
+                float S[21];
+#pragma unroll
+                for (int k2 = 0; k2 < 21; k2++) S[k2] = Sp[k2];
+                float Mr[6], Mc[6];
+                m_row(Tt, r, Mr); m_row(Tt, c, Mc);
                 float acc = 0.0f;
-                for (int k2 = 0; k2 < 6; k2++) acc += u[k2] * Mc[k2];
-                So[tri21(r, c)] = acc;
+#pragma unroll
+                for (int k2 = 0; k2 < 6; k2++) {
+                    float u = 0.0f;                                   // u = (S' Mc^T)[k2]
+#pragma unroll
+                    for (int l = 0; l < 6; l++) u += S[tri21(k2, l)] * Mc[l];
+                    acc += Mr[k2] * u;
+                }
+                So[idx] = acc;
+            } else {
+                const int r = idx - 21;
+                float Mr[6];
+                m_row(Tt, r, Mr);
+                float acc = 0.0f;
+#pragma unroll
+                for (int k2 = 0; k2 < 6; k2++) acc += Mr[k2] * Sp[21 + k2];
+                So[21 + r] = acc;
+                if (r == 0) So[27] = Sp[27];
             }
-            So[21 + r] = gr;
-            if (r == 0) So[27] = Sp[27];
         }
         __syncthreads();
     }
@@ -638,6 +638,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
         vd[e] = 0.0f;
     }
     __syncthreads();
+    BTBA_STAMP(2);
     if (tr) {
         for (int e = tid; e < n; e += nthr) {
             const int k = e / 6, r = e % 6;           // trace order (rot, trans); internal [trans, rot]
@@ -648,46 +649,64 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
         for (int e = tid; e < n * n; e += nthr) tr[D.tr_A + e] = A[(e / n) * ld + (e % n)];
     }
 
-    BTBA_STAMP(2);
-    // Phase C: Jacobi-preconditioned CG, SolverBundling.cu:575-818 (frame 0 entries stay 0)
-    float rz;
-    {
+    BTBA_STAMP(5);
+    // Phase C: Jacobi-preconditioned CG, SolverBundling.cu:575-818 (frame 0 entries stay 0).
+    // ONE wave runs it: <= 240 unknowns = <= 4 rows per lane, vectors live in registers, the two dot products per
+    // step are DPP wave sums, only p travels through LDS.  No workgroup barrier inside the iteration (the
+    // 16-wave version spent ~6 k cycles per step in barriers; this one ~1 k).
+    if (tid < 64) {
+        constexpr int kMaxRows = 4;                     // n = 6N <= 240 (N <= 40 is enforced by the host)
+        const int lane = tid;
+        float r_[kMaxRows], m_[kMaxRows], p_[kMaxRows], d_[kMaxRows];
         float part = 0.0f;
-        for (int e = tid; e < n; e += nthr) { const float z = vM[e] * vb[e]; vp[e] = z; part += vb[e] * z; }
-        rz = block_sum(part, scratch);
-    }
-    for (int li = 0; li < D.n_pcg; li++) {
-        __syncthreads();
-        // Ap = A p : 8 lanes per row (128 rows per pass)
-        {
-            const int seg = tid & 7;
-            float part_pAp = 0.0f;
-            for (int row = tid >> 3; row < n; row += nthr >> 3) {
-                const float *ar = A + (size_t)row * ld;
-                float s = 0.0f;
-                for (int c = seg; c < n; c += 8) s += ar[c] * vp[c];
-                s = dpp_add<0xB1, 0xf>(s);
-                s = dpp_add<0x4E, 0xf>(s);
-                s = dpp_add<0x141, 0xf>(s);
-                if (seg == 0) { vAp[row] = s; part_pAp += vp[row] * s; }
-            }
-            const float pAp = block_sum(part_pAp, scratch);
-            const float alpha = (pAp > kEps) ? rz / pAp : 0.0f;
-            float part = 0.0f;
-            for (int e = tid; e < n; e += nthr) {
-                vd[e] = vd[e] + alpha * vp[e];
-                const float r = vb[e] - alpha * vAp[e];
-                vb[e] = r;
-                const float z = vM[e] * r;
-                vz[e] = z;
-                part += z * r;
-            }
-            const float rz_new = block_sum(part, scratch);
-            const float beta = (rz > kEps) ? rz_new / rz : 0.0f;
-            if (tr && tid == 0) { float *s = tr + D.tr_pcg + 4 * li; s[0] = pAp; s[1] = alpha; s[2] = rz_new; s[3] = beta; }
-            rz = rz_new;
-            for (int e = tid; e < n; e += nthr) vp[e] = vz[e] + beta * vp[e];
+#pragma unroll
+        for (int j = 0; j < kMaxRows; j++) {
+            const int row = lane + 64 * j;
+            const bool live = row < n;
+            r_[j] = live ? vb[row] : 0.0f; m_[j] = live ? vM[row] : 0.0f; d_[j] = 0.0f;
+            p_[j] = m_[j] * r_[j];
+            part += r_[j] * p_[j];
+            if (live) vp[row] = p_[j];
         }
+        float rz = wave_sum_all(part);
+        for (int li = 0; li < D.n_pcg; li++) {
+            float ap_[kMaxRows];
+#pragma unroll
+            for (int j = 0; j < kMaxRows; j++) ap_[j] = 0.0f;
+            const float *a0 = A + (size_t)min(lane, n - 1) * ld, *a1 = A + (size_t)min(lane + 64, n - 1) * ld;
+            const float *a2 = A + (size_t)min(lane + 128, n - 1) * ld, *a3 = A + (size_t)min(lane + 192, n - 1) * ld;
+            if (n <= 128) {
+                for (int c = 0; c < n; c++) { const float pc = vp[c]; ap_[0] += a0[c] * pc; ap_[1] += a1[c] * pc; }
+            } else {
+                for (int c = 0; c < n; c++) { const float pc = vp[c]; ap_[0] += a0[c] * pc; ap_[1] += a1[c] * pc; ap_[2] += a2[c] * pc; ap_[3] += a3[c] * pc; }
+            }
+            part = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kMaxRows; j++) part += (lane + 64 * j < n) ? p_[j] * ap_[j] : 0.0f;
+            const float pAp = wave_sum_all(part);
+            const float alpha = (pAp > kEps) ? rz / pAp : 0.0f;
+            float z_[kMaxRows];
+            part = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kMaxRows; j++) {
+                const bool live = lane + 64 * j < n;
+                d_[j] = d_[j] + alpha * p_[j];
+                r_[j] = r_[j] - alpha * (live ? ap_[j] : 0.0f);
+                z_[j] = m_[j] * r_[j];
+                part += z_[j] * r_[j];
+            }
+            const float rz_new = wave_sum_all(part);
+            const float beta = (rz > kEps) ? rz_new / rz : 0.0f;
+            if (tr && lane == 0) { float *sc = tr + D.tr_pcg + 4 * li; sc[0] = pAp; sc[1] = alpha; sc[2] = rz_new; sc[3] = beta; }
+            rz = rz_new;
+#pragma unroll
+            for (int j = 0; j < kMaxRows; j++) {
+                p_[j] = z_[j] + beta * p_[j];
+                if (lane + 64 * j < n) vp[lane + 64 * j] = p_[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxRows; j++) if (lane + 64 * j < n) vd[lane + 64 * j] = d_[j];
     }
     __syncthreads();
 

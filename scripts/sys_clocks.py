@@ -21,8 +21,8 @@ def main():
         poses_d = torch.from_numpy(np.stack([p["poses"] for p in pick])).to(dev)
         tv = bs.trace_view(bs.solve(cam_d, nrm_d, pick[0]["intr"], corr_d, offs_d, mx, poses_d, trace=True))
         clk = tv.clk[0]          # [n_gn, 8]
-        d = np.diff(np.concatenate([np.zeros((clk.shape[0], 1)), clk[:, :5]], 1), axis=1)
-        print(f"B={B}: k_system_solve phase shader-clock cycles (mean over GN iterations): reduce {d[:,0].mean():.0f}  congruence {d[:,1].mean():.0f}  assemble(+trace dump) {d[:,2].mean():.0f}  PCG {d[:,3].mean():.0f}  update {d[:,4].mean():.0f}  total {clk[:,4].mean():.0f}")
+        c = clk.mean(0)
+        print(f"B={B}: k_system_solve phase shader-clock cycles (mean over GN iterations): reduce {c[0]:.0f}  congruence {c[1]-c[0]:.0f}  assemble {c[2]-c[1]:.0f}  [trace dump {c[5]-c[2]:.0f}]  PCG {c[3]-c[5]:.0f}  update {c[4]-c[3]:.0f}  total w/o dump {c[4]-(c[5]-c[2]):.0f}")
 
 
 if __name__ == "__main__":
