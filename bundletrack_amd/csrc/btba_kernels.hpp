@@ -480,7 +480,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     float *scratch = vd + n;              // 16 floats
     float *vT = scratch + 16;             // this iterate's T[N][16]
     int *dense_pairs_lds = reinterpret_cast<int *>(vT + 16 * N);   // target frame of every dense pair
-    float *ps = D.pairsum_in_lds ? reinterpret_cast<float *>(dense_pairs_lds + D.n_dense_pairs) : pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals);
+    int *adj_off_l = dense_pairs_lds + D.n_dense_pairs, *adj_l = adj_off_l + (N + 1);      // adjacency staged in LDS
+    float *ps = D.pairsum_in_lds ? reinterpret_cast<float *>(adj_l + 2 * D.n_dense_pairs) : pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals);
     float *pd = ps + (size_t)D.n_pairs * kSparseVals;          // model-frame dense pair sums (S, g, count)
     float *pdr = pd + (size_t)D.n_dense_pairs * kDenseVals;     // camera-frame sums as the sweep produced them
     float *tr = D.trace_on ? trace + ((size_t)b * D.n_gn + iter) * D.trace_record : nullptr;
@@ -489,6 +490,10 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
 #define BTBA_STAMP(slot) do { if (tr && tid == 0) tr[D.tr_clk + (slot)] = (float)((long long)clock64() - clk0); } while (0)
     for (int e = tid; e < 16 * N; e += nthr) vT[e] = T[16 * (size_t)b * N + e];
     for (int e = tid; e < D.n_dense_pairs; e += nthr) dense_pairs_lds[e] = dense_pairs[e].x;
+    if (D.use_dense) {
+        for (int e = tid; e < N + 1; e += nthr) adj_off_l[e] = adj_off[e];
+        for (int e = tid; e < 2 * D.n_dense_pairs; e += nthr) adj_l[e] = adj[e];
+    }
     // Phase A: fixed-order reduction of the sweep partials (4 independent loads in flight per lane)
     if (D.use_sparse) {
         const float *src = sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals;
@@ -600,7 +605,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
         }
         if (D.use_dense) {
             const int t21 = tri21(r, c);
-            for (int q = adj_off[k]; q < adj_off[k + 1]; q++) v += pd[(size_t)(adj[q] >> 1) * kDenseVals + t21];
+            for (int q = adj_off_l[k]; q < adj_off_l[k + 1]; q++) v += pd[(size_t)(adj_l[q] >> 1) * kDenseVals + t21];
         }
         A[(6 * k + r) * ld + 6 * k + c] = v;
     }
@@ -625,8 +630,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             }
             if (D.use_dense) {
                 float jtr = 0.0f;
-                for (int q = adj_off[k]; q < adj_off[k + 1]; q++) {
-                    const int a = adj[q];
+                for (int q = adj_off_l[k]; q < adj_off_l[k + 1]; q++) {
+                    const int a = adj_l[q];
                     const float g = pd[(size_t)(a >> 1) * kDenseVals + 21 + r];
                     jtr += (a & 1) ? g : -g;            // source frame: row_j = a;  target frame: row_i = -a
                 }
@@ -676,8 +681,10 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             const float *a0 = A + (size_t)min(lane, n - 1) * ld, *a1 = A + (size_t)min(lane + 64, n - 1) * ld;
             const float *a2 = A + (size_t)min(lane + 128, n - 1) * ld, *a3 = A + (size_t)min(lane + 192, n - 1) * ld;
             if (n <= 128) {
+_Pragma("unroll 16")
                 for (int c = 0; c < n; c++) { const float pc = vp[c]; ap_[0] += a0[c] * pc; ap_[1] += a1[c] * pc; }
             } else {
+_Pragma("unroll 8")
                 for (int c = 0; c < n; c++) { const float pc = vp[c]; ap_[0] += a0[c] * pc; ap_[1] += a1[c] * pc; ap_[2] += a2[c] * pc; ap_[3] += a3[c] * pc; }
             }
             part = 0.0f;

@@ -86,7 +86,7 @@ def test_c5_shape_batch_properties(gpu):
     out2, _, _ = run_gpu(gpu, pbs32)
     assert np.array_equal(out, out2) and np.isfinite(out).all()
     from bundletrack_amd import _lib
-    out3, _, _ = run_gpu(gpu, pbs32, flags=_lib.FLAG_NO_OVERLAP)      # one stream, one piece: same bits as the two-stream pipeline
+    out3, _, _ = run_gpu(gpu, pbs32, flags=_lib.FLAG_OVERLAP)         # two-stream half-batch pipeline: same bits as one stream
     assert np.array_equal(out, out3)
     for b in range(4, 32):
         assert np.array_equal(out[b], out[b % 4])            # same instance data -> same bits wherever it sits in the grid
