@@ -479,9 +479,10 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     float *vM = vb + n, *vz = vM + n, *vp = vz + n, *vAp = vp + n, *vd = vAp + n;
     float *scratch = vd + n;              // 16 floats
     float *vT = scratch + 16;             // this iterate's T[N][16]
-    int *dense_pairs_lds = reinterpret_cast<int *>(vT + 16 * N);   // target frame of every dense pair
-    int *adj_off_l = dense_pairs_lds + D.n_dense_pairs, *adj_l = adj_off_l + (N + 1);      // adjacency staged in LDS
-    float *ps = D.pairsum_in_lds ? reinterpret_cast<float *>(adj_l + 2 * D.n_dense_pairs) : pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals);
+    int *dense_pairs_lds = reinterpret_cast<int *>(vT + 16 * N);   // (target, source) of every dense pair: 2 Pd ints
+    int *adj_off_l = dense_pairs_lds + 2 * D.n_dense_pairs, *adj_l = adj_off_l + (N + 1);      // adjacency staged in LDS
+    int *pair_ij_l = adj_l + 2 * D.n_dense_pairs;                  // canonical pair p -> (i << 8 | j): P ints
+    float *ps = D.pairsum_in_lds ? reinterpret_cast<float *>(pair_ij_l + D.n_pairs) : pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals);
     float *pd = ps + (size_t)D.n_pairs * kSparseVals;          // model-frame dense pair sums (S, g, count)
     float *pdr = pd + (size_t)D.n_dense_pairs * kDenseVals;     // camera-frame sums as the sweep produced them
     float *tr = D.trace_on ? trace + ((size_t)b * D.n_gn + iter) * D.trace_record : nullptr;
@@ -489,7 +490,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     const long long clk0 = tr ? (long long)clock64() : 0;
 #define BTBA_STAMP(slot) do { if (tr && tid == 0) tr[D.tr_clk + (slot)] = (float)((long long)clock64() - clk0); } while (0)
     for (int e = tid; e < 16 * N; e += nthr) vT[e] = T[16 * (size_t)b * N + e];
-    for (int e = tid; e < D.n_dense_pairs; e += nthr) dense_pairs_lds[e] = dense_pairs[e].x;
+    for (int e = tid; e < D.n_dense_pairs; e += nthr) { const int2 ij = dense_pairs[e]; dense_pairs_lds[2 * e] = ij.x; dense_pairs_lds[2 * e + 1] = ij.y; }
+    for (int e = tid; e < D.n_pairs; e += nthr) { int i, j; pair_from_index(e, N, i, j); pair_ij_l[e] = (i << 8) | j; }
     if (D.use_dense) {
         for (int e = tid; e < N + 1; e += nthr) adj_off_l[e] = adj_off[e];
         for (int e = tid; e < 2 * D.n_dense_pairs; e += nthr) adj_l[e] = adj[e];
@@ -530,7 +532,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
         };
         for (int e = tid; e < D.n_dense_pairs * 27; e += nthr) {
             const int p = e / 27, idx = e % 27;
-            const float *Tt = vT + 16 * dense_pairs_lds[p];
+            const float *Tt = vT + 16 * dense_pairs_lds[2 * p];
             const float *Sp = pdr + (size_t)p * kDenseVals;
             float *So = pd + (size_t)p * kDenseVals;
             if (idx < 21) {
@@ -570,8 +572,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     // Phase B1: off-diagonal 6x6 blocks, one canonical pair (i<j) each: A_ij = -(ws Ji^T Jj + S_dense)
     for (int e = tid; e < D.n_pairs * 36; e += nthr) {
         const int p = e / 36, r = (e % 36) / 6, c = e % 6;
-        int i, j;
-        pair_from_index(p, N, i, j);
+        const int i = pair_ij_l[p] >> 8, j = pair_ij_l[p] & 255;
         if (i == 0) continue;
         float v = 0.0f;
         if (D.use_sparse) v -= D.w_sparse * sparse_cross_entry(ps + (size_t)p * kSparseVals, r, c);
@@ -584,7 +585,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
         // an explicit list; handle by serialising over dense pairs per block entry owner.
         for (int e = tid; e < D.n_dense_pairs * 36; e += nthr) {
             const int p = e / 36, r = (e % 36) / 6, c = e % 6;
-            const int2 ij = dense_pairs[p];
+            const int2 ij = make_int2(dense_pairs_lds[2 * p], dense_pairs_lds[2 * p + 1]);
             if (ij.x == 0 || ij.y == 0 || ij.x >= ij.y) continue;      // i>j: erased by FlipJtJ
             // duplicates of the same (i,j) in an explicit list are not supported (documented)
             const float s = pd[(size_t)p * kDenseVals + tri21(r, c)];
