@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     "btba_optimize_frames", "btba_build_cache", "btba_solve_batch", "btba_collect_stats",
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
+    "btba_process_depth", "btba_depth_to_normals",
 ]
 
 
@@ -121,6 +122,8 @@ def lib() -> C.CDLL:
         L.btba_bucket_correspondences.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         L.btba_matrices_to_poses.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.btba_poses_to_matrices.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.btba_process_depth.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
+        L.btba_depth_to_normals.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 

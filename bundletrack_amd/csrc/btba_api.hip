@@ -15,6 +15,7 @@
 
 #include "../../include/btba.h"
 #include "btba_kernels.hpp"
+#include "btba_image.hpp"
 
 using namespace btba;
 
@@ -616,6 +617,30 @@ int btba_poses_to_matrices(btba_workspace *ws, int n, const float *x_dev, float 
 {
     if (!ws || n < 1 || !x_dev || (!T_dev && !Tinv_dev)) return BTBA_EINVAL;
     k_poses_to_matrices<<<(n + 63) / 64, 64, 0, ws->stream>>>(n, x_dev, T_dev, Tinv_dev);
+    HIP_TRY(hipGetLastError());
+    return BTBA_OK;
+}
+
+int btba_process_depth(btba_workspace *ws, int H, int W, const float *depth_in_dev, float *depth_out_dev,
+                       int erode_radius, float erode_diff, float erode_ratio, int bf_radius, float sigma_d, float sigma_r)
+{
+    if (!ws || H < 1 || W < 1 || !depth_in_dev || !depth_out_dev || depth_in_dev == depth_out_dev) return BTBA_EINVAL;
+    if (erode_radius < 0 || bf_radius < 0 || erode_radius + 2 * bf_radius > 16 || !(sigma_d > 0.0f) || !(sigma_r > 0.0f)) return BTBA_EINVAL;
+    DepthFilterParams P{ W, H, erode_radius, erode_diff, erode_ratio, bf_radius, sigma_d, sigma_r };
+    const int h = erode_radius + 2 * bf_radius;
+    const size_t lds = 2 * sizeof(float) * (size_t)(kTileW + 2 * h) * (kTileH + 2 * h);
+    k_process_depth<<<dim3((W + kTileW - 1) / kTileW, (H + kTileH - 1) / kTileH), 256, lds, ws->stream>>>(P, depth_in_dev, depth_out_dev);
+    HIP_TRY(hipGetLastError());
+    return BTBA_OK;
+}
+
+int btba_depth_to_normals(btba_workspace *ws, int H, int W, const float *K, const float *depth_dev, float *normals_dev, float *xyz_dev)
+{
+    if (!ws || H < 1 || W < 1 || !K || !depth_dev || !normals_dev) return BTBA_EINVAL;
+    float intr[4];
+    Mat4 Kinv;
+    scaled_intrinsics(H, W, H, W, K, intr, &Kinv);       // only the generic cofactor inverse of the 4x4 embedding is used
+    k_depth_to_normals<<<dim3((W + 63) / 64, (H + 3) / 4), dim3(64, 4), 0, ws->stream>>>(W, H, Kinv, depth_dev, reinterpret_cast<float4 *>(normals_dev), reinterpret_cast<float4 *>(xyz_dev));
     HIP_TRY(hipGetLastError());
     return BTBA_OK;
 }

@@ -236,3 +236,29 @@ class BatchSolver:
         L, N, npd = self._last_layout
         self.ws.sync()
         return TraceView(L, tr.cpu().numpy(), N, npd, self.params.n_pcg_iters)
+
+
+# ---- the step before the boundary: Frame::processDepth / Frame::depthToCloudAndNormals ----
+DEPTH_PROCESSING_DEFAULTS = dict(erode_radius=1, erode_diff=0.001, erode_ratio=0.8, bf_radius=2, sigma_d=2.0, sigma_r=100000.0)   # config_ycbineoat.yml:9-16
+
+
+def process_depth(ws: Workspace, depth_gpu, **kw):
+    """Frame::processDepth (src/Frame.cpp:152-180) on a CUDA float32 [H,W] depth map; returns a new tensor."""
+    torch = _torch()
+    p = dict(DEPTH_PROCESSING_DEFAULTS); p.update(kw)
+    H, W = depth_gpu.shape
+    out = torch.empty_like(depth_gpu)
+    check(lib().btba_process_depth(ws.handle, H, W, depth_gpu.data_ptr(), out.data_ptr(), int(p["erode_radius"]), float(p["erode_diff"]), float(p["erode_ratio"]),
+                                   int(p["bf_radius"]), float(p["sigma_d"]), float(p["sigma_r"])), "btba_process_depth")
+    return out
+
+
+def depth_to_normals(ws: Workspace, depth_gpu, K, want_xyz=False):
+    """Frame::depthToCloudAndNormals (src/Frame.cpp:182-233): returns normals float4 [H,W,4] (and the xyz map)."""
+    torch = _torch()
+    H, W = depth_gpu.shape
+    normals = torch.empty((H, W, 4), dtype=torch.float32, device=depth_gpu.device)
+    xyz = torch.empty((H, W, 4), dtype=torch.float32, device=depth_gpu.device) if want_xyz else None
+    Kf = np.ascontiguousarray(K, np.float32).reshape(9)
+    check(lib().btba_depth_to_normals(ws.handle, H, W, Kf.ctypes.data, depth_gpu.data_ptr(), normals.data_ptr(), xyz.data_ptr() if xyz is not None else None), "btba_depth_to_normals")
+    return (normals, xyz) if want_xyz else normals

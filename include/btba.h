@@ -198,6 +198,21 @@ BTBA_API int btba_bucket_correspondences(const btba_entryj *in, uint32_t n, int 
 BTBA_API int btba_matrices_to_poses(btba_workspace *ws, int n, const float *T_dev, float *x_dev);
 BTBA_API int btba_poses_to_matrices(btba_workspace *ws, int n, const float *x_dev, float *T_dev, float *Tinv_dev);
 
+/* ---- the step before the boundary (what Frame's constructor runs per frame) ---- */
+/* Frame::processDepth (src/Frame.cpp:152-180): erode (CUDAImageUtil.cu:676-718) then the mean-gated bilateral
+ * filter twice (CUDAImageUtil.cu:735-797), fused in ONE launch.  depth_in_dev / depth_out_dev: device float[H*W]
+ * (must not alias).  Defaults of config_ycbineoat.yml:9-16: erode radius 1, diff 0.001, ratio 0.8; filter radius 2,
+ * sigma_D 2, sigma_R 100000.  Asynchronous on the workspace stream. */
+BTBA_API int btba_process_depth(btba_workspace *ws, int H, int W, const float *depth_in_dev, float *depth_out_dev,
+                                int erode_radius, float erode_diff, float erode_ratio,
+                                int bf_radius, float sigma_d, float sigma_r);
+
+/* Frame::depthToCloudAndNormals (src/Frame.cpp:182-233): depth -> camera-space points (CUDAImageUtil.cu:310-327)
+ * -> normals (computeNormals_Kernel, CUDAImageUtil.cu:342-412), ONE launch.  normals_dev: device float4[H*W]
+ * (xyz unit, w = 0, zeros = invalid: the optimiser's input format); xyz_dev: device float4[H*W] or NULL. */
+BTBA_API int btba_depth_to_normals(btba_workspace *ws, int H, int W, const float *K_rowmajor,
+                                   const float *depth_dev, float *normals_dev, float *xyz_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -842,3 +842,117 @@ ORC_API int orc_sparse_apply(const orc_params *prm, int N, const orc_entryj *cor
     free(corr); free(tab.rows); free(tab.counts); free(pR); free(pT); free(Jp);
     return 0;
 }
+
+/* ==== SURVEY.md 8(f) rank 3: depth pre-processing and normals (Frame::processDepth, Frame.cpp:152-180;
+ * Frame::depthToCloudAndNormals, Frame.cpp:182-233) ========================================= */
+
+/* erodeDepthMapDevice, CUDAImageUtil.cu:676-718.  Out-of-image neighbours are not counted but the
+ * denominator is the full window. */
+ORC_API void orc_erode_depth(const float *in, float *out, int W, int H, int radius, float dThresh, float fracReq)
+{
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            unsigned count = 0;
+            const float oldDepth = in[y * W + x];
+            if (oldDepth <= 0.1f) { out[y * W + x] = 0; continue; }
+            for (int i = -radius; i <= radius; i++)
+                for (int j = -radius; j <= radius; j++)
+                    if (x + j >= 0 && x + j < W && y + i >= 0 && y + i < H) {
+                        const float d = in[(y + i) * W + (x + j)];
+                        if (d == -INFINITY || d < 0.1f || fabsf(d - oldDepth) > dThresh) count++;
+                    }
+            const unsigned sum = (2 * radius + 1) * (2 * radius + 1);
+            out[y * W + x] = ((float)count / (float)sum >= fracReq) ? 0.0f : in[y * W + x];
+        }
+}
+
+/* gaussFilterDepthMapDevice, CUDAImageUtil.cu:735-797 (a mean-gated bilateral filter) */
+ORC_API void orc_gauss_filter_depth(const float *in, float *out, int W, int H, int radius, float sigmaD, float sigmaR)
+{
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            out[y * W + x] = 0;
+            const float depthCenter = in[y * W + x];
+            float mean_depth = 0;
+            int num_valid = 0;
+            for (int m = x - radius; m <= x + radius; m++)
+                for (int n = y - radius; n <= y + radius; n++)
+                    if (m >= 0 && n >= 0 && m < W && n < H) {
+                        const float c = in[n * W + m];
+                        if (c >= 0.1f) { num_valid++; mean_depth += c; }
+                    }
+            if (num_valid == 0) continue;
+            mean_depth /= num_valid;
+            float sum = 0.0f, sumWeight = 0.0f;
+            for (int m = x - radius; m <= x + radius; m++)
+                for (int n = y - radius; n <= y + radius; n++)
+                    if (m >= 0 && n >= 0 && m < W && n < H) {
+                        const float c = in[n * W + m];
+                        if (c >= 0.1f && (double)fabsf(c - mean_depth) < 0.01) {
+                            const float weight = expf(-((m - x) * (m - x) + (y - n) * (y - n)) / (2.0f * sigmaD * sigmaD) - (depthCenter - c) * (depthCenter - c) / (2 * sigmaR * sigmaR));
+                            sumWeight += weight;
+                            sum += weight * c;
+                        }
+                    }
+            const float num_total = (float)((2 * radius + 1) * (2 * radius + 1));
+            if (sumWeight > 0.0f && num_valid / num_total > 0) out[y * W + x] = sum / sumWeight;
+        }
+}
+
+/* Frame::processDepth, Frame.cpp:152-180: erode, then the filter twice */
+ORC_API void orc_process_depth(const float *in, float *out, int W, int H, int erode_radius, float erode_diff, float erode_ratio,
+                               int bf_radius, float sigmaD, float sigmaR)
+{
+    float *a = (float *)malloc(sizeof(float) * (size_t)W * H), *b = (float *)malloc(sizeof(float) * (size_t)W * H);
+    orc_erode_depth(in, a, W, H, erode_radius, erode_diff, erode_ratio);
+    orc_gauss_filter_depth(a, b, W, H, bf_radius, sigmaD, sigmaR);
+    orc_gauss_filter_depth(b, out, W, H, bf_radius, sigmaD, sigmaR);
+    free(a); free(b);
+}
+
+/* convertDepthFloatToCameraSpaceFloat4 (CUDAImageUtil.cu:310-327) with K^-1 embedded in a 4x4 whose last row
+ * is (0,0,0,1) (Frame.cpp:187-197), then computeNormals_Kernel (CUDAImageUtil.cu:342-412).
+ * xyz may be NULL.  Kinv: row-major 4x4 (the generic cofactor inverse of the embedding, like the device path). */
+ORC_API void orc_depth_to_normals(const float *depth, int W, int H, const float *Kinv, float *normals, float *xyz_out)
+{
+    float *xyz = (float *)calloc((size_t)W * H * 4, sizeof(float));
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const float d = depth[y * W + x];
+            float *o = xyz + 4 * ((size_t)y * W + x);
+            if (d >= 0.1) {
+                const float v[4] = { (float)x * d, (float)y * d, d, d };
+                float c[4];
+                m4_vec4(Kinv, v, c);
+                o[0] = c[0]; o[1] = c[1]; o[2] = c[3]; o[3] = 1.0f;       /* (x, y, cameraSpace.w, 1) */
+            }
+        }
+    const float z_diff_thres = 0.02f;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            float *o = normals + 4 * ((size_t)y * W + x);
+            o[0] = o[1] = o[2] = o[3] = 0;
+            if (!(x > 0 && x < W - 1 && y > 0 && y < H - 1)) continue;
+            const float *CC = xyz + 4 * ((size_t)y * W + x), *PC = xyz + 4 * ((size_t)(y + 1) * W + x), *CP = xyz + 4 * ((size_t)y * W + x + 1);
+            const float *MC = xyz + 4 * ((size_t)(y - 1) * W + x), *CM = xyz + 4 * ((size_t)y * W + x - 1);
+            if (CC[2] < 0.1f) continue;
+            float xd[3], yd[3];
+            if (PC[2] >= 0.1f && MC[2] >= 0.1f && fabsf(PC[2] - CC[2]) <= z_diff_thres && fabsf(MC[2] - CC[2]) <= z_diff_thres) { for (int k = 0; k < 3; k++) xd[k] = PC[k] - MC[k]; }
+            else if (PC[2] >= 0.1f && fabsf(PC[2] - CC[2]) <= z_diff_thres) { for (int k = 0; k < 3; k++) xd[k] = PC[k] - CC[k]; }
+            else if (MC[2] >= 0.1f && fabsf(MC[2] - CC[2]) <= z_diff_thres) { for (int k = 0; k < 3; k++) xd[k] = MC[k] - CC[k]; }
+            else continue;
+            if (CP[2] >= 0.1f && CM[2] >= 0.1f && fabsf(CP[2] - CC[2]) <= z_diff_thres && fabsf(CM[2] - CC[2]) <= z_diff_thres) { for (int k = 0; k < 3; k++) yd[k] = CP[k] - CM[k]; }
+            else if (CP[2] >= 0.1f && fabsf(CP[2] - CC[2]) <= z_diff_thres) { for (int k = 0; k < 3; k++) yd[k] = CP[k] - CC[k]; }
+            else if (CM[2] >= 0.1f && fabsf(CM[2] - CC[2]) <= z_diff_thres) { for (int k = 0; k < 3; k++) yd[k] = CM[k] - CC[k]; }
+            else continue;
+            float n[3];
+            cross3(xd, yd, n);
+            const float l = len3(n);
+            n[0] = n[0] / l; n[1] = n[1] / l; n[2] = n[2] / l;
+            const float mcc[3] = { -CC[0], -CC[1], -CC[2] };
+            if (dot3(n, mcc) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+            if (l > 0.0f) { o[0] = n[0]; o[1] = n[1]; o[2] = n[2]; o[3] = 0.0f; }
+        }
+    if (xyz_out) memcpy(xyz_out, xyz, sizeof(float) * 4 * (size_t)W * H);
+    free(xyz);
+}

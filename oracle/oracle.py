@@ -222,3 +222,35 @@ def sparse_apply(corr, T, p, params: OrcParams | None = None) -> np.ndarray:
     out = np.zeros((N, 6), np.float32)
     lib().orc_sparse_apply(C.byref(prm), N, _p(corr), int(corr.shape[0]), _p(T.reshape(N, 16)), _p(p), _p(out))
     return out
+
+
+# ---- depth pre-processing and normals -------------------------------------------
+def erode_depth(depth, radius=1, diff=0.001, ratio=0.8) -> np.ndarray:
+    d = np.ascontiguousarray(depth, np.float32); H, W = d.shape
+    out = np.zeros_like(d)
+    lib().orc_erode_depth(_p(d), _p(out), W, H, int(radius), C.c_float(diff), C.c_float(ratio))
+    return out
+
+
+def gauss_filter_depth(depth, radius=2, sigma_d=2.0, sigma_r=100000.0) -> np.ndarray:
+    d = np.ascontiguousarray(depth, np.float32); H, W = d.shape
+    out = np.zeros_like(d)
+    lib().orc_gauss_filter_depth(_p(d), _p(out), W, H, int(radius), C.c_float(sigma_d), C.c_float(sigma_r))
+    return out
+
+
+def process_depth(depth, erode_radius=1, erode_diff=0.001, erode_ratio=0.8, bf_radius=2, sigma_d=2.0, sigma_r=100000.0) -> np.ndarray:
+    d = np.ascontiguousarray(depth, np.float32); H, W = d.shape
+    out = np.zeros_like(d)
+    lib().orc_process_depth(_p(d), _p(out), W, H, int(erode_radius), C.c_float(erode_diff), C.c_float(erode_ratio), int(bf_radius), C.c_float(sigma_d), C.c_float(sigma_r))
+    return out
+
+
+def depth_to_normals(depth, K):
+    """Returns (normals [H,W,4], xyz [H,W,4]).  K^-1 through the same generic cofactor inverse as the device math."""
+    d = np.ascontiguousarray(depth, np.float32); H, W = d.shape
+    K4 = np.eye(4, dtype=np.float32); K4[:3, :3] = np.asarray(K, np.float32)
+    Ki = np.ascontiguousarray(mat4_inverse(K4), np.float32).reshape(16)
+    normals = np.zeros((H, W, 4), np.float32); xyz = np.zeros((H, W, 4), np.float32)
+    lib().orc_depth_to_normals(_p(d), W, H, _p(Ki), _p(normals), _p(xyz))
+    return normals, xyz
