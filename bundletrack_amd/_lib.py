@@ -28,7 +28,7 @@ ENTRYJ_DTYPE = np.dtype(
 
 EXPORTED_SYMBOLS = [
     "btba_params_default", "btba_strerror", "btba_last_hip_error", "btba_version",
-    "btba_workspace_create", "btba_workspace_destroy", "btba_workspace_sync",
+    "btba_workspace_create", "btba_workspace_create_on_stream", "btba_workspace_destroy", "btba_workspace_sync",
     "btba_optimize_frames", "btba_build_cache", "btba_solve_batch", "btba_collect_stats",
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
@@ -105,6 +105,7 @@ def lib() -> C.CDLL:
         for name in EXPORTED_SYMBOLS:
             getattr(L, name)           # AttributeError if the ABI and the header drift apart
         L.btba_workspace_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p]
+        L.btba_workspace_create_on_stream.argtypes = [C.POINTER(C.c_void_p), C.c_void_p]
         L.btba_workspace_destroy.argtypes = [C.c_void_p]
         L.btba_workspace_destroy.restype = None
         L.btba_workspace_sync.argtypes = [C.c_void_p]

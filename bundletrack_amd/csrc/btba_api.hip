@@ -114,7 +114,12 @@ const char *btba_strerror(int status)
 int btba_last_hip_error(void) { return g_last_hip_error; }
 int btba_version(void) { return BTBA_VERSION; }
 
-int btba_workspace_create(btba_workspace **out, void *stream)
+static int workspace_create(btba_workspace **out, void *stream, bool use_given);
+
+int btba_workspace_create(btba_workspace **out, void *stream) { return workspace_create(out, stream, stream != nullptr); }
+int btba_workspace_create_on_stream(btba_workspace **out, void *stream) { return workspace_create(out, stream, true); }
+
+static int workspace_create(btba_workspace **out, void *stream, bool use_given)
 {
     if (!out) return BTBA_EINVAL;
     *out = nullptr;
@@ -124,8 +129,8 @@ int btba_workspace_create(btba_workspace **out, void *stream)
     btba_workspace *ws = new (std::nothrow) btba_workspace();
     if (!ws) return BTBA_ENOMEM;
     if (hipGetDevice(&ws->device) != hipSuccess) { delete ws; return BTBA_EHIP; }
-    if (stream) {
-        ws->stream = reinterpret_cast<hipStream_t>(stream);
+    if (use_given) {
+        ws->stream = reinterpret_cast<hipStream_t>(stream);       // may be the NULL stream
     } else {
         hipError_t e = hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { g_last_hip_error = (int)e; delete ws; return BTBA_EHIP; }

@@ -31,8 +31,11 @@ class Workspace:
             torch = _torch()
             if not torch.cuda.is_available():
                 raise RuntimeError("bundletrack_amd needs a GPU: torch.cuda.is_available() is False (no CPU fallback)")
-            stream = torch.cuda.current_stream().cuda_stream
-        check(lib().btba_workspace_create(C.byref(h), C.c_void_p(stream) if stream else None), "btba_workspace_create")
+            # torch's default stream is the NULL stream (handle 0): it must be used AS IS, otherwise the workspace
+            # would run on a private non-blocking stream that does not order with torch's copies and kernels.
+            check(lib().btba_workspace_create_on_stream(C.byref(h), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "btba_workspace_create_on_stream")
+        else:
+            check(lib().btba_workspace_create(C.byref(h), C.c_void_p(stream) if stream else None), "btba_workspace_create")
         self._h = h
 
     @property

@@ -134,6 +134,9 @@ BTBA_API int btba_version(void);
 /* One workspace = one HIP stream + reusable device scratch.  `stream` may be NULL (the
  * workspace then creates and owns a non-blocking stream).  Re-entrant across workspaces. */
 BTBA_API int btba_workspace_create(btba_workspace **out, void *stream);
+/* Same, but `stream` is used as given even when it is the NULL (legacy default) stream -- what a framework whose
+ * "current stream" is the default stream (PyTorch) needs so that its own copies and kernels order with the solver. */
+BTBA_API int btba_workspace_create_on_stream(btba_workspace **out, void *stream);
 BTBA_API void btba_workspace_destroy(btba_workspace *ws);
 BTBA_API int btba_workspace_sync(btba_workspace *ws);
 
