@@ -332,7 +332,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     if (lds_bytes > lds_limit) return BTBA_EINVAL;
     if (!D.pairsum_in_lds) { if ((rc = ws->pairsum.ensure((size_t)B * lds_pairs + 16))) return rc; }
     if (lds_bytes > 64 * 1024 || !ws->lds_attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         ws->lds_attr_set = true;
     }
 
@@ -401,7 +402,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                 if ((rc = time_end(ws, slot, H.st))) return rc;
             }
             if ((rc = time_begin(ws, timing, 2, &slot, H.st))) return rc;
-            k_system_solve<<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h);
+            if (D.pairsum_in_lds) k_system_solve<true><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h);
+            else k_system_solve<false><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h);
             if ((rc = time_end(ws, slot, H.st))) return rc;
         }
     }

@@ -465,6 +465,7 @@ __device__ __forceinline__ float strided_sum(const float *__restrict__ q, int co
 
 // grid (B); dynamic LDS: A[n*ld] + 7 vectors[n] + scratch + (optionally) reduced pair sums.
 // cross_ok[p] (dense) = 1 when the dense cross block survives FlipJtJ (target < source).
+template <bool LDS_PAIRS>
 __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int iter,
                                                         const float *__restrict__ sparse_partials, const float *__restrict__ dense_partials,
                                                         const int2 *__restrict__ dense_pairs, const int *__restrict__ adj_off, const int *__restrict__ adj,
@@ -482,7 +483,11 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     int *dense_pairs_lds = reinterpret_cast<int *>(vT + 16 * N);   // (target, source) of every dense pair: 2 Pd ints
     int *adj_off_l = dense_pairs_lds + 2 * D.n_dense_pairs, *adj_l = adj_off_l + (N + 1);      // adjacency staged in LDS
     int *pair_ij_l = adj_l + 2 * D.n_dense_pairs;                  // canonical pair p -> (i << 8 | j): P ints
-    float *ps = D.pairsum_in_lds ? reinterpret_cast<float *>(pair_ij_l + D.n_pairs) : pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals);
+    // reduced pair sums: in LDS when they fit (address space known at compile time -> ds_* instructions, not flat_*),
+    // otherwise in an L2-resident global scratch (K = 30)
+    float *ps;
+    if (LDS_PAIRS) ps = reinterpret_cast<float *>(pair_ij_l + D.n_pairs);
+    else ps = pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals);
     float *pd = ps + (size_t)D.n_pairs * kSparseVals;          // model-frame dense pair sums (S, g, count)
     float *pdr = pd + (size_t)D.n_dense_pairs * kDenseVals;     // camera-frame sums as the sweep produced them
     float *tr = D.trace_on ? trace + ((size_t)b * D.n_gn + iter) * D.trace_record : nullptr;
