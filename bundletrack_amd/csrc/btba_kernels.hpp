@@ -474,11 +474,11 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    const int N = D.n_frames, n = 6 * N, ld = n | 1;
+    const int N = D.n_frames, n = 6 * N, ld = 4 * (((n + 3) / 4) | 1);   // odd multiple of 4: 16-B rows, conflict-free ds_read_b128
     float *A = lds;
-    float *vb = A + (size_t)n * ld;       // rhs / residual r
-    float *vM = vb + n, *vz = vM + n, *vp = vz + n, *vAp = vp + n, *vd = vAp + n;
-    float *scratch = vd + n;              // 16 floats
+    float *vb = A + (size_t)n * ld;       // rhs / residual r   (A's pad columns n..ld-1 stay 0)
+    float *vM = vb + ld, *vz = vM + ld, *vp = vz + ld, *vAp = vp + ld, *vd = vAp + ld;     // vector stride ld (16-B aligned, zero padded)
+    float *scratch = vd + ld;             // 16 floats
     float *vT = scratch + 16;             // this iterate's T[N][16]
     int *dense_pairs_lds = reinterpret_cast<int *>(vT + 16 * N);   // (target, source) of every dense pair: 2 Pd ints
     int *adj_off_l = dense_pairs_lds + 2 * D.n_dense_pairs, *adj_l = adj_off_l + (N + 1);      // adjacency staged in LDS
@@ -502,22 +502,33 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
         for (int e = tid; e < 2 * D.n_dense_pairs; e += nthr) adj_l[e] = adj[e];
     }
     // Phase A: fixed-order reduction of the sweep partials (4 independent loads in flight per lane)
-    if (D.use_sparse) {
-        const float *src = sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals;
-        for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) {
-            const int p = e / kSparseVals, k = e % kSparseVals;
-            ps[e] = strided_sum(src + (size_t)p * D.sparse_chunks * kSparseVals + k, D.sparse_chunks, kSparseVals);
+    // (two items per lane per trip, all their loads issued before the first add: the partials come from other
+    //  CUs' write-through stores, i.e. every load is an L2 miss of ~1-2 k cycles, so memory-level parallelism is
+    //  what this phase is made of)
+    auto reduce_partials = [&](const float *src, float *dst, int n_items_pairs, int vals, int parts) {
+        const int total = n_items_pairs * vals;
+        for (int e = tid; e < total; e += 2 * nthr) {
+            const int e2 = e + nthr;
+            const bool live2 = e2 < total;
+            const int e2c = live2 ? e2 : e;
+            const float *qa = src + (size_t)(e / vals) * parts * vals + (e % vals);
+            const float *qb = src + (size_t)(e2c / vals) * parts * vals + (e2c % vals);
+            float sa = 0.0f, sb = 0.0f;
+            int c = 0;
+            for (; c + 4 <= parts; c += 4) {
+                const float a0 = qa[(size_t)c * vals], a1 = qa[(size_t)(c + 1) * vals], a2 = qa[(size_t)(c + 2) * vals], a3 = qa[(size_t)(c + 3) * vals];
+                const float b0 = qb[(size_t)c * vals], b1 = qb[(size_t)(c + 1) * vals], b2 = qb[(size_t)(c + 2) * vals], b3 = qb[(size_t)(c + 3) * vals];
+                sa += a0; sa += a1; sa += a2; sa += a3;
+                sb += b0; sb += b1; sb += b2; sb += b3;
+            }
+            for (; c < parts; c++) { const float a0 = qa[(size_t)c * vals], b0 = qb[(size_t)c * vals]; sa += a0; sb += b0; }
+            dst[e] = sa;
+            if (live2) dst[e2] = sb;
         }
-    } else {
-        for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) ps[e] = 0.0f;
-    }
-    if (D.use_dense) {
-        const float *src = dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals;
-        for (int e = tid; e < D.n_dense_pairs * kDenseVals; e += nthr) {
-            const int p = e / kDenseVals, k = e % kDenseVals;
-            pdr[e] = strided_sum(src + (size_t)p * D.dense_tiles * kDenseVals + k, D.dense_tiles, kDenseVals);
-        }
-    }
+    };
+    if (D.use_sparse) reduce_partials(sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals, ps, D.n_pairs, kSparseVals, D.sparse_chunks);
+    else for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) ps[e] = 0.0f;
+    if (D.use_dense) reduce_partials(dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals, pdr, D.n_dense_pairs, kDenseVals, D.dense_tiles);
     for (int e = tid; e < n * ld; e += nthr) A[e] = 0.0f;
     __syncthreads();
     BTBA_STAMP(0);
@@ -648,6 +659,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
         vM[e] = (k > 0) ? ((md > kEps) ? 1.0f / md : 1.0f) : 0.0f;
         vd[e] = 0.0f;
     }
+    for (int e = n + tid; e < ld; e += nthr) vp[e] = 0.0f;      // pad of p: read by the 16-byte mat-vec chunks
     __syncthreads();
     BTBA_STAMP(2);
     if (tr) {
@@ -684,14 +696,26 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             float ap_[kMaxRows];
 #pragma unroll
             for (int j = 0; j < kMaxRows; j++) ap_[j] = 0.0f;
-            const float *a0 = A + (size_t)min(lane, n - 1) * ld, *a1 = A + (size_t)min(lane + 64, n - 1) * ld;
-            const float *a2 = A + (size_t)min(lane + 128, n - 1) * ld, *a3 = A + (size_t)min(lane + 192, n - 1) * ld;
+            const float4 *a0 = reinterpret_cast<const float4 *>(A + (size_t)min(lane, n - 1) * ld), *a1 = reinterpret_cast<const float4 *>(A + (size_t)min(lane + 64, n - 1) * ld);
+            const float4 *a2 = reinterpret_cast<const float4 *>(A + (size_t)min(lane + 128, n - 1) * ld), *a3 = reinterpret_cast<const float4 *>(A + (size_t)min(lane + 192, n - 1) * ld);
+            const float4 *p4 = reinterpret_cast<const float4 *>(vp);
+            const int nq = ld >> 2;                       // 16-byte chunks per row (pad columns hold zeros)
             if (n <= 128) {
-_Pragma("unroll 16")
-                for (int c = 0; c < n; c++) { const float pc = vp[c]; ap_[0] += a0[c] * pc; ap_[1] += a1[c] * pc; }
-            } else {
 _Pragma("unroll 8")
-                for (int c = 0; c < n; c++) { const float pc = vp[c]; ap_[0] += a0[c] * pc; ap_[1] += a1[c] * pc; ap_[2] += a2[c] * pc; ap_[3] += a3[c] * pc; }
+                for (int c = 0; c < nq; c++) {
+                    const float4 pc = p4[c], r0 = a0[c], r1 = a1[c];
+                    ap_[0] += r0.x * pc.x + r0.y * pc.y + r0.z * pc.z + r0.w * pc.w;
+                    ap_[1] += r1.x * pc.x + r1.y * pc.y + r1.z * pc.z + r1.w * pc.w;
+                }
+            } else {
+_Pragma("unroll 4")
+                for (int c = 0; c < nq; c++) {
+                    const float4 pc = p4[c], r0 = a0[c], r1 = a1[c], r2 = a2[c], r3 = a3[c];
+                    ap_[0] += r0.x * pc.x + r0.y * pc.y + r0.z * pc.z + r0.w * pc.w;
+                    ap_[1] += r1.x * pc.x + r1.y * pc.y + r1.z * pc.z + r1.w * pc.w;
+                    ap_[2] += r2.x * pc.x + r2.y * pc.y + r2.z * pc.z + r2.w * pc.w;
+                    ap_[3] += r3.x * pc.x + r3.y * pc.y + r3.z * pc.z + r3.w * pc.w;
+                }
             }
             part = 0.0f;
 #pragma unroll
