@@ -20,7 +20,7 @@ HEADER = os.path.join(_ROOT, "include", "btba.h")
 BTBA_OK, BTBA_EINVAL, BTBA_EHIP, BTBA_ENUMERIC, BTBA_ENOMEM = 0, 1, 2, 3, 4
 PAIRS_TARGET_LOWER, PAIRS_TARGET_MORE_VALID, PAIRS_EXPLICIT = 0, 1, 2
 FLAG_TRACE, FLAG_TIME_KERNELS, FLAG_NO_GRAPH = 1, 2, 4
-FLAG_DENSE_2PIX, FLAG_DENSE_4WAVE, FLAG_OVERLAP = 8, 16, 32
+FLAG_DENSE_2PIX, FLAG_DENSE_4WAVE, FLAG_OVERLAP, FLAG_NO_FUSE = 8, 16, 32, 64
 
 ENTRYJ_DTYPE = np.dtype(
     [("imgIdx_i", "<u4"), ("imgIdx_j", "<u4"), ("pos_i", "<f4", (3,)), ("pos_j", "<f4", (3,))]
@@ -55,6 +55,7 @@ class Stats(C.Structure):
         ("ms_dense_sweep", C.c_float), ("ms_sparse_sweep", C.c_float), ("ms_system_solve", C.c_float),
         ("n_dense_launches", C.c_int32), ("n_sparse_launches", C.c_int32), ("n_solve_launches", C.c_int32),
         ("bytes_dense_alg", C.c_int64), ("bytes_sparse_alg", C.c_int64),
+        ("fused_sweeps", C.c_int32), ("reserved_", C.c_int32),
     ]
 
     def as_dict(self):

@@ -386,20 +386,31 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             float *ps_h = ws->pairsum.p ? ws->pairsum.as<float>() + b0 * pairsum_floats : nullptr;
             float *tr_h = trace ? trace + b0 * (size_t)D.n_gn * D.trace_record : nullptr;
             size_t slot;
-            if (use_sparse) {
-                if ((rc = time_begin(ws, timing, 1, &slot, H.st))) return rc;
-                k_sparse_sweep<<<dim3(chunks, P, H.nb), kBlock, 0, H.st>>>(D, corr_h, off_h, T_h, sp_h);
-                if ((rc = time_end(ws, slot, H.st))) return rc;
-            }
-            if (use_dense) {
+            const unsigned n_d = (unsigned)tiles * D.n_dense_pairs * H.nb, n_s = (unsigned)chunks * P * H.nb;
+            const bool fuse = use_sparse && use_dense && n_s >= 64 && n_d >= 64 && !(prm->flags & (BTBA_FLAG_NO_FUSE | BTBA_FLAG_DENSE_2PIX | BTBA_FLAG_DENSE_4WAVE));
+            if (fuse) {
+                // one launch: HBM-streaming sparse workgroups interleaved with the VALU-bound dense ones
                 if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
-                const dim3 dgrid((unsigned)tiles * D.n_dense_pairs * H.nb);
-#define BTBA_DENSE_ARGS D, reinterpret_cast<const float4 *>(campos_h), reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h
-                if (prm->flags & BTBA_FLAG_DENSE_2PIX) k_dense_sweep<2, 2><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
-                else if (prm->flags & BTBA_FLAG_DENSE_4WAVE) k_dense_sweep<1, 4><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
-                else k_dense_sweep<1, 3><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
-#undef BTBA_DENSE_ARGS
+                k_fused_sweeps<<<dim3(n_d + n_s), kBlock, 0, H.st>>>(D, n_d, n_s, reinterpret_cast<const float4 *>(campos_h), reinterpret_cast<const float4 *>(normals_h),
+                                                                     ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, corr_h, off_h, sp_h);
                 if ((rc = time_end(ws, slot, H.st))) return rc;
+                S.fused_sweeps = 1;
+            } else {
+                if (use_sparse) {
+                    if ((rc = time_begin(ws, timing, 1, &slot, H.st))) return rc;
+                    k_sparse_sweep<<<dim3(chunks, P, H.nb), kBlock, 0, H.st>>>(D, corr_h, off_h, T_h, sp_h);
+                    if ((rc = time_end(ws, slot, H.st))) return rc;
+                }
+                if (use_dense) {
+                    if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
+                    const dim3 dgrid(n_d);
+#define BTBA_DENSE_ARGS D, reinterpret_cast<const float4 *>(campos_h), reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h
+                    if (prm->flags & BTBA_FLAG_DENSE_2PIX) k_dense_sweep<2, 2><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
+                    else if (prm->flags & BTBA_FLAG_DENSE_4WAVE) k_dense_sweep<1, 4><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
+                    else k_dense_sweep<1, 3><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
+#undef BTBA_DENSE_ARGS
+                    if ((rc = time_end(ws, slot, H.st))) return rc;
+                }
             }
             if ((rc = time_begin(ws, timing, 2, &slot, H.st))) return rc;
             if (D.pairsum_in_lds) k_system_solve<true><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h);

@@ -162,11 +162,9 @@ __global__ void __launch_bounds__(kBlock) k_build_cache(int W, int H, int Wd, in
 // ---- sparse sweep -----------------------------------------------------------------------------
 // grid (sparse_chunks, P, B).  Workgroup (c, p, b) owns slice c of pair p's contiguous EntryJ
 // segment: two coalesced 16-byte loads per correspondence, 44 register accumulators per lane.
-__global__ void __launch_bounds__(kBlock) k_sparse_sweep(SolveDims D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
-                                                        const float *__restrict__ T, float *__restrict__ partials)
+__device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
+                                             const float *__restrict__ T, float *__restrict__ partials, int chunk, int p, int b, float *red)
 {
-    __shared__ float red[4 * kSparseVals];
-    const int chunk = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
     int fi, fj;
     pair_from_index(p, D.n_frames, fi, fj);
     const uint32_t *off = pair_offsets + (size_t)b * (D.n_pairs + 1);
@@ -220,6 +218,14 @@ __global__ void __launch_bounds__(kBlock) k_sparse_sweep(SolveDims D, const floa
     }
     float *out = partials + (((size_t)b * D.n_pairs + p) * D.sparse_chunks + chunk) * kSparseVals;
     block_reduce_store<kSparseVals, 4>(acc, red, out);
+}
+
+// grid (sparse_chunks, P, B).  Workgroup (c, p, b) owns slice c of pair p's contiguous EntryJ segment.
+__global__ void __launch_bounds__(kBlock) k_sparse_sweep(SolveDims D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
+                                                        const float *__restrict__ T, float *__restrict__ partials)
+{
+    __shared__ float red[4 * kSparseVals];
+    sparse_block(D, corr, pair_offsets, T, partials, blockIdx.x, blockIdx.y, blockIdx.z, red);
 }
 
 // ---- dense sweep ------------------------------------------------------------------------------
@@ -335,16 +341,11 @@ __device__ __forceinline__ void pixel_accumulate(const DenseCtx &C, const PixelG
 // 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).  Lane = consecutive source pixel (coalesced
 // float4 loads of the source camPos / normal); two pixels per lane per trip, sixteen target-tap gathers in
 // flight; the taps stay in L1/L2 because neighbouring source pixels project to neighbouring target pixels.
-template <int PIX, int WAVES>
-__global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, const float4 *__restrict__ campos, const float4 *__restrict__ normals,
-                                                       const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
-                                                       float *__restrict__ partials)
+template <int PIX>
+__device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__restrict__ campos, const float4 *__restrict__ normals,
+                                            const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
+                                            float *__restrict__ partials, int tile, int p, int b, float *red)
 {
-    __shared__ float red[4 * kDenseVals];
-    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = (int)(L % (unsigned)D.dense_tiles);
-    const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
-    const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
     const int2 ij = dense_pairs[p];
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
@@ -395,6 +396,55 @@ __global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, cons
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
     block_reduce_store<kDenseVals, 4>(acc, red, out);
+}
+
+// 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).
+template <int PIX, int WAVES>
+__global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, const float4 *__restrict__ campos, const float4 *__restrict__ normals,
+                                                              const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
+                                                              float *__restrict__ partials)
+{
+    __shared__ float red[4 * kDenseVals];
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = (int)(L % (unsigned)D.dense_tiles);
+    const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
+    const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
+    dense_block<PIX>(D, campos, normals, dense_pairs, T, Tinv, partials, tile, p, b, red);
+}
+
+// Both sweeps of one Gauss-Newton iteration in ONE launch: n_d dense workgroups (VALU-bound) interleaved with
+// n_s sparse workgroups (HBM-streaming) so the two overlap on every CU instead of running back to back.
+// Per XCD x (blocks g = 8 s + x, s = slot): a contiguous range of dense items (L2 locality, as in xcd_remap)
+// and every R_x-th slot a sparse item.
+__global__ void __launch_bounds__(kBlock, 3) k_fused_sweeps(SolveDims D, unsigned n_d, unsigned n_s,
+                                                           const float4 *__restrict__ campos, const float4 *__restrict__ normals,
+                                                           const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
+                                                           float *__restrict__ dense_partials,
+                                                           const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets, float *__restrict__ sparse_partials)
+{
+    __shared__ float red[4 * kSparseVals];
+    const unsigned G = n_d + n_s, g = blockIdx.x, xcd = g & 7u, slot = g >> 3;
+    const unsigned qd = n_d >> 3, rd = n_d & 7u;
+    const unsigned Gx = (G - xcd + 7u) >> 3, ndx = qd + (xcd < rd ? 1u : 0u), nsx = Gx - ndx;
+    unsigned sparse_base = 0;                                   // sparse items owned by lower XCDs
+    for (unsigned y = 0; y < xcd; y++) sparse_base += ((G - y + 7u) >> 3) - (qd + (y < rd ? 1u : 0u));
+    const unsigned Rx = nsx ? Gx / nsx : 0xFFFFFFFFu;
+    const bool is_sparse = nsx && (slot % Rx == 0u) && (slot / Rx < nsx);
+    if (is_sparse) {
+        const unsigned i = sparse_base + slot / Rx;              // (chunk fastest, then pair, then instance)
+        const int chunk = (int)(i % (unsigned)D.sparse_chunks);
+        const int p = (int)((i / (unsigned)D.sparse_chunks) % (unsigned)D.n_pairs);
+        const int b = (int)(i / ((unsigned)D.sparse_chunks * (unsigned)D.n_pairs));
+        sparse_block(D, corr, pair_offsets, T, sparse_partials, chunk, p, b, red);
+    } else {
+        const unsigned before = nsx ? min(nsx, (slot + Rx - 1u) / Rx) : 0u;     // sparse slots of this XCD before `slot`
+        const unsigned dl = slot - before;                                      // dense item local to the XCD
+        const unsigned L = (xcd < rd ? xcd * (qd + 1u) : rd * (qd + 1u) + (xcd - rd) * qd) + dl;
+        const int tile = (int)(L % (unsigned)D.dense_tiles);
+        const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
+        const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
+        dense_block<1>(D, campos, normals, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
+    }
 }
 
 // ---- system solve -------------------------------------------------------------------------------

@@ -65,6 +65,7 @@ enum {
     BTBA_FLAG_NO_GRAPH     = 4,   /* launch kernels eagerly instead of replaying the captured hipGraph */
     BTBA_FLAG_DENSE_2PIX   = 8,   /* tuning: dense sweep variant with two pixels per lane per trip     */
     BTBA_FLAG_DENSE_4WAVE  = 16,  /* tuning: one pixel per trip, registers capped for 4 waves per SIMD (spills) */
+    BTBA_FLAG_NO_FUSE      = 64,  /* launch the sparse and the dense sweep separately instead of as one interleaved launch */
     BTBA_FLAG_OVERLAP      = 32   /* split a batch over two streams (main + low-priority) so one half's k_system_solve
                                      overlaps the other half's dense sweep; per-kernel timings then overlap too */
 };
@@ -104,6 +105,8 @@ typedef struct btba_stats {
     int32_t n_dense_launches, n_sparse_launches, n_solve_launches;
     int64_t bytes_dense_alg;      /* algorithmic bytes of ONE dense sweep launch  (64 * Pd * npix * B) */
     int64_t bytes_sparse_alg;     /* algorithmic bytes of ONE sparse sweep launch (32 * C)             */
+    int32_t fused_sweeps;         /* 1: sparse + dense sweeps ran as ONE launch (timed as ms_dense_sweep) */
+    int32_t reserved_;
 } btba_stats;
 
 /* Per-instance, per-GN-iteration trace record (floats), written when BTBA_FLAG_TRACE is set.
