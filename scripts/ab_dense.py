@@ -35,7 +35,7 @@ def main():
                 st = ws.collect_stats()
                 out = poses_d.cpu().numpy()
                 if ref is None: ref = out
-                print(f"B={B} {name} tiles={tiles}: step {dt*1e3:.3f} ms  dense {st['ms_dense_sweep']/st['n_dense_launches']*1e3:.1f} us/launch  sparse {st['ms_sparse_sweep']/st['n_sparse_launches']*1e3:.1f}  sys {st['ms_system_solve']/st['n_solve_launches']*1e3:.1f}  maxdiff {np.abs(out-ref).max():.2e}", flush=True)
+                print(f"B={B} {name} tiles={tiles}: step {dt*1e3:.3f} ms  dense {st['ms_dense_sweep']/st['n_dense_launches']*1e3:.1f} us/launch  sparse {st['ms_sparse_sweep']/max(st['n_sparse_launches'],1)*1e3:.1f}  sys {st['ms_system_solve']/st['n_solve_launches']*1e3:.1f}  maxdiff {np.abs(out-ref).max():.2e}", flush=True)
 
 
 if __name__ == "__main__":
