@@ -387,7 +387,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             float *tr_h = trace ? trace + b0 * (size_t)D.n_gn * D.trace_record : nullptr;
             size_t slot;
             const unsigned n_d = (unsigned)tiles * D.n_dense_pairs * H.nb, n_s = (unsigned)chunks * P * H.nb;
-            const bool fuse = use_sparse && use_dense && n_s >= 64 && n_d >= 64 && !(prm->flags & (BTBA_FLAG_NO_FUSE | BTBA_FLAG_DENSE_2PIX | BTBA_FLAG_DENSE_4WAVE));
+            // measured (c3): fused vs separate step time  B=1 0.565 / 0.642 ms, B=8 1.156 / 1.226 ms, B=32 3.573 / 3.557 ms:
+            // at large batches both sweeps are limited by the same L2<->fabric path and do not overlap, so fuse only small ones
+            const bool fuse = use_sparse && use_dense && n_s >= 64 && n_d >= 64 && (H.nb <= 16 || (prm->flags & BTBA_FLAG_FUSE)) &&
+                              !(prm->flags & (BTBA_FLAG_NO_FUSE | BTBA_FLAG_DENSE_2PIX | BTBA_FLAG_DENSE_4WAVE));
             if (fuse) {
                 // one launch: HBM-streaming sparse workgroups interleaved with the VALU-bound dense ones
                 if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;

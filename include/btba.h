@@ -65,7 +65,8 @@ enum {
     BTBA_FLAG_NO_GRAPH     = 4,   /* launch kernels eagerly instead of replaying the captured hipGraph */
     BTBA_FLAG_DENSE_2PIX   = 8,   /* tuning: dense sweep variant with two pixels per lane per trip     */
     BTBA_FLAG_DENSE_4WAVE  = 16,  /* tuning: one pixel per trip, registers capped for 4 waves per SIMD (spills) */
-    BTBA_FLAG_NO_FUSE      = 64,  /* launch the sparse and the dense sweep separately instead of as one interleaved launch */
+    BTBA_FLAG_NO_FUSE      = 64,  /* never launch the sparse and the dense sweep as one interleaved launch */
+    BTBA_FLAG_FUSE         = 128, /* always do (default: only for batches of <= 16 instances, where it is measured faster) */
     BTBA_FLAG_OVERLAP      = 32   /* split a batch over two streams (main + low-priority) so one half's k_system_solve
                                      overlaps the other half's dense sweep; per-kernel timings then overlap too */
 };

@@ -88,7 +88,7 @@ def test_c5_shape_batch_properties(gpu):
     from bundletrack_amd import _lib
     out3, _, _ = run_gpu(gpu, pbs32, flags=_lib.FLAG_OVERLAP)         # two-stream half-batch pipeline: same bits as one stream
     assert np.array_equal(out, out3)
-    out4, _, _ = run_gpu(gpu, pbs32, flags=_lib.FLAG_NO_FUSE)         # separate sparse / dense launches: same per-workgroup arithmetic
+    out4, _, _ = run_gpu(gpu, pbs32, flags=_lib.FLAG_FUSE)            # sparse + dense sweeps as one interleaved launch: same per-workgroup arithmetic
     assert np.array_equal(out, out4)
     for b in range(4, 32):
         assert np.array_equal(out[b], out[b % 4])            # same instance data -> same bits wherever it sits in the grid
