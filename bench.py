@@ -181,7 +181,7 @@ def main():
             if os.path.exists(tp):
                 try:
                     tj = json.load(open(tp))
-                    if tj.get("instances") == B and tj.get("config") == args.config and bool(tj.get("fused", False)) == fused:
+                    if tj.get("instances") == B and tj.get("config") == args.config and bool(tj.get("fused", False)) == fused and bool(tj.get("masked", False)) == args.masked:
                         traffic = tj.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
