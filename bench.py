@@ -40,7 +40,8 @@ def _gen(args):
     K, m, seed, masked = args
     pb = S.make_problem(K, m, seed, background=not masked, full_res=False)
     campos, normals, intr = S.analytic_cache(pb)
-    return dict(campos=campos, normals=normals, intr=intr, corr=pb.corr, poses=pb.poses_init)
+    zn = np.concatenate([pb.cache_depth[..., None], pb.cache_normals[..., :3]], -1).astype(np.float32)       # compact cache: (z, nx, ny, nz)
+    return dict(campos=campos, normals=normals, intr=intr, corr=pb.corr, poses=pb.poses_init, zn=zn, K=pb.K, H=pb.H, W=pb.W)
 
 
 def generate_instances(cfg, ids, masked=False):
@@ -92,6 +93,7 @@ def main():
     ap.add_argument("--masked", action="store_true", help="realistic ~5%%-valid object mask instead of the 100%%-valid roofline variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--float4-cache", action="store_true", help="reference-layout float4 camPos + float4 normal caches (32 B/pixel) instead of the compact (z, n) cache")
     ap.add_argument("--latency", action="store_true", help="also measure single-instance latency mode (extra field)")
     args = ap.parse_args()
 
@@ -119,8 +121,12 @@ def main():
     if not args.no_kernel_timing:
         bs.params.flags |= _lib.FLAG_TIME_KERNELS
     corr, offs, mx = bs.pack_correspondences([p["corr"] for p in pick], K)
-    cam_d = torch.from_numpy(np.stack([p["campos"] for p in pick])).to(dev)
-    nrm_d = torch.from_numpy(np.stack([p["normals"] for p in pick])).to(dev)
+    if args.float4_cache:
+        cam_d = torch.from_numpy(np.stack([p["campos"] for p in pick])).to(dev)
+        nrm_d = torch.from_numpy(np.stack([p["normals"] for p in pick])).to(dev)
+    else:
+        cam_d = torch.from_numpy(np.stack([p["zn"] for p in pick])).to(dev)      # [B, K, Hd, Wd, 4] = (z, nx, ny, nz)
+        nrm_d = None
     corr_d = torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(dev)
     offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
     poses0 = torch.from_numpy(np.stack([p["poses"] for p in pick])).to(dev)
@@ -130,7 +136,10 @@ def main():
 
     def step():
         poses_d.copy_(poses0)                               # pose in ...
-        bs.solve(cam_d, nrm_d, intr, corr_d, offs_d, mx, poses_d)   # ... pose out (7 GN iterations per instance)
+        if args.float4_cache:
+            bs.solve(cam_d, nrm_d, intr, corr_d, offs_d, mx, poses_d)   # ... pose out (7 GN iterations per instance)
+        else:
+            bs.solve_zn(cam_d, pick[0]["H"], pick[0]["W"], pick[0]["K"], corr_d, offs_d, mx, poses_d)
 
     for _ in range(args.warmup):
         step()
@@ -155,7 +164,7 @@ def main():
     value, slowest = sharding.aggregate(per_rank)
 
     if rank == 0:
-        npix = cam_d.shape[2] * cam_d.shape[3]
+        npix = int(cam_d.shape[2] * cam_d.shape[3])
         P = K * (K - 1) // 2
         res = {
             "metric": METRIC, "value": round(value, 1), "unit": "GN iterations/s", "n_gpus": world,
@@ -165,7 +174,7 @@ def main():
                                    f"{'~5%-valid object mask' if args.masked else '100%-valid (object + background)'}, 7 GN x 5 PCG, pair policy TARGET_LOWER",
                        "keyframes": K, "corr_per_pair": cfg["m"], "instances_per_gpu": B, "distinct_instances_per_gpu": n_distinct,
                        "gn_iters": int(bs.params.n_gn_iters), "pcg_iters": int(bs.params.n_pcg_iters),
-                       "dense_tiles": st["dense_tiles"], "sparse_chunks": st["sparse_chunks"], "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+                       "dense_tiles": st["dense_tiles"], "sparse_chunks": st["sparse_chunks"], "frame_cache": "float4 camPos + float4 normal (32 B/px)" if args.float4_cache else "compact z + normal (16 B/px)", "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "per_rank": [{"seconds": round(s, 6), "gn_iters": g} for s, g in per_rank],
         }
         if not args.no_kernel_timing and st["n_dense_launches"] > 0:
@@ -181,7 +190,7 @@ def main():
             if os.path.exists(tp):
                 try:
                     tj = json.load(open(tp))
-                    if tj.get("instances") == B and tj.get("config") == args.config and bool(tj.get("fused", False)) == fused and bool(tj.get("masked", False)) == args.masked:
+                    if tj.get("instances") == B and tj.get("config") == args.config and bool(tj.get("fused", False)) == fused and bool(tj.get("masked", False)) == args.masked and bool(tj.get("float4_cache", True)) == args.float4_cache:
                         traffic = tj.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
@@ -211,13 +220,19 @@ def main():
             c1d = torch.from_numpy(c1.view(np.uint8).reshape(1, -1, 32)).to(dev)
             o1d = torch.from_numpy(o1.astype(np.int32)).to(dev)
             p1 = poses0[:1].clone()
+
+            def one(p):
+                if args.float4_cache:
+                    bs1.solve(cam_d[:1], nrm_d[:1], intr, c1d, o1d, m1, p)
+                else:
+                    bs1.solve_zn(cam_d[:1], pick[0]["H"], pick[0]["W"], pick[0]["K"], c1d, o1d, m1, p)
             for _ in range(5):
-                p1.copy_(poses0[:1]); bs1.solve(cam_d[:1], nrm_d[:1], intr, c1d, o1d, m1, p1)
+                p1.copy_(poses0[:1]); one(p1)
             torch.cuda.synchronize()
             ta = time.perf_counter()
             reps = 50
             for _ in range(reps):
-                p1.copy_(poses0[:1]); bs1.solve(cam_d[:1], nrm_d[:1], intr, c1d, o1d, m1, p1)
+                p1.copy_(poses0[:1]); one(p1)
             torch.cuda.synchronize()
             tb = time.perf_counter()
             res["single_instance"] = {"gn_iters_per_s": round(7 * reps / (tb - ta), 1), "ms_per_solve": round(1e3 * (tb - ta) / reps, 4)}

@@ -20,7 +20,7 @@ HEADER = os.path.join(_ROOT, "include", "btba.h")
 BTBA_OK, BTBA_EINVAL, BTBA_EHIP, BTBA_ENUMERIC, BTBA_ENOMEM = 0, 1, 2, 3, 4
 PAIRS_TARGET_LOWER, PAIRS_TARGET_MORE_VALID, PAIRS_EXPLICIT = 0, 1, 2
 FLAG_TRACE, FLAG_TIME_KERNELS, FLAG_NO_GRAPH = 1, 2, 4
-FLAG_DENSE_2PIX, FLAG_DENSE_4WAVE, FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_FUSE = 8, 16, 32, 64, 128
+FLAG_DENSE_2PIX, FLAG_DENSE_4WAVE, FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_FUSE, FLAG_FLOAT4_CACHE = 8, 16, 32, 64, 128, 256
 
 ENTRYJ_DTYPE = np.dtype(
     [("imgIdx_i", "<u4"), ("imgIdx_j", "<u4"), ("pos_i", "<f4", (3,)), ("pos_j", "<f4", (3,))]
@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
     "btba_process_depth", "btba_depth_to_normals",
+    "btba_build_cache_zn", "btba_pack_zn", "btba_solve_batch_zn",
 ]
 
 
@@ -124,6 +125,10 @@ def lib() -> C.CDLL:
         L.btba_bucket_correspondences.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         L.btba_matrices_to_poses.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.btba_poses_to_matrices.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.btba_build_cache_zn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.btba_pack_zn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.btba_solve_batch_zn.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.btba_process_depth.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
         L.btba_depth_to_normals.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L

@@ -251,8 +251,12 @@ static int pick_tiles(const btba_params *prm, int B, int Pd, int npix)
     return want;
 }
 
+static void scaled_intrinsics(int H, int W, int Hd, int Wd, const float *K, float intr[4], Mat4 *Kinv);
+
+struct ZnSpec { const float *zn = nullptr; int H = 0, W = 0; const float *K = nullptr; };     // compact cache + the full-res geometry it encodes
+
 static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int N, int Hd, int Wd, const float *intr,
-                         const float *campos, const float *normals, const btba_entryj *corr, int64_t corr_stride,
+                         const float *campos, const float *normals, const ZnSpec &Z, const btba_entryj *corr, int64_t corr_stride,
                          const uint32_t *pair_offsets, uint32_t max_corr_per_pair,
                          const int32_t *dense_pairs, int Pd_in, float *poses, float *trace)
 {
@@ -270,7 +274,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             if (pairs[k] < 0 || pairs[k] >= N || pairs[k + 1] < 0 || pairs[k + 1] >= N || pairs[k] == pairs[k + 1]) return BTBA_EINVAL;
     }
     const int Pd = (int)(pairs.size() / 2);
-    const bool use_dense = Pd > 0 && campos && normals;      // Pd == 0: "no overlapping images", SolverBundling.cu:280-283
+    const bool use_zn = Z.zn != nullptr;
+    const bool use_dense = Pd > 0 && ((campos && normals) || use_zn);      // Pd == 0: "no overlapping images", SolverBundling.cu:280-283
     if (!use_sparse && !use_dense) {
         // nothing to optimise: poses still go through Log/Exp like the reference (SBA.cpp:106,115)
     }
@@ -316,6 +321,19 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;
     D.n_gn = prm->n_gn_iters;
+    int zn_layout = 0;
+    if (use_zn) {
+        if (!Z.K || Z.H < 2 || Z.W < 2) return BTBA_EINVAL;
+        float intr_chk[4];
+        Mat4 Kinv;
+        scaled_intrinsics(Z.H, Z.W, Hd, Wd, Z.K, intr_chk, &Kinv);
+        for (int k = 0; k < 16; k++) D.zn_ki[k] = Kinv.m[k];
+        D.zn_scale_w = (float)(Z.W - 1) / (float)(Wd - 1);
+        D.zn_scale_h = (float)(Z.H - 1) / (float)(Hd - 1);
+        const float *ki = D.zn_ki;
+        D.zn_simple = (ki[1] == 0.f && ki[3] == 0.f && ki[4] == 0.f && ki[7] == 0.f && ki[12] == 0.f && ki[13] == 0.f && ki[14] == 0.f) ? 1 : 0;
+        zn_layout = D.zn_simple ? 1 : 2;
+    }
     D.trace_on = (trace != nullptr) && (prm->flags & BTBA_FLAG_TRACE);
     btba_trace_layout L;
     btba_trace_layout_get(N, D.n_dense_pairs, prm->n_pcg_iters, &L);
@@ -378,6 +396,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             const Half &H = halves[h];
             const size_t b0 = (size_t)H.b0;
             const float *campos_h = campos ? campos + 4 * b0 * N * npix : nullptr, *normals_h = normals ? normals + 4 * b0 * N * npix : nullptr;
+            const float4 *zn_h = use_zn ? reinterpret_cast<const float4 *>(Z.zn) + b0 * N * npix : nullptr;
             const float4 *corr_h = corr ? reinterpret_cast<const float4 *>(corr) + 2 * b0 * (size_t)corr_stride : nullptr;
             const uint32_t *off_h = pair_offsets ? pair_offsets + b0 * (P + 1) : nullptr;
             float *x_h = ws->x.as<float>() + 6 * b0 * N, *T_h = ws->T.as<float>() + 16 * b0 * N, *Ti_h = ws->Tinv.as<float>() + 16 * b0 * N;
@@ -394,8 +413,11 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             if (fuse) {
                 // one launch: HBM-streaming sparse workgroups interleaved with the VALU-bound dense ones
                 if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
-                k_fused_sweeps<<<dim3(n_d + n_s), kBlock, 0, H.st>>>(D, n_d, n_s, reinterpret_cast<const float4 *>(campos_h), reinterpret_cast<const float4 *>(normals_h),
-                                                                     ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, corr_h, off_h, sp_h);
+#define BTBA_FUSED_ARGS(CACHE) D, n_d, n_s, CACHE, reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, corr_h, off_h, sp_h
+                if (zn_layout == 0) k_fused_sweeps<0><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(reinterpret_cast<const float4 *>(campos_h)));
+                else if (zn_layout == 1) k_fused_sweeps<1><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
+                else k_fused_sweeps<2><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
+#undef BTBA_FUSED_ARGS
                 if ((rc = time_end(ws, slot, H.st))) return rc;
                 S.fused_sweeps = 1;
             } else {
@@ -408,7 +430,9 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                     if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
                     const dim3 dgrid(n_d);
 #define BTBA_DENSE_ARGS D, reinterpret_cast<const float4 *>(campos_h), reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h
-                    if (prm->flags & BTBA_FLAG_DENSE_2PIX) k_dense_sweep<2, 2><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
+                    if (zn_layout == 1) k_dense_sweep_zn<true><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h);
+                    else if (zn_layout == 2) k_dense_sweep_zn<false><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h);
+                    else if (prm->flags & BTBA_FLAG_DENSE_2PIX) k_dense_sweep<2, 2><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
                     else if (prm->flags & BTBA_FLAG_DENSE_4WAVE) k_dense_sweep<1, 4><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
                     else k_dense_sweep<1, 3><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
 #undef BTBA_DENSE_ARGS
@@ -474,7 +498,7 @@ int btba_solve_batch(btba_workspace *ws, const btba_params *params, int n_instan
         for (auto &ep : ws->events) { ws->event_pool.push_back(ep.a); ws->event_pool.push_back(ep.b); }
         ws->events.clear();
     }
-    return solve_enqueue(ws, params, n_instances, n_frames, Hd, Wd, intr, campos_dev, normals_dev, corr_dev, corr_stride,
+    return solve_enqueue(ws, params, n_instances, n_frames, Hd, Wd, intr, campos_dev, normals_dev, ZnSpec{}, corr_dev, corr_stride,
                          pair_offsets_dev, max_corr_per_pair, dense_pairs, dense_pairs ? n_dense_pairs : -1, poses_dev, trace_dev);
 }
 
@@ -583,7 +607,10 @@ int btba_optimize_frames(btba_workspace *ws_in, const btba_params *params_in, in
     const auto tu1 = std::chrono::steady_clock::now();
 
     float intr[4];
-    if ((rc = btba_build_cache(ws, N, H, W, K, prm.image_downscale, depth_dev, normal_dev, ws->campos.as<float>(), ws->normals.as<float>(), ws->nvalid.as<int32_t>(), intr))) return finish(rc);
+    const bool compact = !(prm.flags & BTBA_FLAG_FLOAT4_CACHE);        // compact (z, n) cache: identical results, half the bytes
+    if (compact) rc = btba_build_cache_zn(ws, N, H, W, K, prm.image_downscale, depth_dev, normal_dev, ws->campos.as<float>(), ws->nvalid.as<int32_t>(), intr);
+    else rc = btba_build_cache(ws, N, H, W, K, prm.image_downscale, depth_dev, normal_dev, ws->campos.as<float>(), ws->normals.as<float>(), ws->nvalid.as<int32_t>(), intr);
+    if (rc) return finish(rc);
 
     std::vector<int32_t> pairs;
     const int32_t *pairs_ptr = nullptr;
@@ -606,7 +633,9 @@ int btba_optimize_frames(btba_workspace *ws_in, const btba_params *params_in, in
 
     // keep cache-build timing event, then enqueue the solve
     ws->always_time_region = true;
-    rc = solve_enqueue(ws, &prm, 1, N, Hd, Wd, intr, ws->campos.as<float>(), ws->normals.as<float>(), ws->corr.as<btba_entryj>(), (int64_t)(kept ? kept : 1),
+    ZnSpec Z;
+    if (compact) { Z.zn = ws->campos.as<float>(); Z.H = H; Z.W = W; Z.K = K; }
+    rc = solve_enqueue(ws, &prm, 1, N, Hd, Wd, intr, compact ? nullptr : ws->campos.as<float>(), compact ? nullptr : ws->normals.as<float>(), Z, ws->corr.as<btba_entryj>(), (int64_t)(kept ? kept : 1),
                        ws->offsets.as<uint32_t>(), max_per_pair, pairs_ptr, n_pairs_dense, ws->poses.as<float>(), nullptr);
     ws->always_time_region = false;
     if (rc) return finish(rc);
@@ -664,6 +693,66 @@ int btba_depth_to_normals(btba_workspace *ws, int H, int W, const float *K, cons
     k_depth_to_normals<<<dim3((W + 63) / 64, (H + 3) / 4), dim3(64, 4), 0, ws->stream>>>(W, H, Kinv, depth_dev, reinterpret_cast<float4 *>(normals_dev), reinterpret_cast<float4 *>(xyz_dev));
     HIP_TRY(hipGetLastError());
     return BTBA_OK;
+}
+
+int btba_build_cache_zn(btba_workspace *ws, int n_frames, int H, int W, const float *K, float image_downscale,
+                        const float *const *depth_dev, const float *const *normal_dev, float *zn_dev, int32_t *n_valid_dev, float *intr_out)
+{
+    if (!ws || n_frames < 1 || H < 2 || W < 2 || !K || !depth_dev || !normal_dev || !zn_dev || !(image_downscale >= 1.0f)) return BTBA_EINVAL;
+    const int Wd = (int)(W / image_downscale), Hd = (int)(H / image_downscale);
+    if (Wd < 2 || Hd < 2) return BTBA_EINVAL;
+    float intr[4];
+    Mat4 Kinv;
+    scaled_intrinsics(H, W, Hd, Wd, K, intr, &Kinv);
+    if (intr_out) std::memcpy(intr_out, intr, sizeof intr);
+    int rc;
+    if ((rc = ws->ptrs.ensure(sizeof(void *) * 2 * (size_t)n_frames))) return rc;
+    std::vector<const float *> h(2 * (size_t)n_frames);
+    for (int k = 0; k < n_frames; k++) {
+        if (!depth_dev[k] || !normal_dev[k]) return BTBA_EINVAL;
+        h[k] = depth_dev[k]; h[n_frames + k] = normal_dev[k];
+    }
+    HIP_TRY(hipMemcpyAsync(ws->ptrs.p, h.data(), sizeof(void *) * h.size(), hipMemcpyHostToDevice, ws->stream));
+    HIP_TRY(hipStreamSynchronize(ws->stream));    // h is a local
+    if (n_valid_dev) HIP_TRY(hipMemsetAsync(n_valid_dev, 0, sizeof(int32_t) * n_frames, ws->stream));
+    const int npix = Wd * Hd;
+    size_t slot;
+    if ((rc = time_begin(ws, true, 4, &slot))) return rc;
+    k_build_cache_zn<<<dim3((npix + kBlock - 1) / kBlock, n_frames), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, ws->ptrs.as<const float *>(), ws->ptrs.as<const float *>() + n_frames,
+                                                                                            reinterpret_cast<float4 *>(zn_dev), n_valid_dev);
+    if ((rc = time_end(ws, slot))) return rc;
+    HIP_TRY(hipGetLastError());
+    return BTBA_OK;
+}
+
+int btba_pack_zn(btba_workspace *ws, int64_t n_pixels_total, const float *campos_dev, const float *normals_dev, float *zn_dev)
+{
+    if (!ws || n_pixels_total < 1 || !campos_dev || !normals_dev || !zn_dev) return BTBA_EINVAL;
+    k_pack_zn<<<(unsigned)((n_pixels_total + kBlock - 1) / kBlock), kBlock, 0, ws->stream>>>((size_t)n_pixels_total, reinterpret_cast<const float4 *>(campos_dev),
+                                                                                            reinterpret_cast<const float4 *>(normals_dev), reinterpret_cast<float4 *>(zn_dev));
+    HIP_TRY(hipGetLastError());
+    return BTBA_OK;
+}
+
+int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames, int H, int W, const float *K,
+                        const float *zn_dev, const btba_entryj *corr_dev, int64_t corr_stride,
+                        const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
+                        float *poses_dev, float *trace_dev)
+{
+    if (!ws || !params || !K || !zn_dev || H < 2 || W < 2 || !(params->image_downscale >= 1.0f)) return BTBA_EINVAL;
+    const int Wd = (int)(W / params->image_downscale), Hd = (int)(H / params->image_downscale);
+    if (Wd < 2 || Hd < 2) return BTBA_EINVAL;
+    float intr[4];
+    Mat4 Kinv;
+    scaled_intrinsics(H, W, Hd, Wd, K, intr, &Kinv);
+    if (ws->events.size() > 65536) {
+        for (auto &ep : ws->events) { ws->event_pool.push_back(ep.a); ws->event_pool.push_back(ep.b); }
+        ws->events.clear();
+    }
+    ZnSpec Z;
+    Z.zn = zn_dev; Z.H = H; Z.W = W; Z.K = K;
+    return solve_enqueue(ws, params, n_instances, n_frames, Hd, Wd, intr, nullptr, nullptr, Z, corr_dev, corr_stride,
+                         pair_offsets_dev, max_corr_per_pair, dense_pairs, dense_pairs ? n_dense_pairs : -1, poses_dev, trace_dev);
 }
 
 }  // extern "C"

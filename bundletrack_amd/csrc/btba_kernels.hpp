@@ -60,6 +60,10 @@ struct SolveDims {
     int64_t tr_x, tr_T, tr_rhs, tr_prec, tr_pcg, tr_delta, tr_dpair, tr_A, tr_clk;
     int n_gn;
     int pairsum_in_lds;  // 1: stage reduced pair sums in LDS, 0: in global scratch
+    // compact (z, nx, ny, nz) frame cache: how a cached pixel maps back to camera space -- the arithmetic of k_build_cache
+    float zn_ki[16];     // full-resolution intrinsicsInv (4x4 embedding, generic cofactor inverse)
+    float zn_scale_w, zn_scale_h;   // (W-1)/(Wd-1), (H-1)/(Hd-1) of the nearest-neighbour resample
+    int zn_simple;       // 1: zero skew and affine last row (ki[1]=ki[3]=ki[4]=ki[7]=ki[12]=ki[13]=ki[14]=0)
 };
 
 // canonical pair index -> (i, j), i < j, outer i
@@ -157,6 +161,67 @@ __global__ void __launch_bounds__(kBlock) k_build_cache(int W, int H, int Wd, in
         const unsigned long long b = __ballot(valid);
         if ((threadIdx.x & 63) == 0 && b) atomicAdd(&n_valid[f], __popcll(b));
     }
+}
+
+// ---- compact frame cache ("ZN": float4 = depth z, normal x, y, z; 16 B per pixel instead of 32) -----------
+// camPos is a pure function of (full-res pixel, depth): CUDAImageUtil.cu:310-327 computes
+// intrinsicsInv * (x d, y d, d, d).  Storing only d and re-evaluating that expression with the SAME fp32
+// operations (no contraction) where it is consumed gives bit-identical camera-space points while halving the
+// bytes and the load instructions of the dense sweep (one 16-byte load per tap instead of two).
+template <bool SIMPLE>
+__device__ __forceinline__ float3 zn_backproject(const float *ki, unsigned xi, unsigned yi, float d)
+{
+#pragma clang fp contract(off)
+    if (!((double)d >= 0.1)) return make_float3(0.f, 0.f, 0.f);
+    const float vx = (float)xi * d, vy = (float)yi * d;
+    if (SIMPLE)   // the zero terms of the general form add exact zeros
+        return make_float3(ki[0] * vx + ki[2] * d, ki[5] * vy + ki[6] * d, ki[15] * d);
+    return make_float3(ki[0] * vx + ki[1] * vy + ki[2] * d + ki[3] * d, ki[4] * vx + ki[5] * vy + ki[6] * d + ki[7] * d,
+                       ki[12] * vx + ki[13] * vy + ki[14] * d + ki[15] * d);
+}
+__device__ __forceinline__ unsigned zn_src_coord(int c, float scale)
+{
+#pragma clang fp contract(off)
+    return (unsigned)(c * scale + 0.5f);          // CUDAImageUtil.cu:60-61
+}
+
+// grid (ceil(npix/256), n_frames): CUDACache::storeFrame for all frames, compact output.
+__global__ void __launch_bounds__(kBlock) k_build_cache_zn(int W, int H, int Wd, int Hd, const float *const *__restrict__ depth, const float *const *__restrict__ normals,
+                                                          float4 *__restrict__ zn_out, int *__restrict__ n_valid)
+{
+#pragma clang fp contract(off)
+    const int f = blockIdx.y;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    const int npix = Wd * Hd;
+    int valid = 0;
+    if (o < npix) {
+        const int x = o % Wd, y = o / Wd;
+        const float scaleW = (float)(W - 1) / (float)(Wd - 1);
+        const float scaleH = (float)(H - 1) / (float)(Hd - 1);
+        const unsigned xi = (unsigned)(x * scaleW + 0.5f);
+        const unsigned yi = (unsigned)(y * scaleH + 0.5f);
+        if (xi < (unsigned)W && yi < (unsigned)H) {
+            const size_t s = (size_t)yi * W + xi;
+            const float d = depth[f][s];
+            const float4 nr = reinterpret_cast<const float4 *>(normals[f])[s];
+            zn_out[(size_t)f * npix + o] = make_float4(d, nr.x, nr.y, nr.z);
+            valid = ((double)d >= 0.1) ? 1 : 0;
+        }
+    }
+    if (n_valid) {
+        const unsigned long long b = __ballot(valid);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&n_valid[f], __popcll(b));
+    }
+}
+
+// float4 camPos + float4 normal caches -> compact cache (for callers that already hold the reference layout;
+// camPos.xy are dropped and later recomputed from z, so the input must come from the standard formula)
+__global__ void __launch_bounds__(kBlock) k_pack_zn(size_t total, const float4 *__restrict__ campos, const float4 *__restrict__ normals, float4 *__restrict__ zn)
+{
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const float4 c = campos[o], nr = normals[o];
+    zn[o] = make_float4(c.z, nr.x, nr.y, nr.z);
 }
 
 // ---- sparse sweep -----------------------------------------------------------------------------
@@ -266,6 +331,7 @@ struct PixelGeom {                  // stage 1: everything that does not need th
     float qx, qy, qz, nqx, nqy, nqz;
     float c00, c10, c01, c11;       // final bilinear coefficients (row/column renormalisation folded in)
     int i00, i10, i01, i11;
+    int xa, xb, ya, yb;             // clamped tap columns / rows (compact cache: needed to back-project the taps)
     bool valid;
 };
 
@@ -294,6 +360,7 @@ __device__ __forceinline__ PixelGeom pixel_geom(const DenseCtx &C, const float4 
     const int xa = min(max(x0, 0), C.W - 1), xb = min(max(x0 + 1, 0), C.W - 1);
     const int ya = min(max(y0, 0), C.H - 1), yb = min(max(y0 + 1, 0), C.H - 1);
     g.i00 = ya * C.W + xa; g.i10 = ya * C.W + xb; g.i01 = yb * C.W + xa; g.i11 = yb * C.W + xb;
+    g.xa = xa; g.xb = xb; g.ya = ya; g.yb = yb;
     const float a0 = okx0 ? 1.0f - alpha : 0.0f, a1 = okx1 ? alpha : 0.0f;
     const float wr = a0 + a1;                                   // same for both rows
     const float b0 = (oky0 && wr > 0.0f) ? 1.0f - beta : 0.0f, b1 = (oky1 && wr > 0.0f) ? beta : 0.0f;
@@ -398,6 +465,67 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
     block_reduce_store<kDenseVals, 4>(acc, red, out);
 }
 
+// The same sweep on the compact cache: ONE 16-byte load per source pixel and per tap (5 loads instead of 10),
+// camera-space points re-derived from z with the cache builder's exact arithmetic (zn_backproject).
+template <bool SIMPLE>
+__device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
+                                               const float *__restrict__ T, const float *__restrict__ Tinv,
+                                               float *__restrict__ partials, int tile, int p, int b, float *red)
+{
+    const int2 ij = dense_pairs[p];
+    const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
+    const size_t fb = (size_t)b * D.n_frames;
+    DenseCtx C;
+    C.Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), load_mat4(T + 16 * (fb + fj)));
+    C.cam_t = nullptr; C.nrm_t = nullptr;
+    C.fx = D.fx; C.fy = D.fy; C.cx = D.cx; C.cy = D.cy; C.depth_min = D.depth_min; C.depth_max = D.depth_max;
+    C.normal_thresh = D.normal_thresh; C.dist2_thresh = D.dist_thresh * D.dist_thresh;
+    C.delta = D.robust_delta; C.delta2 = D.robust_delta * D.robust_delta; C.w_dense = D.w_dense;
+    C.W = D.width; C.H = D.height;
+    const float4 *zn_t = zn + (fb + fi) * (size_t)D.npix, *zn_s = zn + (fb + fj) * (size_t)D.npix;
+    const int per = (D.npix + D.dense_tiles - 1) / D.dense_tiles;
+    const int lo = min(D.npix, per * tile), hi = min(D.npix, per * (tile + 1));
+    float acc[kDenseVals];
+#pragma unroll
+    for (int k = 0; k < kDenseVals; k++) acc[k] = 0.0f;
+
+    int s = lo + (int)threadIdx.x;
+    int px = s % D.width, py = s / D.width;                // pixel coordinates advance incrementally (no division in the loop)
+    const int step_x = kBlock % D.width, step_y = kBlock / D.width;
+    float4 zs_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s < hi) zs_n = zn_s[s];
+    for (; s < hi; s += kBlock) {
+        const float4 zs = zs_n;
+        if (s + kBlock < hi) zs_n = zn_s[s + kBlock];
+        const float3 cp = zn_backproject<SIMPLE>(D.zn_ki, zn_src_coord(px, D.zn_scale_w), zn_src_coord(py, D.zn_scale_h), zs.x);
+        px += step_x; py += step_y;
+        if (px >= D.width) { px -= D.width; py++; }
+        const PixelGeom g = pixel_geom(C, make_float4(cp.x, cp.y, cp.z, 1.0f), make_float4(zs.y, zs.z, zs.w, 0.0f));
+        if (__builtin_amdgcn_ballot_w64(g.valid) == 0ull) continue;
+        const float4 z00 = zn_t[g.i00], z10 = zn_t[g.i10], z01 = zn_t[g.i01], z11 = zn_t[g.i11];
+        const unsigned xia = zn_src_coord(g.xa, D.zn_scale_w), xib = zn_src_coord(g.xb, D.zn_scale_w);
+        const unsigned yia = zn_src_coord(g.ya, D.zn_scale_h), yib = zn_src_coord(g.yb, D.zn_scale_h);
+        const float3 c00 = zn_backproject<SIMPLE>(D.zn_ki, xia, yia, z00.x), c10 = zn_backproject<SIMPLE>(D.zn_ki, xib, yia, z10.x);
+        const float3 c01 = zn_backproject<SIMPLE>(D.zn_ki, xia, yib, z01.x), c11 = zn_backproject<SIMPLE>(D.zn_ki, xib, yib, z11.x);
+        pixel_accumulate(C, g, make_float4(c00.x, c00.y, c00.z, 1.f), make_float4(c10.x, c10.y, c10.z, 1.f), make_float4(c01.x, c01.y, c01.z, 1.f), make_float4(c11.x, c11.y, c11.z, 1.f),
+                         make_float4(z00.y, z00.z, z00.w, 0.f), make_float4(z10.y, z10.z, z10.w, 0.f), make_float4(z01.y, z01.z, z01.w, 0.f), make_float4(z11.y, z11.z, z11.w, 0.f), acc);
+    }
+    float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
+    block_reduce_store<kDenseVals, 4>(acc, red, out);
+}
+
+template <bool SIMPLE>
+__global__ void __launch_bounds__(kBlock, 3) k_dense_sweep_zn(SolveDims D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
+                                                             const float *__restrict__ T, const float *__restrict__ Tinv, float *__restrict__ partials)
+{
+    __shared__ float red[4 * kDenseVals];
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = (int)(L % (unsigned)D.dense_tiles);
+    const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
+    const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
+    dense_block_zn<SIMPLE>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red);
+}
+
 // 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).
 template <int PIX, int WAVES>
 __global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, const float4 *__restrict__ campos, const float4 *__restrict__ normals,
@@ -416,6 +544,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, cons
 // n_s sparse workgroups (HBM-streaming) so the two overlap on every CU instead of running back to back.
 // Per XCD x (blocks g = 8 s + x, s = slot): a contiguous range of dense items (L2 locality, as in xcd_remap)
 // and every R_x-th slot a sparse item.
+template <int LAYOUT>   // 0: float4 camPos + float4 normals, 1: compact cache (zero-skew intrinsics), 2: compact cache (general)
 __global__ void __launch_bounds__(kBlock, 3) k_fused_sweeps(SolveDims D, unsigned n_d, unsigned n_s,
                                                            const float4 *__restrict__ campos, const float4 *__restrict__ normals,
                                                            const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
@@ -443,7 +572,9 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused_sweeps(SolveDims D, unsigne
         const int tile = (int)(L % (unsigned)D.dense_tiles);
         const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
         const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
-        dense_block<1>(D, campos, normals, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
+        if (LAYOUT == 0) dense_block<1>(D, campos, normals, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
+        else if (LAYOUT == 1) dense_block_zn<true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);     // `campos` carries the compact cache
+        else dense_block_zn<false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
     }
 }
 

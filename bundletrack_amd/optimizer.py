@@ -144,6 +144,30 @@ def build_cache(ws: Workspace, depths_gpu, normals_gpu, H, W, K, image_downscale
     return campos, normals, nvalid, intr
 
 
+def build_cache_zn(ws: Workspace, depths_gpu, normals_gpu, H, W, K, image_downscale=4.0):
+    """Compact frame cache: float4 (z, nx, ny, nz) per downsampled pixel.  Returns (zn [N,Hd,Wd,4], n_valid, intr)."""
+    torch = _torch()
+    N = len(depths_gpu)
+    Wd, Hd = int(W / image_downscale), int(H / image_downscale)
+    dev = depths_gpu[0].device
+    zn = torch.empty((N, Hd, Wd, 4), dtype=torch.float32, device=dev)
+    nvalid = torch.zeros((N,), dtype=torch.int32, device=dev)
+    intr = np.zeros(4, np.float32)
+    Kf = np.ascontiguousarray(K, np.float32).reshape(9)
+    dptr, nptr = _ptr_array(depths_gpu), _ptr_array(normals_gpu)
+    check(lib().btba_build_cache_zn(ws.handle, N, H, W, Kf.ctypes.data, float(image_downscale), C.cast(dptr, C.c_void_p), C.cast(nptr, C.c_void_p),
+                                    zn.data_ptr(), nvalid.data_ptr(), intr.ctypes.data), "btba_build_cache_zn")
+    return zn, nvalid, intr
+
+
+def pack_zn(ws: Workspace, campos, normals):
+    """Reference-layout float4 caches -> compact cache (camPos.xy are re-derived from z by the solver)."""
+    torch = _torch()
+    zn = torch.empty_like(campos)
+    check(lib().btba_pack_zn(ws.handle, campos.numel() // 4, campos.data_ptr(), normals.data_ptr(), zn.data_ptr()), "btba_pack_zn")
+    return zn
+
+
 @dataclass
 class TraceView:
     layout: TraceLayout
@@ -232,6 +256,36 @@ class BatchSolver:
             dp.ctypes.data if dp is not None else None, dp.shape[0] if dp is not None else 0,
             poses_dev.data_ptr(), tr.data_ptr() if tr is not None else None)
         check(rc, "btba_solve_batch")
+        self._last_layout = (L, N, npd if self.params.weight_dense_depth > 0 else 0)
+        return tr
+
+    def solve_zn(self, zn, H, W, K, corr_dev, pair_offsets_dev, max_corr_per_pair, poses_dev, dense_pairs=None, trace=False):
+        """Same as solve() on compact caches: zn CUDA float32 [B,N,Hd,Wd,4] = (z, nx, ny, nz); H, W, K = the FULL-resolution
+        frame geometry the caches were built from (Hd = H / image_downscale)."""
+        torch = _torch()
+        B, N = zn.shape[:2]
+        Kf = np.ascontiguousarray(K, np.float32).reshape(9)
+        stride = corr_dev.shape[1] if corr_dev is not None else 0
+        dp = None
+        npd = N * (N - 1) // 2
+        if dense_pairs is not None:
+            dp = np.ascontiguousarray(dense_pairs, np.int32).reshape(-1, 2)
+            npd = dp.shape[0]
+        tr = None
+        L = TraceLayout()
+        lib().btba_trace_layout_get(N, npd if self.params.weight_dense_depth > 0 else 0, self.params.n_pcg_iters, C.byref(L))
+        if trace:
+            self.params.flags |= _lib.FLAG_TRACE
+            tr = torch.zeros((B, self.params.n_gn_iters, L.record_floats), dtype=torch.float32, device=zn.device)
+        else:
+            self.params.flags &= ~_lib.FLAG_TRACE
+        rc = lib().btba_solve_batch_zn(
+            self.ws.handle, C.byref(self.params), B, N, int(H), int(W), Kf.ctypes.data, zn.data_ptr(),
+            corr_dev.data_ptr() if corr_dev is not None else None, stride,
+            pair_offsets_dev.data_ptr() if pair_offsets_dev is not None else None, int(max_corr_per_pair),
+            dp.ctypes.data if dp is not None else None, dp.shape[0] if dp is not None else 0,
+            poses_dev.data_ptr(), tr.data_ptr() if tr is not None else None)
+        check(rc, "btba_solve_batch_zn")
         self._last_layout = (L, N, npd if self.params.weight_dense_depth > 0 else 0)
         return tr
 

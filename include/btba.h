@@ -66,6 +66,7 @@ enum {
     BTBA_FLAG_DENSE_2PIX   = 8,   /* tuning: dense sweep variant with two pixels per lane per trip     */
     BTBA_FLAG_DENSE_4WAVE  = 16,  /* tuning: one pixel per trip, registers capped for 4 waves per SIMD (spills) */
     BTBA_FLAG_NO_FUSE      = 64,  /* never launch the sparse and the dense sweep as one interleaved launch */
+    BTBA_FLAG_FLOAT4_CACHE = 256, /* btba_optimize_frames: build the reference-layout float4 cache instead of the compact one */
     BTBA_FLAG_FUSE         = 128, /* always do (default: only for batches of <= 16 instances, where it is measured faster) */
     BTBA_FLAG_OVERLAP      = 32   /* split a batch over two streams (main + low-priority) so one half's k_system_solve
                                      overlaps the other half's dense sweep; per-kernel timings then overlap too */
@@ -219,6 +220,25 @@ BTBA_API int btba_process_depth(btba_workspace *ws, int H, int W, const float *d
  * (xyz unit, w = 0, zeros = invalid: the optimiser's input format); xyz_dev: device float4[H*W] or NULL. */
 BTBA_API int btba_depth_to_normals(btba_workspace *ws, int H, int W, const float *K_rowmajor,
                                    const float *depth_dev, float *normals_dev, float *xyz_dev);
+
+/* ---- compact frame cache ("ZN") ------------------------------------------------------------------------
+ * camPos is a pure function of (full-resolution pixel, depth) -- CUDAImageUtil.cu:310-327 -- so the cache can hold
+ * float4 (z, nx, ny, nz) per pixel, 16 B instead of the reference's 32 B (CUDACachedFrame, CUDACacheUtil.h:10-53), and
+ * the sweep re-derives camPos with the cache builder's exact fp32 operations: identical results, half the bytes,
+ * half the load instructions.  btba_optimize_frames uses it internally (BTBA_FLAG_FLOAT4_CACHE switches back). */
+BTBA_API int btba_build_cache_zn(btba_workspace *ws, int n_frames, int H, int W, const float *K_rowmajor,
+                                 float image_downscale, const float *const *depth_dev, const float *const *normal_dev,
+                                 float *zn_dev /* float4[n_frames][Hd*Wd] */, int32_t *n_valid_dev, float *intr_out);
+/* float4 camPos + float4 normals (reference layout) -> compact cache.  camPos.xy are dropped and re-derived from z, so
+ * the input must have been produced by the standard formula (btba_build_cache or CUDACache). */
+BTBA_API int btba_pack_zn(btba_workspace *ws, int64_t n_pixels_total, const float *campos_dev, const float *normals_dev, float *zn_dev);
+/* btba_solve_batch on compact caches: zn_dev float4 [n_instances][n_frames][Hd*Wd]; H, W, K_rowmajor describe the
+ * FULL-resolution frames the caches were built from (Hd = H / image_downscale, ...). */
+BTBA_API int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames,
+                                 int H, int W, const float *K_rowmajor, const float *zn_dev,
+                                 const btba_entryj *corr_dev, int64_t corr_stride,
+                                 const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair,
+                                 const int32_t *dense_pairs, int n_dense_pairs, float *poses_dev, float *trace_dev);
 
 #ifdef __cplusplus
 }

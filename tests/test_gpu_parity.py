@@ -373,3 +373,45 @@ def test_tile_and_chunk_counts_do_not_change_the_result(gpu, oracle, small_probl
         for k in range(pb.n_frames):
             r, t = S.pose_error(o[k], outs[0][k])
             assert r < 2e-5 and t < 2e-5
+
+
+def test_compact_cache_gives_identical_results(gpu, oracle, small_problem, small_problem_masked):
+    """The compact (z, nx, ny, nz) cache re-derives camPos with the cache builder's exact fp32 operations: the
+    solver's output must be bit-identical to the float4-cache path, through every entry point."""
+    from bundletrack_amd.optimizer import build_cache_zn, pack_zn
+    for pb in (small_problem, small_problem_masked):
+        d, n = upload_frames(gpu, pb)
+        campos, nrm, nvalid, intr = gpu.build_cache(gpu.ws, d, n, pb.H, pb.W, pb.K, 4.0)
+        zn, nvalid2, intr2 = build_cache_zn(gpu.ws, d, n, pb.H, pb.W, pb.K, 4.0)
+        gpu.ws.sync()
+        assert np.array_equal(intr, intr2) and np.array_equal(nvalid.cpu().numpy(), nvalid2.cpu().numpy())
+        znh, camh, nrmh = zn.cpu().numpy(), campos.cpu().numpy(), nrm.cpu().numpy()
+        assert np.array_equal(znh[..., 1:], nrmh[..., :3])
+        valid = camh[..., 3] == 1
+        assert np.array_equal(znh[..., 0][valid], camh[..., 2][valid])                 # z = depth where valid
+        assert np.array_equal(pack_zn(gpu.ws, campos, nrm).cpu().numpy()[valid], znh[valid])
+        bs = gpu.BatchSolver(gpu.ws)
+        corr_d, offs_d, mx, poses_a = batch_inputs(gpu, bs, camh[None], None, [pb.corr], [pb.poses_init])
+        poses_b = poses_a.clone()
+        ta = bs.trace_view(bs.solve(campos[None], nrm[None], intr, corr_d, offs_d, mx, poses_a, trace=True))
+        tb = bs.trace_view(bs.solve_zn(zn[None], pb.H, pb.W, pb.K, corr_d, offs_d, mx, poses_b, trace=True))
+        assert np.array_equal(ta.dense_pair, tb.dense_pair)          # every per-pair sum, every iteration
+        assert np.array_equal(poses_a.cpu().numpy(), poses_b.cpu().numpy())
+        p1, p2 = pb.poses_init.copy(), pb.poses_init.copy()
+        gpu.OptimizerGpu(workspace=gpu.ws).optimizeFrames(pb.corr, None, pb.n_frames, pb.H, pb.W, d, None, n, p1, pb.K)
+        gpu.OptimizerGpu(workspace=gpu.ws, flags=_lib.FLAG_FLOAT4_CACHE).optimizeFrames(pb.corr, None, pb.n_frames, pb.H, pb.W, d, None, n, p2, pb.K)
+        assert np.array_equal(p1, p2)
+
+
+def test_compact_cache_general_intrinsics(gpu, oracle):
+    """Skewed K (non-zero K[0,1]): the general back-projection path, against the oracle."""
+    K = S.NOCS_K.copy(); K[0, 1] = 3.7
+    pb = S.make_problem(3, 200, seed=61, background=False, K=K)
+    d, n = upload_frames(gpu, pb)
+    ocam, onrm, ointr, _ = oracle_cache(oracle, pb)
+    ref = oracle.solve(ocam, onrm, ointr, pb.corr, pb.poses_init)
+    poses = pb.poses_init.copy()
+    gpu.OptimizerGpu(workspace=gpu.ws).optimizeFrames(pb.corr, None, pb.n_frames, pb.H, pb.W, d, None, n, poses, pb.K)
+    for k in range(pb.n_frames):
+        r, t = S.pose_error(poses[k], ref.poses[k])
+        assert r < TOL_R and t < TOL_T
