@@ -59,6 +59,7 @@ struct btba_workspace {
     int device = 0;
     DevBuf x, T, Tinv, sparse_part, dense_part, pairsum, dense_pairs, ptrs;
     DevBuf corr, offsets, poses, campos, normals, nvalid;   // optimize_frames staging
+    DevBuf valid_lists, valid_counts;                       // per-frame lists of pixels with a depth (compact cache)
     std::vector<int32_t> dense_pairs_host;                  // what dense_pairs currently holds
     int dense_pairs_frames = -1;
     std::vector<EventPair> events;                          // pending timed regions
@@ -147,7 +148,7 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto &ep : ws->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs,
-                       &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid };
+                       &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts };
     for (auto b : bufs) b->release();
     if (ws->aux_stream) (void)hipStreamDestroy(ws->aux_stream);
     if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
@@ -370,6 +371,13 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         const int total = B * N;
         k_prepare<<<(total + 63) / 64, 64, 0, ws->stream>>>(total, poses, ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>());
     }
+    // per-frame valid-pixel lists for the compact dense sweep (once per solve; the frames do not change across iterations)
+    const bool compaction = use_zn && use_dense && !(prm->flags & BTBA_FLAG_NO_COMPACTION);
+    if (compaction) {
+        if ((rc = ws->valid_lists.ensure(sizeof(uint32_t) * (size_t)B * N * npix))) return rc;
+        if ((rc = ws->valid_counts.ensure(sizeof(int) * (size_t)B * N))) return rc;
+        k_valid_lists<<<B * N, kBlock, 0, ws->stream>>>(npix, reinterpret_cast<const float4 *>(Z.zn), ws->valid_lists.as<uint32_t>(), ws->valid_counts.as<int>());
+    }
     // Software pipelining across instances: the batch is split in two halves on two streams, so one half's
     // latency-bound k_system_solve (B/2 workgroups on a 256-CU chip) and its sparse sweep overlap the other
     // half's dense sweep.  Halves never touch each other's data; fork/join events keep the caller's stream
@@ -397,6 +405,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             const size_t b0 = (size_t)H.b0;
             const float *campos_h = campos ? campos + 4 * b0 * N * npix : nullptr, *normals_h = normals ? normals + 4 * b0 * N * npix : nullptr;
             const float4 *zn_h = use_zn ? reinterpret_cast<const float4 *>(Z.zn) + b0 * N * npix : nullptr;
+            const uint32_t *vl_h = compaction ? ws->valid_lists.as<uint32_t>() + b0 * N * npix : nullptr;
+            const int *vc_h = compaction ? ws->valid_counts.as<int>() + b0 * N : nullptr;
             const float4 *corr_h = corr ? reinterpret_cast<const float4 *>(corr) + 2 * b0 * (size_t)corr_stride : nullptr;
             const uint32_t *off_h = pair_offsets ? pair_offsets + b0 * (P + 1) : nullptr;
             float *x_h = ws->x.as<float>() + 6 * b0 * N, *T_h = ws->T.as<float>() + 16 * b0 * N, *Ti_h = ws->Tinv.as<float>() + 16 * b0 * N;
@@ -413,7 +423,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             if (fuse) {
                 // one launch: HBM-streaming sparse workgroups interleaved with the VALU-bound dense ones
                 if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
-#define BTBA_FUSED_ARGS(CACHE) D, n_d, n_s, CACHE, reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, corr_h, off_h, sp_h
+#define BTBA_FUSED_ARGS(CACHE) D, n_d, n_s, CACHE, reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, corr_h, off_h, sp_h, vl_h, vc_h
                 if (zn_layout == 0) k_fused_sweeps<0><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(reinterpret_cast<const float4 *>(campos_h)));
                 else if (zn_layout == 1) k_fused_sweeps<1><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
                 else k_fused_sweeps<2><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
@@ -430,8 +440,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                     if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
                     const dim3 dgrid(n_d);
 #define BTBA_DENSE_ARGS D, reinterpret_cast<const float4 *>(campos_h), reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h
-                    if (zn_layout == 1) k_dense_sweep_zn<true><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h);
-                    else if (zn_layout == 2) k_dense_sweep_zn<false><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h);
+                    if (zn_layout == 1) k_dense_sweep_zn<true><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    else if (zn_layout == 2) k_dense_sweep_zn<false><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
                     else if (prm->flags & BTBA_FLAG_DENSE_2PIX) k_dense_sweep<2, 2><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
                     else if (prm->flags & BTBA_FLAG_DENSE_4WAVE) k_dense_sweep<1, 4><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
                     else k_dense_sweep<1, 3><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);

@@ -465,12 +465,40 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
     block_reduce_store<kDenseVals, 4>(acc, red, out);
 }
 
+// Ordered list of the pixels of every frame that carry a depth (>= 0.1 m, the cache builder's validity rule).
+// grid (B * K) x 256.  The dense sweep walks this list instead of all Wd x Hd source pixels: a tracker's frames
+// are masked to the object (~5 % of the image, src/Frame.cpp:342-358), so 95 % of the source stream disappears.
+// Deterministic order (ascending pixel index): ballot + mbcnt prefix inside a wave, fixed wave order.
+__global__ void __launch_bounds__(kBlock) k_valid_lists(int npix, const float4 *__restrict__ zn, uint32_t *__restrict__ lists, int *__restrict__ counts)
+{
+    __shared__ int wave_cnt[4];
+    const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4 *z = zn + (size_t)f * npix;
+    uint32_t *out = lists + (size_t)f * npix;
+    int base = 0;
+    for (int s0 = 0; s0 < npix; s0 += kBlock) {
+        const int s = s0 + (int)threadIdx.x;
+        const bool v = (s < npix) && ((double)z[s].x >= 0.1);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; w++) off += wave_cnt[w];
+        if (v) out[off + before] = (uint32_t)s;
+        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[f] = base;
+}
+
 // The same sweep on the compact cache: ONE 16-byte load per source pixel and per tap (5 loads instead of 10),
 // camera-space points re-derived from z with the cache builder's exact arithmetic (zn_backproject).
 template <bool SIMPLE>
 __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
                                                const float *__restrict__ T, const float *__restrict__ Tinv,
-                                               float *__restrict__ partials, int tile, int p, int b, float *red)
+                                               float *__restrict__ partials, int tile, int p, int b, float *red,
+                                               const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts)
 {
     const int2 ij = dense_pairs[p];
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
@@ -483,23 +511,30 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
     C.delta = D.robust_delta; C.delta2 = D.robust_delta * D.robust_delta; C.w_dense = D.w_dense;
     C.W = D.width; C.H = D.height;
     const float4 *zn_t = zn + (fb + fi) * (size_t)D.npix, *zn_s = zn + (fb + fj) * (size_t)D.npix;
-    const int per = (D.npix + D.dense_tiles - 1) / D.dense_tiles;
-    const int lo = min(D.npix, per * tile), hi = min(D.npix, per * (tile + 1));
+    // the source frame's pixels with a depth, in ascending order; a fully valid frame is walked directly
+    const int n_src = valid_counts ? valid_counts[fb + fj] : D.npix;
+    const bool direct = (n_src == D.npix);
+    const uint32_t *list = valid_lists ? valid_lists + (fb + fj) * (size_t)D.npix : nullptr;
+    const int per = (n_src + D.dense_tiles - 1) / D.dense_tiles;
+    const int lo = min(n_src, per * tile), hi = min(n_src, per * (tile + 1));
+    const float inv_w = 1.0f / (float)D.width;
     float acc[kDenseVals];
 #pragma unroll
     for (int k = 0; k < kDenseVals; k++) acc[k] = 0.0f;
 
-    int s = lo + (int)threadIdx.x;
-    int px = s % D.width, py = s / D.width;                // pixel coordinates advance incrementally (no division in the loop)
-    const int step_x = kBlock % D.width, step_y = kBlock / D.width;
+    int t = lo + (int)threadIdx.x;
+    int s_n = (t < hi) ? (direct ? t : (int)list[t]) : 0;
     float4 zs_n = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (s < hi) zs_n = zn_s[s];
-    for (; s < hi; s += kBlock) {
+    if (t < hi) zs_n = zn_s[s_n];
+    for (; t < hi; t += kBlock) {
         const float4 zs = zs_n;
-        if (s + kBlock < hi) zs_n = zn_s[s + kBlock];
+        const int s = s_n;
+        if (t + kBlock < hi) { s_n = direct ? t + kBlock : (int)list[t + kBlock]; zs_n = zn_s[s_n]; }      // next pixel's stream loads
+        int py = (int)((float)s * inv_w);                   // s < 2^24: exact up to one unit, fixed up below
+        py -= (py * D.width > s) ? 1 : 0;
+        py += ((py + 1) * D.width <= s) ? 1 : 0;
+        const int px = s - py * D.width;
         const float3 cp = zn_backproject<SIMPLE>(D.zn_ki, zn_src_coord(px, D.zn_scale_w), zn_src_coord(py, D.zn_scale_h), zs.x);
-        px += step_x; py += step_y;
-        if (px >= D.width) { px -= D.width; py++; }
         const PixelGeom g = pixel_geom(C, make_float4(cp.x, cp.y, cp.z, 1.0f), make_float4(zs.y, zs.z, zs.w, 0.0f));
         if (__builtin_amdgcn_ballot_w64(g.valid) == 0ull) continue;
         const float4 z00 = zn_t[g.i00], z10 = zn_t[g.i10], z01 = zn_t[g.i01], z11 = zn_t[g.i11];
@@ -516,14 +551,15 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
 
 template <bool SIMPLE>
 __global__ void __launch_bounds__(kBlock, 3) k_dense_sweep_zn(SolveDims D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
-                                                             const float *__restrict__ T, const float *__restrict__ Tinv, float *__restrict__ partials)
+                                                             const float *__restrict__ T, const float *__restrict__ Tinv, float *__restrict__ partials,
+                                                             const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts)
 {
     __shared__ float red[4 * kDenseVals];
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = (int)(L % (unsigned)D.dense_tiles);
     const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
     const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
-    dense_block_zn<SIMPLE>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red);
+    dense_block_zn<SIMPLE>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts);
 }
 
 // 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).
@@ -549,7 +585,8 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused_sweeps(SolveDims D, unsigne
                                                            const float4 *__restrict__ campos, const float4 *__restrict__ normals,
                                                            const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
                                                            float *__restrict__ dense_partials,
-                                                           const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets, float *__restrict__ sparse_partials)
+                                                           const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets, float *__restrict__ sparse_partials,
+                                                           const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts)
 {
     __shared__ float red[4 * kSparseVals];
     const unsigned G = n_d + n_s, g = blockIdx.x, xcd = g & 7u, slot = g >> 3;
@@ -573,8 +610,8 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused_sweeps(SolveDims D, unsigne
         const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
         const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
         if (LAYOUT == 0) dense_block<1>(D, campos, normals, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
-        else if (LAYOUT == 1) dense_block_zn<true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);     // `campos` carries the compact cache
-        else dense_block_zn<false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
+        else if (LAYOUT == 1) dense_block_zn<true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts);     // `campos` carries the compact cache
+        else dense_block_zn<false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts);
     }
 }
 
