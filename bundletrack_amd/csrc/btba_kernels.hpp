@@ -522,10 +522,32 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
 #pragma unroll
     for (int k = 0; k < kDenseVals; k++) acc[k] = 0.0f;
 
-    auto pixel = [&](int px, int py, const float4 &zs) {
+    // ONE loop body (inlined once: the kernel sits right at the 96-VGPR / 5-waves-per-SIMD boundary); only the way
+    // the next source pixel and its coordinates are found depends on whether the frame is fully valid.
+    int t = lo + (int)threadIdx.x;
+    int s_n = (t < hi) ? (direct ? t : (int)list[t]) : 0;
+    int px_i = s_n % D.width, py_i = s_n / D.width;             // incremental coordinates (direct walk only)
+    const int step_x = kBlock % D.width, step_y = kBlock / D.width;
+    float4 zs_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < hi) zs_n = zn_s[s_n];
+    for (; t < hi; t += kBlock) {
+        const float4 zs = zs_n;
+        const int s = s_n;
+        if (t + kBlock < hi) { s_n = direct ? t + kBlock : (int)list[t + kBlock]; zs_n = zn_s[s_n]; }      // next pixel's stream loads
+        int px, py;
+        if (direct) {
+            px = px_i; py = py_i;
+            px_i += step_x; py_i += step_y;
+            if (px_i >= D.width) { px_i -= D.width; py_i++; }
+        } else {
+            py = (int)((float)s * inv_w);                       // s < 2^24: exact up to one unit, fixed up below
+            py -= (py * D.width > s) ? 1 : 0;
+            py += ((py + 1) * D.width <= s) ? 1 : 0;
+            px = s - py * D.width;
+        }
         const float3 cp = zn_backproject<SIMPLE>(D.zn_ki, zn_src_coord(px, D.zn_scale_w), zn_src_coord(py, D.zn_scale_h), zs.x);
         const PixelGeom g = pixel_geom(C, make_float4(cp.x, cp.y, cp.z, 1.0f), make_float4(zs.y, zs.z, zs.w, 0.0f));
-        if (__builtin_amdgcn_ballot_w64(g.valid) == 0ull) return;
+        if (__builtin_amdgcn_ballot_w64(g.valid) == 0ull) continue;
         const float4 z00 = zn_t[g.i00], z10 = zn_t[g.i10], z01 = zn_t[g.i01], z11 = zn_t[g.i11];
         const unsigned xia = zn_src_coord(g.xa, D.zn_scale_w), xib = zn_src_coord(g.xb, D.zn_scale_w);
         const unsigned yia = zn_src_coord(g.ya, D.zn_scale_h), yib = zn_src_coord(g.yb, D.zn_scale_h);
@@ -533,43 +555,13 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
         const float3 c01 = zn_backproject<SIMPLE>(D.zn_ki, xia, yib, z01.x), c11 = zn_backproject<SIMPLE>(D.zn_ki, xib, yib, z11.x);
         pixel_accumulate(C, g, make_float4(c00.x, c00.y, c00.z, 1.f), make_float4(c10.x, c10.y, c10.z, 1.f), make_float4(c01.x, c01.y, c01.z, 1.f), make_float4(c11.x, c11.y, c11.z, 1.f),
                          make_float4(z00.y, z00.z, z00.w, 0.f), make_float4(z10.y, z10.z, z10.w, 0.f), make_float4(z01.y, z01.z, z01.w, 0.f), make_float4(z11.y, z11.z, z11.w, 0.f), acc);
-    };
-    if (direct) {
-        // every pixel of the source frame has a depth: consecutive pixels, coordinates advanced incrementally
-        int s = lo + (int)threadIdx.x;
-        int px = s % D.width, py = s / D.width;
-        const int step_x = kBlock % D.width, step_y = kBlock / D.width;
-        float4 zs_n = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s < hi) zs_n = zn_s[s];
-        for (; s < hi; s += kBlock) {
-            const float4 zs = zs_n;
-            if (s + kBlock < hi) zs_n = zn_s[s + kBlock];          // next pixel's stream load
-            const int cx_ = px, cy_ = py;
-            px += step_x; py += step_y;
-            if (px >= D.width) { px -= D.width; py++; }
-            pixel(cx_, cy_, zs);
-        }
-    } else {
-        int t = lo + (int)threadIdx.x;
-        int s_n = (t < hi) ? (int)list[t] : 0;
-        float4 zs_n = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < hi) zs_n = zn_s[s_n];
-        for (; t < hi; t += kBlock) {
-            const float4 zs = zs_n;
-            const int s = s_n;
-            if (t + kBlock < hi) { s_n = (int)list[t + kBlock]; zs_n = zn_s[s_n]; }
-            int py = (int)((float)s * inv_w);                   // s < 2^24: exact up to one unit, fixed up below
-            py -= (py * D.width > s) ? 1 : 0;
-            py += ((py + 1) * D.width <= s) ? 1 : 0;
-            pixel(s - py * D.width, py, zs);
-        }
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
     block_reduce_store<kDenseVals, 4>(acc, red, out);
 }
 
 template <bool SIMPLE>
-__global__ void __launch_bounds__(kBlock, 3) k_dense_sweep_zn(SolveDims D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
+__global__ void __launch_bounds__(kBlock, 5) k_dense_sweep_zn(SolveDims D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
                                                              const float *__restrict__ T, const float *__restrict__ Tinv, float *__restrict__ partials,
                                                              const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts)
 {
