@@ -372,7 +372,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         k_prepare<<<(total + 63) / 64, 64, 0, ws->stream>>>(total, poses, ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>());
     }
     // per-frame valid-pixel lists for the compact dense sweep (once per solve; the frames do not change across iterations)
-    const bool compaction = use_zn && use_dense && !(prm->flags & BTBA_FLAG_NO_COMPACTION);
+    const bool compaction = use_zn && use_dense && (prm->flags & BTBA_FLAG_COMPACTION);
     if (compaction) {
         if ((rc = ws->valid_lists.ensure(sizeof(uint32_t) * (size_t)B * N * npix))) return rc;
         if ((rc = ws->valid_counts.ensure(sizeof(int) * (size_t)B * N))) return rc;
@@ -424,9 +424,12 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                 // one launch: HBM-streaming sparse workgroups interleaved with the VALU-bound dense ones
                 if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
 #define BTBA_FUSED_ARGS(CACHE) D, n_d, n_s, CACHE, reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, corr_h, off_h, sp_h, vl_h, vc_h
-                if (zn_layout == 0) k_fused_sweeps<0><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(reinterpret_cast<const float4 *>(campos_h)));
-                else if (zn_layout == 1) k_fused_sweeps<1><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
-                else k_fused_sweeps<2><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
+                const int lay = zn_layout ? zn_layout + (compaction ? 2 : 0) : 0;
+                if (lay == 0) k_fused_sweeps<0><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(reinterpret_cast<const float4 *>(campos_h)));
+                else if (lay == 1) k_fused_sweeps<1><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
+                else if (lay == 2) k_fused_sweeps<2><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
+                else if (lay == 3) k_fused_sweeps<3><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
+                else k_fused_sweeps<4><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
 #undef BTBA_FUSED_ARGS
                 if ((rc = time_end(ws, slot, H.st))) return rc;
                 S.fused_sweeps = 1;
@@ -440,8 +443,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                     if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
                     const dim3 dgrid(n_d);
 #define BTBA_DENSE_ARGS D, reinterpret_cast<const float4 *>(campos_h), reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h
-                    if (zn_layout == 1) k_dense_sweep_zn<true><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
-                    else if (zn_layout == 2) k_dense_sweep_zn<false><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    if (zn_layout == 1 && !compaction) k_dense_sweep_zn<true, false><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    else if (zn_layout == 2 && !compaction) k_dense_sweep_zn<false, false><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    else if (zn_layout == 1) k_dense_sweep_zn<true, true><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    else if (zn_layout == 2) k_dense_sweep_zn<false, true><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
                     else if (prm->flags & BTBA_FLAG_DENSE_2PIX) k_dense_sweep<2, 2><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
                     else if (prm->flags & BTBA_FLAG_DENSE_4WAVE) k_dense_sweep<1, 4><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
                     else k_dense_sweep<1, 3><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
@@ -644,7 +649,19 @@ int btba_optimize_frames(btba_workspace *ws_in, const btba_params *params_in, in
     // keep cache-build timing event, then enqueue the solve
     ws->always_time_region = true;
     ZnSpec Z;
-    if (compact) { Z.zn = ws->campos.as<float>(); Z.H = H; Z.W = W; Z.K = K; }
+    if (compact) {
+        Z.zn = ws->campos.as<float>(); Z.H = H; Z.W = W; Z.K = K;
+        if (!(prm.flags & (BTBA_FLAG_COMPACTION | BTBA_FLAG_NO_COMPACTION))) {
+            // a tracker's frames are masked to the object: walk valid-pixel lists when under 60 % of the pixels carry a depth.
+            // (the cache builder counted them; this call is synchronous anyway, so the 4*N-byte read-back costs nothing extra)
+            std::vector<int32_t> nv(N);
+            if ((e = hipMemcpyAsync(nv.data(), ws->nvalid.p, sizeof(int32_t) * N, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) return hip_fail(e);
+            if ((e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
+            long tot = 0;
+            for (int v : nv) tot += v;
+            if (tot * 10 < (long)N * npix * 6) prm.flags |= BTBA_FLAG_COMPACTION;
+        }
+    }
     rc = solve_enqueue(ws, &prm, 1, N, Hd, Wd, intr, compact ? nullptr : ws->campos.as<float>(), compact ? nullptr : ws->normals.as<float>(), Z, ws->corr.as<btba_entryj>(), (int64_t)(kept ? kept : 1),
                        ws->offsets.as<uint32_t>(), max_per_pair, pairs_ptr, n_pairs_dense, ws->poses.as<float>(), nullptr);
     ws->always_time_region = false;

@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(kBlock) k_valid_lists(int npix, const float4 *
 
 // The same sweep on the compact cache: ONE 16-byte load per source pixel and per tap (5 loads instead of 10),
 // camera-space points re-derived from z with the cache builder's exact arithmetic (zn_backproject).
-template <bool SIMPLE>
+template <bool SIMPLE, bool LISTS>
 __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
                                                const float *__restrict__ T, const float *__restrict__ Tinv,
                                                float *__restrict__ partials, int tile, int p, int b, float *red,
@@ -511,10 +511,11 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
     C.delta = D.robust_delta; C.delta2 = D.robust_delta * D.robust_delta; C.w_dense = D.w_dense;
     C.W = D.width; C.H = D.height;
     const float4 *zn_t = zn + (fb + fi) * (size_t)D.npix, *zn_s = zn + (fb + fj) * (size_t)D.npix;
-    // the source frame's pixels with a depth, in ascending order; a fully valid frame is walked directly
-    const int n_src = valid_counts ? valid_counts[fb + fj] : D.npix;
-    const bool direct = (n_src == D.npix);
-    const uint32_t *list = valid_lists ? valid_lists + (fb + fj) * (size_t)D.npix : nullptr;
+    // LISTS: walk the source frame's ordered list of pixels that carry a depth (masked scenes: ~5 % of the image);
+    // otherwise walk all pixels with incrementally advanced coordinates.  Two instantiations rather than one loop
+    // with both: the kernel sits at the 96-VGPR / 5-waves-per-SIMD boundary and the merged loop measured 8 % slower.
+    const int n_src = LISTS ? valid_counts[fb + fj] : D.npix;
+    const uint32_t *list = LISTS ? valid_lists + (fb + fj) * (size_t)D.npix : nullptr;
     const int per = (n_src + D.dense_tiles - 1) / D.dense_tiles;
     const int lo = min(n_src, per * tile), hi = min(n_src, per * (tile + 1));
     const float inv_w = 1.0f / (float)D.width;
@@ -522,10 +523,8 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
 #pragma unroll
     for (int k = 0; k < kDenseVals; k++) acc[k] = 0.0f;
 
-    // ONE loop body (inlined once: the kernel sits right at the 96-VGPR / 5-waves-per-SIMD boundary); only the way
-    // the next source pixel and its coordinates are found depends on whether the frame is fully valid.
     int t = lo + (int)threadIdx.x;
-    int s_n = (t < hi) ? (direct ? t : (int)list[t]) : 0;
+    int s_n = (t < hi) ? (LISTS ? (int)list[t] : t) : 0;
     int px_i = s_n % D.width, py_i = s_n / D.width;             // incremental coordinates (direct walk only)
     const int step_x = kBlock % D.width, step_y = kBlock / D.width;
     float4 zs_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -533,9 +532,9 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
     for (; t < hi; t += kBlock) {
         const float4 zs = zs_n;
         const int s = s_n;
-        if (t + kBlock < hi) { s_n = direct ? t + kBlock : (int)list[t + kBlock]; zs_n = zn_s[s_n]; }      // next pixel's stream loads
+        if (t + kBlock < hi) { s_n = LISTS ? (int)list[t + kBlock] : t + kBlock; zs_n = zn_s[s_n]; }      // next pixel's stream loads
         int px, py;
-        if (direct) {
+        if (!LISTS) {
             px = px_i; py = py_i;
             px_i += step_x; py_i += step_y;
             if (px_i >= D.width) { px_i -= D.width; py_i++; }
@@ -560,8 +559,8 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
     block_reduce_store<kDenseVals, 4>(acc, red, out);
 }
 
-template <bool SIMPLE>
-__global__ void __launch_bounds__(kBlock, 5) k_dense_sweep_zn(SolveDims D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
+template <bool SIMPLE, bool LISTS>
+__global__ void __launch_bounds__(kBlock, 3) k_dense_sweep_zn(SolveDims D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
                                                              const float *__restrict__ T, const float *__restrict__ Tinv, float *__restrict__ partials,
                                                              const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts)
 {
@@ -570,7 +569,7 @@ __global__ void __launch_bounds__(kBlock, 5) k_dense_sweep_zn(SolveDims D, const
     const int tile = (int)(L % (unsigned)D.dense_tiles);
     const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
     const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
-    dense_block_zn<SIMPLE>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts);
+    dense_block_zn<SIMPLE, LISTS>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts);
 }
 
 // 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).
@@ -591,7 +590,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, cons
 // n_s sparse workgroups (HBM-streaming) so the two overlap on every CU instead of running back to back.
 // Per XCD x (blocks g = 8 s + x, s = slot): a contiguous range of dense items (L2 locality, as in xcd_remap)
 // and every R_x-th slot a sparse item.
-template <int LAYOUT>   // 0: float4 camPos + float4 normals, 1: compact cache (zero-skew intrinsics), 2: compact cache (general)
+template <int LAYOUT>   // 0: float4 camPos + float4 normals; compact cache: 1 zero-skew K, 2 general K, 3 / 4 the same walking valid-pixel lists
 __global__ void __launch_bounds__(kBlock, 3) k_fused_sweeps(SolveDims D, unsigned n_d, unsigned n_s,
                                                            const float4 *__restrict__ campos, const float4 *__restrict__ normals,
                                                            const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
@@ -621,8 +620,10 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused_sweeps(SolveDims D, unsigne
         const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
         const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
         if (LAYOUT == 0) dense_block<1>(D, campos, normals, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
-        else if (LAYOUT == 1) dense_block_zn<true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts);     // `campos` carries the compact cache
-        else dense_block_zn<false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts);
+        else if (LAYOUT == 1) dense_block_zn<true, false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts);     // `campos` carries the compact cache
+        else if (LAYOUT == 2) dense_block_zn<false, false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts);
+        else if (LAYOUT == 3) dense_block_zn<true, true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts);
+        else dense_block_zn<false, true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts);
     }
 }
 

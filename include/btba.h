@@ -66,7 +66,10 @@ enum {
     BTBA_FLAG_DENSE_2PIX   = 8,   /* tuning: dense sweep variant with two pixels per lane per trip     */
     BTBA_FLAG_DENSE_4WAVE  = 16,  /* tuning: one pixel per trip, registers capped for 4 waves per SIMD (spills) */
     BTBA_FLAG_NO_FUSE      = 64,  /* never launch the sparse and the dense sweep as one interleaved launch */
-    BTBA_FLAG_NO_COMPACTION = 512, /* compact cache: walk all Wd x Hd source pixels instead of the per-frame list of pixels with a depth */
+    BTBA_FLAG_NO_COMPACTION = 512, /* compact cache: always walk all Wd x Hd source pixels */
+    BTBA_FLAG_COMPACTION   = 1024, /* compact cache: walk each source frame's ordered list of pixels that carry a depth (masked scenes).
+                                      btba_optimize_frames decides by itself from the valid-pixel counts unless one of the two is set;
+                                      btba_solve_batch_zn (asynchronous, no read-back) uses lists only when this flag is set */
     BTBA_FLAG_FLOAT4_CACHE = 256, /* btba_optimize_frames: build the reference-layout float4 cache instead of the compact one */
     BTBA_FLAG_FUSE         = 128, /* always do (default: only for batches of <= 16 instances, where it is measured faster) */
     BTBA_FLAG_OVERLAP      = 32   /* split a batch over two streams (main + low-priority) so one half's k_system_solve

@@ -432,22 +432,25 @@ def test_compact_cache_general_intrinsics(gpu, oracle):
 
 
 def test_valid_pixel_compaction(gpu, oracle, small_problem, small_problem_masked):
-    """Walking each source frame's list of pixels with a depth (default) vs all Wd x Hd pixels: identical bits when
-    every pixel is valid (the list is bypassed), round-off-level agreement on masked scenes (different lane
-    assignment); the accepted-pixel counts are identical either way."""
+    """Walking each source frame's list of pixels with a depth (BTBA_FLAG_COMPACTION; chosen automatically by
+    optimize_frames for masked frames) vs all Wd x Hd pixels: round-off-level agreement (different kernel
+    instantiation / lane assignment); the accepted-pixel counts are identical either way."""
     from bundletrack_amd.optimizer import build_cache_zn
     for pb, full in ((small_problem, True), (small_problem_masked, False)):
         d, n = upload_frames(gpu, pb)
         zn, nvalid, intr = build_cache_zn(gpu.ws, d, n, pb.H, pb.W, pb.K, 4.0)
         outs, cnts = [], []
-        for flags in (0, _lib.FLAG_NO_COMPACTION):
+        for flags in (_lib.FLAG_COMPACTION, 0):
             bs = gpu.BatchSolver(gpu.ws, flags=flags)
             corr_d, offs_d, mx, poses_d = batch_inputs(gpu, bs, zn.cpu().numpy()[None], None, [pb.corr], [pb.poses_init])
             tv = bs.trace_view(bs.solve_zn(zn[None], pb.H, pb.W, pb.K, corr_d, offs_d, mx, poses_d, trace=True))
             outs.append(poses_d.cpu().numpy()[0]); cnts.append(tv.dense_pair[0, :, :, 27].copy())
         if full:
             assert int(nvalid.min()) == zn.shape[1] * zn.shape[2]
-            assert np.array_equal(outs[0], outs[1])
+            assert np.array_equal(cnts[0][0], cnts[1][0])
+            for k in range(pb.n_frames):
+                r, t = S.pose_error(outs[0][k], outs[1][k])
+                assert r < 1e-3 and t < 1e-3            # weakly conditioned 100 %-valid K=4 scene, see test_parity_on_weakly_conditioned_scenes
         else:
             assert int(nvalid.max()) < 0.2 * zn.shape[1] * zn.shape[2]
             assert np.array_equal(cnts[0][0], cnts[1][0])            # first linearisation: same accepted pixels
