@@ -930,23 +930,28 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             const float4 *a2 = reinterpret_cast<const float4 *>(A + (size_t)min(lane + 128, n - 1) * ld), *a3 = reinterpret_cast<const float4 *>(A + (size_t)min(lane + 192, n - 1) * ld);
             const float4 *p4 = reinterpret_cast<const float4 *>(vp);
             const int nq = ld >> 2;                       // 16-byte chunks per row (pad columns hold zeros)
+            // four independent partial sums per row (x, y, z, w lanes of the 16-byte chunks): the single wave has no other
+            // work to hide FMA latency behind, so a 92-long dependent chain per row was the critical path of this phase
+            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0;
             if (n <= 128) {
 _Pragma("unroll 8")
                 for (int c = 0; c < nq; c++) {
                     const float4 pc = p4[c], r0 = a0[c], r1 = a1[c];
-                    ap_[0] += r0.x * pc.x + r0.y * pc.y + r0.z * pc.z + r0.w * pc.w;
-                    ap_[1] += r1.x * pc.x + r1.y * pc.y + r1.z * pc.z + r1.w * pc.w;
+                    q0.x += r0.x * pc.x; q0.y += r0.y * pc.y; q0.z += r0.z * pc.z; q0.w += r0.w * pc.w;
+                    q1.x += r1.x * pc.x; q1.y += r1.y * pc.y; q1.z += r1.z * pc.z; q1.w += r1.w * pc.w;
                 }
             } else {
 _Pragma("unroll 4")
                 for (int c = 0; c < nq; c++) {
                     const float4 pc = p4[c], r0 = a0[c], r1 = a1[c], r2 = a2[c], r3 = a3[c];
-                    ap_[0] += r0.x * pc.x + r0.y * pc.y + r0.z * pc.z + r0.w * pc.w;
-                    ap_[1] += r1.x * pc.x + r1.y * pc.y + r1.z * pc.z + r1.w * pc.w;
-                    ap_[2] += r2.x * pc.x + r2.y * pc.y + r2.z * pc.z + r2.w * pc.w;
-                    ap_[3] += r3.x * pc.x + r3.y * pc.y + r3.z * pc.z + r3.w * pc.w;
+                    q0.x += r0.x * pc.x; q0.y += r0.y * pc.y; q0.z += r0.z * pc.z; q0.w += r0.w * pc.w;
+                    q1.x += r1.x * pc.x; q1.y += r1.y * pc.y; q1.z += r1.z * pc.z; q1.w += r1.w * pc.w;
+                    q2.x += r2.x * pc.x; q2.y += r2.y * pc.y; q2.z += r2.z * pc.z; q2.w += r2.w * pc.w;
+                    q3.x += r3.x * pc.x; q3.y += r3.y * pc.y; q3.z += r3.z * pc.z; q3.w += r3.w * pc.w;
                 }
             }
+            ap_[0] = (q0.x + q0.y) + (q0.z + q0.w); ap_[1] = (q1.x + q1.y) + (q1.z + q1.w);
+            ap_[2] = (q2.x + q2.y) + (q2.z + q2.w); ap_[3] = (q3.x + q3.y) + (q3.z + q3.w);
             part = 0.0f;
 #pragma unroll
             for (int j = 0; j < kMaxRows; j++) part += (lane + 64 * j < n) ? p_[j] * ap_[j] : 0.0f;
