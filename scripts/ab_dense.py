@@ -20,7 +20,7 @@ def main():
         corr_d = torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(dev); offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
         poses0 = torch.from_numpy(np.stack([p["poses"] for p in pick])).to(dev)
         ref = None
-        for name, flag in (("split-solve", 0), ("mono-solve", 2048)):
+        for name, flag in (("default", 0), ("no-fuse", 64)):
             for tiles in ((3, 5, 8) if B > 1 else (15, 25)):
                 bs = BatchSolver(ws, dense_tiles=tiles)
                 bs.params.flags |= _lib.FLAG_TIME_KERNELS | flag
