@@ -59,14 +59,13 @@ struct btba_workspace {
     int device = 0;
     DevBuf x, T, Tinv, sparse_part, dense_part, pairsum, dense_pairs, ptrs;
     DevBuf corr, offsets, poses, campos, normals, nvalid;   // optimize_frames staging
-    DevBuf valid_lists, valid_counts;
-    DevBuf Ag, bg, Mg;                                      // assembled system of the split solve                       // per-frame lists of pixels with a depth (compact cache)
+    DevBuf valid_lists, valid_counts;                       // per-frame lists of pixels with a depth (compact cache)
     std::vector<int32_t> dense_pairs_host;                  // what dense_pairs currently holds
     int dense_pairs_frames = -1;
     std::vector<EventPair> events;                          // pending timed regions
     std::vector<hipEvent_t> event_pool;
     btba_stats stats{};
-    bool lds_attr_set = false, lds_attr_pcg = false;
+    bool lds_attr_set = false;
     bool always_time_region = false;   // optimize_frames: ms_solve is part of its stats contract
     hipStream_t aux_stream = nullptr;  // second half of a batch runs here (software pipelining across instances)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -149,7 +148,7 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto &ep : ws->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs,
-                       &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts, &ws->Ag, &ws->bg, &ws->Mg };
+                       &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts };
     for (auto b : bufs) b->release();
     if (ws->aux_stream) (void)hipStreamDestroy(ws->aux_stream);
     if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
@@ -357,22 +356,6 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         ws->lds_attr_set = true;
     }
 
-    // split solve (assembly over N-1 workgroups + small PCG/update launch) unless the single-kernel variant is asked for
-    bool split_solve = !(prm->flags & BTBA_FLAG_MONO_SOLVE);
-    if (split_solve) {
-        int max_adj = 0;
-        if (Pd > 0) { std::vector<int> deg(N, 0); for (int q = 0; q < Pd; q++) { deg[pairs[2 * q]]++; deg[pairs[2 * q + 1]]++; } for (int v : deg) max_adj = std::max(max_adj, v); }
-        if (max_adj > kMaxAdj) split_solve = false;
-    }
-    if (split_solve) {
-        if ((rc = ws->Ag.ensure(sizeof(float) * (size_t)B * n * ld))) return rc;
-        if ((rc = ws->bg.ensure(sizeof(float) * (size_t)B * ld))) return rc;
-        if ((rc = ws->Mg.ensure(sizeof(float) * (size_t)B * ld))) return rc;
-        if ((n * ld + 2 * ld) * sizeof(float) > 64 * 1024 && !ws->lds_attr_pcg) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pcg_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
-            ws->lds_attr_pcg = true;
-        }
-    }
     // stats bookkeeping (collected after sync)
     btba_stats &S = ws->stats;
     if (ws->events.empty() || !timing) std::memset(&S, 0, sizeof S);     // new accumulation window
@@ -472,11 +455,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                 }
             }
             if ((rc = time_begin(ws, timing, 2, &slot, H.st))) return rc;
-            if (split_solve) {
-                float *Ag_h = ws->Ag.as<float>() + b0 * n * ld, *bg_h = ws->bg.as<float>() + b0 * ld, *Mg_h = ws->Mg.as<float>() + b0 * ld;
-                k_assemble_rows<<<dim3(N - 1, H.nb), kAsmBlock, 0, H.st>>>(D, it, (int)ld, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, T_h, Ag_h, bg_h, Mg_h, tr_h);
-                k_pcg_update<<<H.nb, 256, (n * ld + 2 * ld) * sizeof(float), H.st>>>(D, it, (int)ld, Ag_h, bg_h, Mg_h, x_h, T_h, Ti_h, tr_h);
-            } else if (D.pairsum_in_lds) k_system_solve<true><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h);
+            if (D.pairsum_in_lds) k_system_solve<true><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h);
             else k_system_solve<false><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h);
             if ((rc = time_end(ws, slot, H.st))) return rc;
         }

@@ -1008,280 +1008,3 @@ _Pragma("unroll 4")
 }
 
 }  // namespace btba
-
-// =====================================================================================================
-// Split system solve: the assembly is spread over N-1 workgroups per instance (one per free frame), the
-// PCG + update run in a second, small launch.  k_system_solve above does everything in one workgroup per
-// instance (36 us at c3, of which 24 us are the serial reduce / congruence / assemble phases); splitting
-// shortens the per-iteration critical path to ~6 us + one launch boundary + ~14 us.
-// =====================================================================================================
-namespace btba {
-
-// row r of the camera-frame -> model-frame congruence M = [[R, 0], [[t]x R, R]] of pose Tt (row-major 4x4)
-__device__ __forceinline__ void congruence_row(const float *Tt, int r, float (&Mr)[6])
-{
-    if (r < 3) {
-        Mr[0] = Tt[4 * r]; Mr[1] = Tt[4 * r + 1]; Mr[2] = Tt[4 * r + 2]; Mr[3] = 0.f; Mr[4] = 0.f; Mr[5] = 0.f;
-    } else {
-        const int q = r - 3, qa = (q + 1) % 3, qb = (q + 2) % 3;         // ([t]x R)[q][c] = t[qa] R[qb][c] - t[qb] R[qa][c]
-        const float ta = Tt[4 * qa + 3], tb = Tt[4 * qb + 3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) { Mr[c] = ta * Tt[4 * qb + c] - tb * Tt[4 * qa + c]; Mr[3 + c] = Tt[4 * q + c]; }
-    }
-}
-
-constexpr int kAsmBlock = 256;
-constexpr int kMaxAdj = 80;       // dense pairs one frame may take part in (2 (N-1) for an explicit both-ways list at N = 40)
-
-// grid (N - 1, B) x 256: workgroup (k - 1, b) builds rows 6k .. 6k+5 of the normal matrix, the right-hand side and the
-// Jacobi diagonal of frame k.  Outputs (global, L2-resident): Ag [B][6N][ld], bg [B][ld], Mg [B][ld].
-__global__ void __launch_bounds__(kAsmBlock) k_assemble_rows(SolveDims D, int iter, int ld,
-                                                            const float *__restrict__ sparse_partials, const float *__restrict__ dense_partials,
-                                                            const int2 *__restrict__ dense_pairs, const int *__restrict__ adj_off, const int *__restrict__ adj,
-                                                            const float *__restrict__ T, float *__restrict__ Ag, float *__restrict__ bg, float *__restrict__ Mg,
-                                                            float *__restrict__ trace)
-{
-    __shared__ float sp[40 * kSparseVals];            // sparse pair sums of the pairs (k, m), indexed by m
-    __shared__ float dr[kMaxAdj * kDenseVals];        // dense pair sums of k's pairs, camera frame
-    __shared__ float dm[kMaxAdj * kDenseVals];        // ... model frame
-    __shared__ float vT[40 * 16];
-    __shared__ int aq[kMaxAdj];                       // adjacency entries of k: pair << 1 | is_source
-    __shared__ int ai[kMaxAdj], aj[kMaxAdj];          // (target, source) of those pairs
-    const int k = blockIdx.x + 1, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
-    const int N = D.n_frames, n = 6 * N;
-    const int a0 = D.use_dense ? adj_off[k] : 0, na = D.use_dense ? min(adj_off[k + 1] - a0, kMaxAdj) : 0;
-    for (int e = tid; e < 16 * N; e += nthr) vT[e] = T[16 * (size_t)b * N + e];
-    for (int e = tid; e < na; e += nthr) { const int a = adj[a0 + e]; aq[e] = a; const int2 ij = dense_pairs[a >> 1]; ai[e] = ij.x; aj[e] = ij.y; }
-    __syncthreads();
-    // reduce the sweep partials of this frame's pairs (fixed order over chunks / tiles)
-    if (D.use_sparse) {
-        const float *src = sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals;
-        for (int e = tid; e < N * kSparseVals; e += nthr) {
-            const int m = e / kSparseVals, v = e % kSparseVals;
-            float s = 0.0f;
-            if (m != k) {
-                const int i = m < k ? m : k, j = m < k ? k : m;
-                s = strided_sum(src + (size_t)pair_index(i, j, N) * D.sparse_chunks * kSparseVals + v, D.sparse_chunks, kSparseVals);
-            }
-            sp[e] = s;
-        }
-    }
-    if (D.use_dense) {
-        const float *src = dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals;
-        for (int e = tid; e < na * kDenseVals; e += nthr) {
-            const int q = e / kDenseVals, v = e % kDenseVals;
-            dr[e] = strided_sum(src + (size_t)(aq[q] >> 1) * D.dense_tiles * kDenseVals + v, D.dense_tiles, kDenseVals);
-        }
-    }
-    __syncthreads();
-    // camera-frame -> model-frame congruence of k's dense pair sums (target frame's pose)
-    for (int e = tid; e < na * 27; e += nthr) {
-        const int q = e / 27, idx = e % 27;
-        const float *Tt = vT + 16 * ai[q];
-        const float *Sp = dr + q * kDenseVals;
-        float *So = dm + q * kDenseVals;
-        if (idx < 21) {
-            int r = 0, rem = idx;
-            while (rem >= 6 - r) { rem -= 6 - r; r++; }
-            const int c = r + rem;
-            float S[21];
-#pragma unroll
-            for (int k2 = 0; k2 < 21; k2++) S[k2] = Sp[k2];
-            float Mr[6], Mc[6];
-            congruence_row(Tt, r, Mr); congruence_row(Tt, c, Mc);
-            float acc = 0.0f;
-#pragma unroll
-            for (int k2 = 0; k2 < 6; k2++) {
-                float u = 0.0f;
-#pragma unroll
-                for (int l = 0; l < 6; l++) u += S[tri21(k2, l)] * Mc[l];
-                acc += Mr[k2] * u;
-            }
-            So[idx] = acc;
-        } else {
-            const int r = idx - 21;
-            float Mr[6];
-            congruence_row(Tt, r, Mr);
-            float acc = 0.0f;
-#pragma unroll
-            for (int k2 = 0; k2 < 6; k2++) acc += Mr[k2] * Sp[21 + k2];
-            So[21 + r] = acc;
-            if (r == 0) So[27] = Sp[27];
-        }
-    }
-    __syncthreads();
-    if (trace && D.trace_on) {            // each dense pair is recorded once: by its source frame's workgroup (by the target's if the source is frame 0)
-        float *tr = trace + ((size_t)b * D.n_gn + iter) * D.trace_record;
-        for (int e = tid; e < na * kDenseVals; e += nthr) {
-            const int q = e / kDenseVals;
-            const int writer = aj[q] != 0 ? aj[q] : ai[q];
-            if (writer == k) tr[D.tr_dpair + (size_t)(aq[q] >> 1) * kDenseVals + e % kDenseVals] = dm[e];
-        }
-    }
-    // rows 6k .. 6k+5 of A: one (row, column) entry per lane
-    float *Arow = Ag + ((size_t)b * n + 6 * k) * ld;
-    for (int e = tid; e < 6 * ld; e += nthr) {
-        const int r = e / ld, col = e % ld;
-        float v = 0.0f;
-        if (col >= 6 && col < n) {
-            const int m = col / 6, c = col % 6;
-            if (m == k) {
-                if (D.use_sparse)
-                    for (int m2 = 0; m2 < N; m2++)
-                        if (m2 != k) v += D.w_sparse * sparse_diag_entry(sp + m2 * kSparseVals, k < m2 ? 0 : 1, r, c);
-                if (D.use_dense) { const int t21 = tri21(r, c); for (int q = 0; q < na; q++) v += dm[q * kDenseVals + t21]; }
-            } else {
-                // block (k, m) = -(w_s J_k^T J_m + S_dense); the moment record is stored for (i, j) = (min, max)
-                if (D.use_sparse) v -= D.w_sparse * (k < m ? sparse_cross_entry(sp + m * kSparseVals, r, c) : sparse_cross_entry(sp + m * kSparseVals, c, r));
-                if (D.use_dense) {
-                    const int t21 = tri21(r, c);
-                    for (int q = 0; q < na; q++) {
-                        const int partner = (aq[q] & 1) ? ai[q] : aj[q];
-                        if (partner == m && ai[q] < aj[q]) v -= dm[q * kDenseVals + t21];      // target > source: erased by FlipJtJ
-                    }
-                }
-            }
-        }
-        Arow[(size_t)r * ld + col] = v;
-    }
-    // right-hand side and Jacobi diagonal of frame k
-    if (tid < 6) {
-        const int r = tid;
-        float rhs = 0.0f, md = 0.0f;
-        if (D.use_sparse) {
-            for (int m = 0; m < N; m++) {
-                if (m == k) continue;
-                const float *rec = sp + m * kSparseVals;
-                if (k < m) { rhs += (r < 3) ? -rec[28 + r] : -rec[31 + r - 3]; md += (r < 3) ? rec[37] : rec[38 + r - 3]; }
-                else       { rhs += (r < 3) ? rec[28 + r] : rec[34 + r - 3];   md += (r < 3) ? rec[37] : rec[41 + r - 3]; }
-            }
-            rhs *= D.w_sparse;
-        }
-        if (D.use_dense) {
-            float jtr = 0.0f;
-            for (int q = 0; q < na; q++) { const float g = dm[q * kDenseVals + 21 + r]; jtr += (aq[q] & 1) ? g : -g; }
-            rhs -= jtr;
-        }
-        bg[(size_t)b * ld + 6 * k + r] = rhs;
-        Mg[(size_t)b * ld + 6 * k + r] = (md > kEps) ? 1.0f / md : 1.0f;
-    }
-}
-
-// grid (B) x 256; dynamic LDS: A [6N][ld] + p [ld].  Loads the assembled system, runs the PCG in one wave and the
-// Lie update on N lanes, writes x, T, T^-1 (and the trace).
-__global__ void __launch_bounds__(256) k_pcg_update(SolveDims D, int iter, int ld, const float *__restrict__ Ag, const float *__restrict__ bg, const float *__restrict__ Mg,
-                                                   float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv, float *__restrict__ trace)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    const int N = D.n_frames, n = 6 * N;
-    float *A = lds, *vp = A + (size_t)n * ld, *vd = vp + ld;
-    float *tr = (trace && D.trace_on) ? trace + ((size_t)b * D.n_gn + iter) * D.trace_record : nullptr;
-    {   // coalesced 16-byte copies; frame 0's rows are zero by construction (never written by k_assemble_rows)
-        const float4 *src = reinterpret_cast<const float4 *>(Ag + (size_t)b * n * ld);
-        float4 *dst = reinterpret_cast<float4 *>(A);
-        const int total4 = n * ld / 4, first4 = 6 * ld / 4;
-        for (int e = tid; e < total4; e += nthr) dst[e] = e < first4 ? make_float4(0.f, 0.f, 0.f, 0.f) : src[e];
-        for (int e = tid; e < ld; e += nthr) { vp[e] = 0.0f; vd[e] = 0.0f; }
-    }
-    __syncthreads();
-    if (tr) {
-        for (int e = tid; e < n; e += nthr) {
-            const int k = e / 6, r = e % 6, o = k * 6 + (r < 3 ? r + 3 : r - 3);           // trace order (rot, trans); internal [trans, rot]
-            tr[D.tr_rhs + o] = e >= 6 ? bg[(size_t)b * ld + e] : 0.0f;
-            tr[D.tr_prec + o] = e >= 6 ? Mg[(size_t)b * ld + e] : 0.0f;
-        }
-        for (int e = tid; e < n * n; e += nthr) tr[D.tr_A + e] = A[(e / n) * ld + (e % n)];
-    }
-    if (tid < 64) {
-        constexpr int kMaxRows = 4;
-        const int lane = tid;
-        float r_[kMaxRows], m_[kMaxRows], p_[kMaxRows], d_[kMaxRows];
-        float part = 0.0f;
-#pragma unroll
-        for (int j = 0; j < kMaxRows; j++) {
-            const int row = lane + 64 * j;
-            const bool live = row < n && row >= 6;
-            r_[j] = live ? bg[(size_t)b * ld + row] : 0.0f; m_[j] = live ? Mg[(size_t)b * ld + row] : 0.0f; d_[j] = 0.0f;
-            p_[j] = m_[j] * r_[j];
-            part += r_[j] * p_[j];
-            if (row < n) vp[row] = p_[j];
-        }
-        float rz = wave_sum_all(part);
-        const float4 *a0 = reinterpret_cast<const float4 *>(A + (size_t)min(lane, n - 1) * ld), *a1 = reinterpret_cast<const float4 *>(A + (size_t)min(lane + 64, n - 1) * ld);
-        const float4 *a2 = reinterpret_cast<const float4 *>(A + (size_t)min(lane + 128, n - 1) * ld), *a3 = reinterpret_cast<const float4 *>(A + (size_t)min(lane + 192, n - 1) * ld);
-        const float4 *p4 = reinterpret_cast<const float4 *>(vp);
-        const int nq = ld >> 2;
-        for (int li = 0; li < D.n_pcg; li++) {
-            float ap_[kMaxRows];
-            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0;
-            if (n <= 128) {
-_Pragma("unroll 8")
-                for (int c = 0; c < nq; c++) {
-                    const float4 pc = p4[c], r0 = a0[c], r1 = a1[c];
-                    q0.x += r0.x * pc.x; q0.y += r0.y * pc.y; q0.z += r0.z * pc.z; q0.w += r0.w * pc.w;
-                    q1.x += r1.x * pc.x; q1.y += r1.y * pc.y; q1.z += r1.z * pc.z; q1.w += r1.w * pc.w;
-                }
-            } else {
-_Pragma("unroll 4")
-                for (int c = 0; c < nq; c++) {
-                    const float4 pc = p4[c], r0 = a0[c], r1 = a1[c], r2 = a2[c], r3 = a3[c];
-                    q0.x += r0.x * pc.x; q0.y += r0.y * pc.y; q0.z += r0.z * pc.z; q0.w += r0.w * pc.w;
-                    q1.x += r1.x * pc.x; q1.y += r1.y * pc.y; q1.z += r1.z * pc.z; q1.w += r1.w * pc.w;
-                    q2.x += r2.x * pc.x; q2.y += r2.y * pc.y; q2.z += r2.z * pc.z; q2.w += r2.w * pc.w;
-                    q3.x += r3.x * pc.x; q3.y += r3.y * pc.y; q3.z += r3.z * pc.z; q3.w += r3.w * pc.w;
-                }
-            }
-            ap_[0] = (q0.x + q0.y) + (q0.z + q0.w); ap_[1] = (q1.x + q1.y) + (q1.z + q1.w);
-            ap_[2] = (q2.x + q2.y) + (q2.z + q2.w); ap_[3] = (q3.x + q3.y) + (q3.z + q3.w);
-            part = 0.0f;
-#pragma unroll
-            for (int j = 0; j < kMaxRows; j++) part += (lane + 64 * j < n) ? p_[j] * ap_[j] : 0.0f;
-            const float pAp = wave_sum_all(part);
-            const float alpha = (pAp > kEps) ? rz / pAp : 0.0f;
-            float z_[kMaxRows];
-            part = 0.0f;
-#pragma unroll
-            for (int j = 0; j < kMaxRows; j++) {
-                const bool live = lane + 64 * j < n;
-                d_[j] = d_[j] + alpha * p_[j];
-                r_[j] = r_[j] - alpha * (live ? ap_[j] : 0.0f);
-                z_[j] = m_[j] * r_[j];
-                part += z_[j] * r_[j];
-            }
-            const float rz_new = wave_sum_all(part);
-            const float beta = (rz > kEps) ? rz_new / rz : 0.0f;
-            if (tr && lane == 0) { float *sc = tr + D.tr_pcg + 4 * li; sc[0] = pAp; sc[1] = alpha; sc[2] = rz_new; sc[3] = beta; }
-            rz = rz_new;
-#pragma unroll
-            for (int j = 0; j < kMaxRows; j++) {
-                p_[j] = z_[j] + beta * p_[j];
-                if (lane + 64 * j < n) vp[lane + 64 * j] = p_[j];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kMaxRows; j++) if (lane + 64 * j < n) vd[lane + 64 * j] = d_[j];
-    }
-    __syncthreads();
-    for (int k = tid; k < N; k += nthr) {
-        float *xk = x + 6 * ((size_t)b * N + k);
-        float rot[3] = { xk[0], xk[1], xk[2] }, trans[3] = { xk[3], xk[4], xk[5] };
-        if (k > 0) {
-            const float dW[3] = { vd[6 * k + 3], vd[6 * k + 4], vd[6 * k + 5] }, dT[3] = { vd[6 * k], vd[6 * k + 1], vd[6 * k + 2] };
-            const Mat4 U = pose_to_matrix(dW, dT);
-            const Mat4 C = pose_to_matrix(rot, trans);
-            matrix_to_pose(mat_mul(U, C), rot, trans);
-            xk[0] = rot[0]; xk[1] = rot[1]; xk[2] = rot[2]; xk[3] = trans[0]; xk[4] = trans[1]; xk[5] = trans[2];
-        }
-        const Mat4 E = pose_to_matrix(rot, trans);
-        store_mat4(T + 16 * ((size_t)b * N + k), E);
-        store_mat4(Tinv + 16 * ((size_t)b * N + k), mat_inverse(E));
-        if (tr) {
-            for (int q = 0; q < 3; q++) { tr[D.tr_x + 6 * k + q] = rot[q]; tr[D.tr_x + 6 * k + 3 + q] = trans[q]; }
-            for (int q = 0; q < 16; q++) tr[D.tr_T + 16 * k + q] = E.m[q];
-            for (int q = 0; q < 3; q++) { tr[D.tr_delta + 6 * k + q] = vd[6 * k + 3 + q]; tr[D.tr_delta + 6 * k + 3 + q] = vd[6 * k + q]; }
-        }
-    }
-}
-
-}  // namespace btba

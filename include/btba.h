@@ -67,8 +67,6 @@ enum {
     BTBA_FLAG_DENSE_4WAVE  = 16,  /* tuning: one pixel per trip, registers capped for 4 waves per SIMD (spills) */
     BTBA_FLAG_NO_FUSE      = 64,  /* never launch the sparse and the dense sweep as one interleaved launch */
     BTBA_FLAG_NO_COMPACTION = 512, /* compact cache: always walk all Wd x Hd source pixels */
-    BTBA_FLAG_MONO_SOLVE   = 2048, /* assemble + PCG + update in ONE workgroup per instance (k_system_solve) instead of the split
-                                      k_assemble_rows (N-1 workgroups per instance) + k_pcg_update pair */
     BTBA_FLAG_COMPACTION   = 1024, /* compact cache: walk each source frame's ordered list of pixels that carry a depth (masked scenes).
                                       btba_optimize_frames decides by itself from the valid-pixel counts unless one of the two is set;
                                       btba_solve_batch_zn (asynchronous, no read-back) uses lists only when this flag is set */

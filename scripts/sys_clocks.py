@@ -14,8 +14,7 @@ def main():
     ws = Workspace()
     for B in (1, 32):
         pick = [inst[b % 2] for b in range(B)]
-        from bundletrack_amd import _lib
-        bs = BatchSolver(ws, flags=_lib.FLAG_MONO_SOLVE)
+        bs = BatchSolver(ws)
         corr, offs, mx = bs.pack_correspondences([p["corr"] for p in pick], 15)
         cam_d = torch.from_numpy(np.stack([p["campos"] for p in pick])).to(dev); nrm_d = torch.from_numpy(np.stack([p["normals"] for p in pick])).to(dev)
         corr_d = torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(dev); offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
