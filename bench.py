@@ -106,8 +106,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
+    local_dev = local % torch.cuda.device_count()        # == local on a real node; lets a functional test run 2 ranks on 1 GPU
+    torch.cuda.set_device(local_dev)
+    dev = torch.device(f"cuda:{local_dev}")
     cfg = CONFIGS[args.config]
     B, K = args.instances, cfg["K"]
 
@@ -162,7 +163,9 @@ def main():
     assert np.isfinite(out_poses).all(), "non-finite poses"
 
     gn_iters = float(B * bs.params.n_gn_iters * args.steps)
-    per_rank = sharding.gather_throughput(seconds, gn_iters, device=dev if world > 1 else "cpu")
+    import torch.distributed as dist
+    gather_dev = dev if (world > 1 and dist.get_backend() == "nccl") else "cpu"
+    per_rank = sharding.gather_throughput(seconds, gn_iters, device=gather_dev)
     value, slowest = sharding.aggregate(per_rank)
 
     if rank == 0:

@@ -32,9 +32,9 @@ def init_from_env(backend: str | None = None):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                backend = os.environ.get("BTBA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
-                torch.cuda.set_device(local)
+                torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -42,7 +42,7 @@ def init_from_env(backend: str | None = None):
 def barrier(device=None):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        if device is not None and str(device).startswith("cuda"):
+        if device is not None and str(device).startswith("cuda") and dist.get_backend() == "nccl":
             dist.barrier(device_ids=[int(str(device).split(":")[1])] if ":" in str(device) else None)
         else:
             dist.barrier()
