@@ -97,11 +97,12 @@ def lib() -> C.CDLL:
     """Load libbtba.so; raises if it has not been built (no fallback)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("BTBA_LIB_PATH", LIB_PATH)      # developer A/B of kernel builds; still no fallback
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                f"{path} is missing: the HIP extension has not been built. "
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         L.btba_strerror.restype = C.c_char_p
         L.btba_strerror.argtypes = [C.c_int]
         for name in EXPORTED_SYMBOLS:

@@ -399,6 +399,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         HIP_TRY(hipStreamWaitEvent(ws->aux_stream, ws->ev_fork, 0));
     }
     const size_t pairsum_floats = lds_pairs / sizeof(float);
+    const size_t lut_bytes = sizeof(float) * (size_t)(Wd + Hd);         // coordinate look-up tables of the compact dense sweep
     for (int it = 0; it < prm->n_gn_iters; it++) {
         for (int h = 0; h < n_halves; h++) {
             const Half &H = halves[h];
@@ -426,10 +427,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
 #define BTBA_FUSED_ARGS(CACHE) D, n_d, n_s, CACHE, reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, corr_h, off_h, sp_h, vl_h, vc_h
                 const int lay = zn_layout ? zn_layout + (compaction ? 2 : 0) : 0;
                 if (lay == 0) k_fused_sweeps<0><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(reinterpret_cast<const float4 *>(campos_h)));
-                else if (lay == 1) k_fused_sweeps<1><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
-                else if (lay == 2) k_fused_sweeps<2><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
-                else if (lay == 3) k_fused_sweeps<3><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
-                else k_fused_sweeps<4><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(zn_h));
+                else if (lay == 1) k_fused_sweeps<1><<<dim3(n_d + n_s), kBlock, lut_bytes, H.st>>>(BTBA_FUSED_ARGS(zn_h));
+                else if (lay == 2) k_fused_sweeps<2><<<dim3(n_d + n_s), kBlock, lut_bytes, H.st>>>(BTBA_FUSED_ARGS(zn_h));
+                else if (lay == 3) k_fused_sweeps<3><<<dim3(n_d + n_s), kBlock, lut_bytes, H.st>>>(BTBA_FUSED_ARGS(zn_h));
+                else k_fused_sweeps<4><<<dim3(n_d + n_s), kBlock, lut_bytes, H.st>>>(BTBA_FUSED_ARGS(zn_h));
 #undef BTBA_FUSED_ARGS
                 if ((rc = time_end(ws, slot, H.st))) return rc;
                 S.fused_sweeps = 1;
@@ -443,10 +444,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                     if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
                     const dim3 dgrid(n_d);
 #define BTBA_DENSE_ARGS D, reinterpret_cast<const float4 *>(campos_h), reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h
-                    if (zn_layout == 1 && !compaction) k_dense_sweep_zn<true, false><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
-                    else if (zn_layout == 2 && !compaction) k_dense_sweep_zn<false, false><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
-                    else if (zn_layout == 1) k_dense_sweep_zn<true, true><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
-                    else if (zn_layout == 2) k_dense_sweep_zn<false, true><<<dgrid, kBlock, 0, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    if (zn_layout == 1 && !compaction) k_dense_sweep_zn<true, false><<<dgrid, kBlock, lut_bytes, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    else if (zn_layout == 2 && !compaction) k_dense_sweep_zn<false, false><<<dgrid, kBlock, lut_bytes, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    else if (zn_layout == 1) k_dense_sweep_zn<true, true><<<dgrid, kBlock, lut_bytes, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    else if (zn_layout == 2) k_dense_sweep_zn<false, true><<<dgrid, kBlock, lut_bytes, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
                     else if (prm->flags & BTBA_FLAG_DENSE_2PIX) k_dense_sweep<2, 2><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
                     else if (prm->flags & BTBA_FLAG_DENSE_4WAVE) k_dense_sweep<1, 4><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
                     else k_dense_sweep<1, 3><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);

@@ -169,11 +169,14 @@ __global__ void __launch_bounds__(kBlock) k_build_cache(int W, int H, int Wd, in
 // operations (no contraction) where it is consumed gives bit-identical camera-space points while halving the
 // bytes and the load instructions of the dense sweep (one 16-byte load per tap instead of two).
 template <bool SIMPLE>
-__device__ __forceinline__ float3 zn_backproject(const float *ki, unsigned xi, unsigned yi, float d)
+__device__ __forceinline__ float3 zn_backproject(const float *ki, float fxi, float fyi, float d)
 {
 #pragma clang fp contract(off)
-    if (!((double)d >= 0.1)) return make_float3(0.f, 0.f, 0.f);
-    const float vx = (float)xi * d, vy = (float)yi * d;
+    // fxi, fyi = (float) of the full-res pixel the cache pixel was resampled from (LDS look-up tables).
+    // (double)d >= 0.1  <=>  d >= 0.1f  (0.1f is the smallest float above 0.1); below it the reference stores zeros,
+    // and with d := 0 every product below is an exact zero as well, so one select replaces three.
+    d = (d >= 0.1f) ? d : 0.0f;
+    const float vx = fxi * d, vy = fyi * d;
     if (SIMPLE)   // the zero terms of the general form add exact zeros
         return make_float3(ki[0] * vx + ki[2] * d, ki[5] * vy + ki[6] * d, ki[15] * d);
     return make_float3(ki[0] * vx + ki[1] * vy + ki[2] * d + ki[3] * d, ki[4] * vx + ki[5] * vy + ki[6] * d + ki[7] * d,
@@ -498,8 +501,14 @@ template <bool SIMPLE, bool LISTS>
 __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
                                                const float *__restrict__ T, const float *__restrict__ Tinv,
                                                float *__restrict__ partials, int tile, int p, int b, float *red,
-                                               const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts)
+                                               const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts, float *lut)
 {
+    // lut[0 .. Wd) = (float) full-res column of cache column x, lut[Wd .. Wd+Hd) the same for rows: five VALU
+    // instructions (int->float, mul, add, float->uint, uint->float) per coordinate become one LDS read
+    for (int e = (int)threadIdx.x; e < D.width + D.height; e += kBlock)
+        lut[e] = (float)(e < D.width ? zn_src_coord(e, D.zn_scale_w) : zn_src_coord(e - D.width, D.zn_scale_h));
+    __syncthreads();
+    const float *lut_x = lut, *lut_y = lut + D.width;
     const int2 ij = dense_pairs[p];
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
@@ -544,12 +553,11 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
             py += ((py + 1) * D.width <= s) ? 1 : 0;
             px = s - py * D.width;
         }
-        const float3 cp = zn_backproject<SIMPLE>(D.zn_ki, zn_src_coord(px, D.zn_scale_w), zn_src_coord(py, D.zn_scale_h), zs.x);
+        const float3 cp = zn_backproject<SIMPLE>(D.zn_ki, lut_x[px], lut_y[py], zs.x);
         const PixelGeom g = pixel_geom(C, make_float4(cp.x, cp.y, cp.z, 1.0f), make_float4(zs.y, zs.z, zs.w, 0.0f));
         if (__builtin_amdgcn_ballot_w64(g.valid) == 0ull) continue;
         const float4 z00 = zn_t[g.i00], z10 = zn_t[g.i10], z01 = zn_t[g.i01], z11 = zn_t[g.i11];
-        const unsigned xia = zn_src_coord(g.xa, D.zn_scale_w), xib = zn_src_coord(g.xb, D.zn_scale_w);
-        const unsigned yia = zn_src_coord(g.ya, D.zn_scale_h), yib = zn_src_coord(g.yb, D.zn_scale_h);
+        const float xia = lut_x[g.xa], xib = lut_x[g.xb], yia = lut_y[g.ya], yib = lut_y[g.yb];
         const float3 c00 = zn_backproject<SIMPLE>(D.zn_ki, xia, yia, z00.x), c10 = zn_backproject<SIMPLE>(D.zn_ki, xib, yia, z10.x);
         const float3 c01 = zn_backproject<SIMPLE>(D.zn_ki, xia, yib, z01.x), c11 = zn_backproject<SIMPLE>(D.zn_ki, xib, yib, z11.x);
         pixel_accumulate(C, g, make_float4(c00.x, c00.y, c00.z, 1.f), make_float4(c10.x, c10.y, c10.z, 1.f), make_float4(c01.x, c01.y, c01.z, 1.f), make_float4(c11.x, c11.y, c11.z, 1.f),
@@ -560,16 +568,17 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
 }
 
 template <bool SIMPLE, bool LISTS>
-__global__ void __launch_bounds__(kBlock, 3) k_dense_sweep_zn(SolveDims D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
+__global__ void __launch_bounds__(kBlock, 5) k_dense_sweep_zn(SolveDims D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
                                                              const float *__restrict__ T, const float *__restrict__ Tinv, float *__restrict__ partials,
                                                              const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts)
 {
     __shared__ float red[4 * kDenseVals];
+    extern __shared__ __attribute__((aligned(16))) float zn_lut[];        // (Wd + Hd) floats
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = (int)(L % (unsigned)D.dense_tiles);
     const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
     const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
-    dense_block_zn<SIMPLE, LISTS>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts);
+    dense_block_zn<SIMPLE, LISTS>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
 }
 
 // 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).
@@ -599,6 +608,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused_sweeps(SolveDims D, unsigne
                                                            const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts)
 {
     __shared__ float red[4 * kSparseVals];
+    extern __shared__ __attribute__((aligned(16))) float zn_lut[];        // (Wd + Hd) floats, compact layouts only
     const unsigned G = n_d + n_s, g = blockIdx.x, xcd = g & 7u, slot = g >> 3;
     const unsigned qd = n_d >> 3, rd = n_d & 7u;
     const unsigned Gx = (G - xcd + 7u) >> 3, ndx = qd + (xcd < rd ? 1u : 0u), nsx = Gx - ndx;
@@ -620,10 +630,10 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused_sweeps(SolveDims D, unsigne
         const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
         const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
         if (LAYOUT == 0) dense_block<1>(D, campos, normals, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
-        else if (LAYOUT == 1) dense_block_zn<true, false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts);     // `campos` carries the compact cache
-        else if (LAYOUT == 2) dense_block_zn<false, false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts);
-        else if (LAYOUT == 3) dense_block_zn<true, true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts);
-        else dense_block_zn<false, true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts);
+        else if (LAYOUT == 1) dense_block_zn<true, false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);     // `campos` carries the compact cache
+        else if (LAYOUT == 2) dense_block_zn<false, false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+        else if (LAYOUT == 3) dense_block_zn<true, true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+        else dense_block_zn<false, true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
     }
 }
 
