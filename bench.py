@@ -121,6 +121,7 @@ def main():
     bs = BatchSolver(ws, weight_dense_depth=cfg["w_dense"])
     if not args.no_kernel_timing:
         bs.params.flags |= _lib.FLAG_TIME_KERNELS
+    bs.params.flags |= int(os.environ.get("BTBA_BENCH_FLAGS", "0"))          # developer A/B of tuning flags
     if args.masked and not args.float4_cache:
         bs.params.flags |= _lib.FLAG_COMPACTION         # workload hint: masked frames -> walk valid-pixel lists (optimize_frames decides this by itself)
     corr, offs, mx = bs.pack_correspondences([p["corr"] for p in pick], K)

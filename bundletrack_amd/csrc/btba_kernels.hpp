@@ -514,6 +514,9 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
     const size_t fb = (size_t)b * D.n_frames;
     DenseCtx C;
     C.Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), load_mat4(T + 16 * (fb + fj)));
+    // the relative pose is the same in every lane: keep it in scalar registers (12 VGPRs back)
+#pragma unroll
+    for (int e = 0; e < 12; e++) C.Tij.m[e] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, C.Tij.m[e])));
     C.cam_t = nullptr; C.nrm_t = nullptr;
     C.fx = D.fx; C.fy = D.fy; C.cx = D.cx; C.cy = D.cy; C.depth_min = D.depth_min; C.depth_max = D.depth_max;
     C.normal_thresh = D.normal_thresh; C.dist2_thresh = D.dist_thresh * D.dist_thresh;
