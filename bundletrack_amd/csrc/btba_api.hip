@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <memory>
 #include <vector>
 
 #include "../../include/btba.h"
@@ -181,26 +182,47 @@ void btba_trace_layout_get(int n_frames, int n_dense_pairs, int n_pcg_iters, btb
     L->record_floats = o;
 }
 
-int btba_bucket_correspondences(const btba_entryj *in, uint32_t n, int n_frames, btba_entryj *out_sorted, uint32_t *out_offsets)
+static inline int pair_index(int n_frames, uint32_t i, uint32_t j) { return (int)(i * n_frames - i * (i + 1) / 2 + (j - i - 1)); }
+
+// One validating pass: per-pair counts -> offsets, and whether the input is already pair-major with nothing to drop
+// (the only order Bundler::optimizeGPU produces, Bundler.cpp:298-323) so that callers can skip the scatter.
+static int count_correspondences(const btba_entryj *in, uint32_t n, int n_frames, uint32_t *out_offsets, bool *already_bucketed)
 {
-    if ((!in && n) || n_frames < 2 || !out_sorted || !out_offsets) return BTBA_EINVAL;
     const int P = n_frames * (n_frames - 1) / 2;
     std::vector<uint32_t> cnt(P + 1, 0);
-    auto pidx = [n_frames](uint32_t i, uint32_t j) { return (int)(i * n_frames - i * (i + 1) / 2 + (j - i - 1)); };
+    bool ordered = true;
+    int prev = 0;
     for (uint32_t e = 0; e < n; e++) {
         const btba_entryj &c = in[e];
-        if (c.imgIdx_i == 0xFFFFFFFFu) continue;
+        if (c.imgIdx_i == 0xFFFFFFFFu) { ordered = false; continue; }
         if (c.imgIdx_i >= (uint32_t)n_frames || c.imgIdx_j >= (uint32_t)n_frames || c.imgIdx_i >= c.imgIdx_j) return BTBA_EINVAL;
-        cnt[pidx(c.imgIdx_i, c.imgIdx_j) + 1]++;
+        const int p = pair_index(n_frames, c.imgIdx_i, c.imgIdx_j);
+        ordered = ordered && (p >= prev);
+        prev = p;
+        cnt[p + 1]++;
     }
     out_offsets[0] = 0;
     for (int p = 0; p < P; p++) out_offsets[p + 1] = out_offsets[p] + cnt[p + 1];
-    std::vector<uint32_t> cur(out_offsets, out_offsets + P);
+    if (already_bucketed) *already_bucketed = ordered;
+    return BTBA_OK;
+}
+
+static void scatter_correspondences(const btba_entryj *in, uint32_t n, int n_frames, const uint32_t *offsets, btba_entryj *out_sorted)
+{
+    const int P = n_frames * (n_frames - 1) / 2;
+    std::vector<uint32_t> cur(offsets, offsets + P);
     for (uint32_t e = 0; e < n; e++) {                       // stable: keeps the caller's order inside a pair
         const btba_entryj &c = in[e];
         if (c.imgIdx_i == 0xFFFFFFFFu) continue;
-        out_sorted[cur[pidx(c.imgIdx_i, c.imgIdx_j)]++] = c;
+        out_sorted[cur[pair_index(n_frames, c.imgIdx_i, c.imgIdx_j)]++] = c;
     }
+}
+
+int btba_bucket_correspondences(const btba_entryj *in, uint32_t n, int n_frames, btba_entryj *out_sorted, uint32_t *out_offsets)
+{
+    if ((!in && n) || n_frames < 2 || !out_sorted || !out_offsets) return BTBA_EINVAL;
+    if (int rc = count_correspondences(in, n, n_frames, out_offsets, nullptr)) return rc;
+    scatter_correspondences(in, n, n_frames, out_offsets, out_sorted);
     return BTBA_OK;
 }
 
@@ -600,10 +622,17 @@ int btba_optimize_frames(btba_workspace *ws_in, const btba_params *params_in, in
     const int npix = Wd * Hd;
 
     // A0/A6: bucket by frame pair (a pair-major input, the only order Bundler::optimizeGPU produces, passes through)
-    std::vector<btba_entryj> sorted(n_corres ? n_corres : 1);
     std::vector<uint32_t> offsets(P + 1, 0);
-    if ((rc = btba_bucket_correspondences(corres_host, n_corres, N, sorted.data(), offsets.data()))) return finish(rc);
+    bool bucketed = false;
+    if ((rc = count_correspondences(corres_host, n_corres, N, offsets.data(), &bucketed))) return finish(rc);
     const uint32_t kept = offsets[P];
+    std::unique_ptr<btba_entryj[]> scattered;                 // only when the caller's order is not pair-major already
+    const btba_entryj *upload = corres_host;
+    if (!bucketed && kept) {
+        scattered.reset(new btba_entryj[kept]);
+        scatter_correspondences(corres_host, n_corres, N, offsets.data(), scattered.get());
+        upload = scattered.get();
+    }
     uint32_t max_per_pair = 0;
     for (int p = 0; p < P; p++) max_per_pair = std::max(max_per_pair, offsets[p + 1] - offsets[p]);
 
@@ -616,10 +645,11 @@ int btba_optimize_frames(btba_workspace *ws_in, const btba_params *params_in, in
     if ((rc = ws->nvalid.ensure(sizeof(int32_t) * N))) return finish(rc);
     auto hip_fail = [&](hipError_t e) { g_last_hip_error = (int)e; return finish(BTBA_EHIP); };
     hipError_t e;
-    if (kept && (e = hipMemcpyAsync(ws->corr.p, sorted.data(), sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
+    if (kept && (e = hipMemcpyAsync(ws->corr.p, upload, sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
     if ((e = hipMemcpyAsync(ws->offsets.p, offsets.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
     if ((e = hipMemcpyAsync(ws->poses.p, poses, sizeof(float) * 16 * N, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
-    if ((e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
+    // pageable sources are staged by the runtime before hipMemcpyAsync returns; the sync only serves the upload timer
+    if ((prm.flags & BTBA_FLAG_TIME_KERNELS) && (e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
     const auto tu1 = std::chrono::steady_clock::now();
 
     float intr[4];

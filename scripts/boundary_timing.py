@@ -1,0 +1,42 @@
+"""PCIe-inclusive cost of the drop-in boundary (btba_optimize_frames: host EntryJ[] + host poses in, host poses out,
+K borrowed full-resolution device depth/normal maps) at tracker-like sizes.  GPU box only.
+    python scripts/boundary_timing.py > gpurun_out/boundary_timing.json"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bundletrack_amd import _lib, synthetic as S
+from bundletrack_amd.optimizer import OptimizerGpu, Workspace
+
+
+def main():
+    dev = torch.device("cuda:0")
+    ws = Workspace()
+    rows = []
+    for (K, m, bg) in ((5, 300, False), (10, 1000, False), (15, 2000, False), (15, 2000, True)):
+        pb = S.make_problem(K, m, seed=S.config_seed(3, 0) + K, background=bg)          # 640x480 frames
+        depths = [torch.from_numpy(pb.depth[k]).to(dev) for k in range(K)]
+        normals = [torch.from_numpy(pb.normals[k]).to(dev) for k in range(K)]
+        opt = OptimizerGpu(workspace=ws)
+        walls = []
+        for timed in (False, True):
+            if timed: opt.params.flags |= _lib.FLAG_TIME_KERNELS
+            for rep in range(25):
+                poses = pb.poses_init.copy()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                opt.optimizeFrames(pb.corr, pb.n_match_per_pair, K, pb.H, pb.W, depths, None, normals, poses, pb.K)
+                dt = time.perf_counter() - t0
+                if not timed and rep >= 5: walls.append(dt)
+        st = opt.last_stats
+        walls = np.array(walls) * 1e3
+        err = max(max(S.pose_error(poses[k], pb.poses_gt[k])) for k in range(K))
+        rows.append(dict(K=K, corr_per_pair=m, n_corr=int(len(pb.corr)), frame="%dx%d" % (pb.W, pb.H), valid_fraction=round(float((pb.depth >= 0.1).mean()), 4),
+                         wall_ms_median=round(float(np.median(walls)), 4), wall_ms_min=round(float(walls.min()), 4),
+                         gn_iters_per_s=round(7e3 / float(np.median(walls)), 1),
+                         stats_ms={k: round(float(v), 4) for k, v in st.items() if k.startswith("ms_")},
+                         entryj_bytes=int(len(pb.corr)) * 32, err_vs_gt=float(err)))
+        print(json.dumps(rows[-1]), flush=True)
+
+
+if __name__ == "__main__":
+    main()
