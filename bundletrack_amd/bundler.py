@@ -133,3 +133,150 @@ def marshal_window(local_frames, matches, newframe, min_fm_edges_newframe: int =
     if not run:
         newframe.status = "NO_BA"
     return Window(frames=frames, corr=corr, n_match_per_pair=np.asarray(counts, np.int32), n_edges_newframe=n_edges, run_ba=run)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The rest of Bundler's BA-facing slice: Kabsch initialisation, the per-frame driver, the pose-file format.
+# Feature detection / matching / RANSAC (LF-Net, SiftGPU, cuda_ransac) stay behind `feature_manager`.
+# ---------------------------------------------------------------------------------------------------------
+
+def solve_rigid_transform_between_points(points1: np.ndarray, points2: np.ndarray) -> np.ndarray:
+    """Utils::solveRigidTransformBetweenPoints (src/Utils.cpp:180-214): Kabsch, points1 -> points2, fp32.
+    Identity when V U^T is not orthonormal or the result is not finite; a reflection flips V's last column."""
+    p1 = np.asarray(points1, np.float32).reshape(-1, 3)
+    p2 = np.asarray(points2, np.float32).reshape(-1, 3)
+    pose = np.eye(4, dtype=np.float32)
+    if p1.shape[0] < 3 or p1.shape != p2.shape:
+        return pose
+    m1, m2 = p1.mean(0, dtype=np.float32), p2.mean(0, dtype=np.float32)
+    S = (p1 - m1).T @ (p2 - m2)
+    if not np.isfinite(S).all():            # Eigen's JacobiSVD would return NaNs and the isApprox test below would fail
+        return pose
+    U, _, Vt = np.linalg.svd(S.astype(np.float32))
+    V = Vt.T
+    R = V @ U.T
+    if not np.allclose(R.T @ R, np.eye(3, dtype=np.float32), rtol=1e-5, atol=1e-5):       # Eigen isApprox, float precision
+        return pose
+    if np.linalg.det(R) < 0:
+        V = V.copy()
+        V[:, 2] = -V[:, 2]
+        R = V @ U.T
+    pose[:3, :3] = R
+    pose[:3, 3] = m2 - R @ m1
+    if not np.isfinite(pose).all():
+        return np.eye(4, dtype=np.float32)
+    return pose
+
+
+def format_pose_txt(ob_in_cam: np.ndarray) -> str:
+    """`ff << std::setprecision(10) << ob_in_cam << std::endl` (Bundler.cpp:372-377) with Eigen's default
+    IOFormat: coefficients in %.10g, every column padded to the widest coefficient, single-space separator."""
+    M = np.asarray(ob_in_cam, np.float32).reshape(4, 4)
+    cells = [[format(float(v), ".10g") for v in row] for row in M]
+    width = max(len(c) for row in cells for c in row)
+    return "\n".join(" ".join(c.rjust(width) for c in row) for row in cells) + "\n"
+
+
+def save_pose_txt(path: str, pose_in_model: np.ndarray) -> None:
+    """saveNewframeResult's pose file: poses/<id_str>.txt holds ob_in_cam = inverse(camera -> model)."""
+    ob_in_cam = np.linalg.inv(np.asarray(pose_in_model, np.float32)).astype(np.float32)
+    with open(path, "w") as f:
+        f.write(format_pose_txt(ob_in_cam))
+
+
+def load_pose_txt(path: str) -> np.ndarray:
+    """What scripts/eval_ycbineoat.py:124-144 does with the file (np.loadtxt -> 4x4)."""
+    return np.loadtxt(path).reshape(4, 4)
+
+
+class Bundler:
+    """Bundler::processNewFrame (src/Bundler.cpp:52-183) from the point where a frame has a mask and features:
+    pose initialisation from the previous frame, sliding window, keyframe subset, bundle adjustment through
+    an injected `optimizer` (anything with OptimizerGpu.optimizeFrames' signature) and keyframe insertion.
+
+    feature_manager must offer (the slice of SiftManager the caller uses):
+        find_corres(frameA, frameB)        -> None; fills matches[(frameA.id, frameB.id)] = (ptA_cam, ptB_cam), A newer
+        matches                            -> dict as above
+        procrustes_by_correspondence(frameA, frameB) -> 4x4 model-frame offset (FeatureManager.cpp:523-556)
+        forget_frame(frame)                -> None
+    """
+
+    def __init__(self, optimizer, feature_manager, K, H, W, *, window_size=5, max_BA_frames=15, min_rot_deg=10.0,
+                 min_feat_num=0, min_fm_edges_newframe=5, pose_dir=None):
+        self.opt, self.fm = optimizer, feature_manager
+        self.K, self.H, self.W = np.asarray(K, np.float32), int(H), int(W)
+        self.window_size = int(window_size)                        # bundle.window_size
+        self.min_fm_edges_newframe = int(min_fm_edges_newframe)    # bundle.min_fm_edges_newframe
+        self.memory = KeyframeMemory(min_rot_deg=min_rot_deg, min_feat_num=min_feat_num, max_BA_frames=max_BA_frames)
+        self.frames: list = []                                     # _frames (deque)
+        self.local_frames: list = []
+        self.newframe = None
+        self.need_reinit = False
+        self.pose_dir = pose_dir
+        self.n_ba_calls = 0
+        self.last_window = None
+
+    @property
+    def keyframes(self):
+        return self.memory.keyframes
+
+    def process_new_frame(self, frame: FrameRef) -> None:
+        self.newframe = frame
+        last = self.frames[-1] if self.frames else None
+        if last is not None:
+            frame.id = last.id + 1
+            frame.pose_in_model = np.array(last.pose_in_model, np.float32)             # :78-79
+        if frame.status == "FAIL":
+            self.fm.forget_frame(frame)
+            self.need_reinit = True
+            return
+        if last is not None:
+            self.fm.find_corres(frame, last)                                           # :122
+            if frame.status == "FAIL":
+                self.need_reinit = True
+                self.fm.forget_frame(frame)
+                return
+            offset = self.fm.procrustes_by_correspondence(frame, last)                 # :134-136
+            frame.pose_in_model = (np.asarray(offset, np.float32) @ frame.pose_in_model).astype(np.float32)
+        if len(self.frames) >= self.window_size + 3:                                   # :150-158
+            if self.frames[0] not in self.keyframes:
+                self.fm.forget_frame(self.frames[0])
+            self.frames.pop(0)
+        self.frames.append(frame)
+        if frame.id == 0:
+            self.memory.check_and_add_keyframe(frame)
+            return
+        self.local_frames = self.memory.select_keyframes_for_ba(frame)                 # :168
+        self.optimize_gpu()                                                            # :169
+        if frame.status == "FAIL":
+            self.fm.forget_frame(frame)
+            self.frames.pop()
+            self.need_reinit = True
+            return
+        self.memory.check_and_add_keyframe(frame)
+        if self.pose_dir is not None:
+            self.save_newframe_result()
+
+    def optimize_gpu(self) -> None:
+        """Bundler::optimizeGPU (:279-359): match every pair of the window, marshal, gate, optimise, write back."""
+        frames = sorted(self.local_frames, key=lambda f: f.id)
+        for i in range(len(frames)):
+            for j in range(i + 1, len(frames)):
+                self.fm.find_corres(frames[j], frames[i])
+        win = marshal_window(frames, self.fm.matches, self.newframe, self.min_fm_edges_newframe)
+        self.last_window = win
+        if not win.run_ba:
+            return
+        poses = np.stack([np.asarray(f.pose_in_model, np.float32) for f in win.frames])
+        self.opt.optimizeFrames(win.corr, win.n_match_per_pair, len(win.frames), self.H, self.W,
+                                [f.depth_gpu for f in win.frames], [f.color_gpu for f in win.frames],
+                                [f.normal_gpu for f in win.frames], poses, self.K)
+        self.n_ba_calls += 1
+        for f, T in zip(win.frames, poses):
+            f.pose_in_model = np.array(T, np.float32)
+
+    def save_newframe_result(self) -> None:
+        import os
+        os.makedirs(self.pose_dir, exist_ok=True)
+        name = getattr(self.newframe, "id_str", None) or "%04d" % self.newframe.id
+        save_pose_txt(os.path.join(self.pose_dir, name + ".txt"), self.newframe.pose_in_model)

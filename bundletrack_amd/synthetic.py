@@ -258,3 +258,91 @@ def analytic_cache(pb: Problem):
     intr = np.array([fx * (np.float32(Wd) / np.float32(pb.W)), fy * (np.float32(Hd) / np.float32(pb.H)),
                      cx * (np.float32(Wd - 1) / np.float32(pb.W - 1)), cy * (np.float32(Hd - 1) / np.float32(pb.H - 1))], np.float32)
     return campos, pb.cache_normals.astype(np.float32), intr
+
+
+# ---------------------------------------------------------------------------------------------------------
+# A synthetic tracking SEQUENCE: frames on an orbit handed one by one to
+# bundler.Bundler, with a stand-in for the feature front end (LF-Net / matching / RANSAC are out of scope).
+# ---------------------------------------------------------------------------------------------------------
+
+class SyntheticSequence:
+    """`n_frames` views of the ellipsoid on an orbit (`step_deg` per frame), rendered on demand."""
+
+    def __init__(self, n_frames: int = 60, seed: int = 2234, *, step_deg=(5.5, 6.5), background: bool = False,
+                 H: int = 480, W: int = 640, K: np.ndarray | None = None):
+        rng = np.random.default_rng(seed)
+        self.seed, self.n_frames, self.H, self.W, self.background = seed, n_frames, H, W, background
+        self.K = (NOCS_K if K is None else np.asarray(K, np.float64))
+        steps = np.deg2rad(rng.uniform(step_deg[0], step_deg[1], size=n_frames - 1))
+        self.poses_gt = np.stack([orbit_pose(a) for a in np.concatenate([[0.0], np.cumsum(steps)])])   # camera -> model
+        self._ys, self._xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+
+    def render(self, k: int):
+        """(depth [H,W] f32, normals [H,W,4] f32) of frame k, masked to the object unless `background`."""
+        return render(self.poses_gt[k], self.K, self._xs, self._ys, self.background)
+
+
+class SyntheticFeatureManager:
+    """Stand-in for the slice of SiftManager that Bundler calls (FeatureManager.h:86-130): matches are surface
+    points seen by both frames, expressed in each camera frame (+ N(0, noise_m), `outlier_frac` displaced 2-5 cm),
+    deterministic per frame pair.  `procrustes_by_correspondence` is the reference's Kabsch on the matches moved
+    into the model frame with the frames' CURRENT poses (FeatureManager.cpp:523-556); the outliers the reference
+    would have pruned by RANSAC beforehand are pruned here with one residual gate."""
+
+    def __init__(self, seq: SyntheticSequence, corr_per_pair: int = 300, *, noise_m: float = 0.001, outlier_frac: float = 0.05,
+                 inlier_dist: float = 0.01):
+        self.seq, self.m, self.noise_m, self.outlier_frac, self.inlier_dist = seq, corr_per_pair, noise_m, outlier_frac, inlier_dist
+        self.matches: dict = {}
+        self._inv = np.linalg.inv(seq.poses_gt)
+        self.gt_index: dict = {}          # frame id -> index into the sequence (ids are re-assigned by Bundler)
+
+    def register(self, frame, seq_index: int) -> None:
+        self.gt_index[id(frame)] = seq_index
+
+    def _gt(self, frame) -> int:
+        return self.gt_index[id(frame)]
+
+    def forget_frame(self, frame) -> None:
+        for key in [k for k in self.matches if frame.id in k]:
+            del self.matches[key]
+
+    def find_corres(self, frameA, frameB) -> None:
+        key = (frameA.id, frameB.id)
+        if key in self.matches:
+            return
+        a, b = self._gt(frameA), self._gt(frameB)
+        rng = np.random.default_rng([self.seq.seed, a, b])
+        ca, cb = self.seq.poses_gt[a][:3, 3], self.seq.poses_gt[b][:3, 3]
+        pts = np.zeros((0, 3))
+        for _ in range(6):
+            cand, nrm = _sample_surface(rng, max(4 * self.m, 2048))
+            vis = (((ca - cand) * nrm).sum(1) > 0.02) & (((cb - cand) * nrm).sum(1) > 0.02)
+            pts = np.concatenate([pts, cand[vis]])
+            if pts.shape[0] >= self.m:
+                break
+        pts = pts[: self.m]
+        n = pts.shape[0]
+        pa = pts @ self._inv[a, :3, :3].T + self._inv[a, :3, 3] + rng.normal(scale=self.noise_m, size=(n, 3))
+        pb = pts @ self._inv[b, :3, :3].T + self._inv[b, :3, 3] + rng.normal(scale=self.noise_m, size=(n, 3))
+        n_out = int(round(self.outlier_frac * n))
+        if n_out:
+            idx = rng.choice(n, n_out, replace=False)
+            dirs = rng.normal(size=(n_out, 3))
+            dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+            pa[idx] += dirs * rng.uniform(0.02, 0.05, size=(n_out, 1))
+        self.matches[key] = (pa.astype(np.float32), pb.astype(np.float32))
+
+    def procrustes_by_correspondence(self, frameA, frameB) -> np.ndarray:
+        from .bundler import solve_rigid_transform_between_points
+        ptA, ptB = self.matches.get((frameA.id, frameB.id), (np.zeros((0, 3), np.float32),) * 2)
+        if len(ptA) < 5:
+            return np.eye(4, dtype=np.float32)
+        Ta, Tb = np.asarray(frameA.pose_in_model, np.float32), np.asarray(frameB.pose_in_model, np.float32)
+        src = ptA @ Ta[:3, :3].T + Ta[:3, 3]
+        dst = ptB @ Tb[:3, :3].T + Tb[:3, 3]
+        pose = solve_rigid_transform_between_points(src, dst)
+        res = np.linalg.norm(src @ pose[:3, :3].T + pose[:3, 3] - dst, axis=1)
+        keep = res < self.inlier_dist
+        if 5 <= keep.sum() < len(keep):
+            pose = solve_rigid_transform_between_points(src[keep], dst[keep])
+        return pose

@@ -1,0 +1,101 @@
+"""a sliding K=5 window over a synthetic orbit, ~300 correspondences per pair,
+driven frame by frame through bundler.Bundler (processNewFrame -> selectKeyFramesForBA -> optimizeGPU ->
+checkAndAddKeyframe, src/Bundler.cpp:52-359).  CPU: the oracle is the optimiser.  GPU: the HIP path is, with
+the oracle run beside it on identical inputs at every call."""
+import os
+
+import numpy as np
+import pytest
+
+from bundletrack_amd import synthetic as S
+from bundletrack_amd.bundler import Bundler, FrameRef, format_pose_txt, load_pose_txt, solve_rigid_transform_between_points
+
+from helpers import OracleOptimizer, ParityOptimizer
+
+
+def run_session(optimizer, n_frames, tmp_path=None, to_device=None, max_BA_frames=5):
+    seq = S.SyntheticSequence(n_frames=n_frames, seed=S.config_seed(1))
+    fm = S.SyntheticFeatureManager(seq, corr_per_pair=300)
+    bundler = Bundler(optimizer, fm, seq.K, seq.H, seq.W, window_size=5, max_BA_frames=max_BA_frames, pose_dir=tmp_path)
+    errs, frames = [], []
+    for k in range(n_frames):
+        depth, normals = seq.render(k)
+        if to_device is not None:
+            depth, normals = to_device(depth), to_device(normals)
+        fr = FrameRef(id=0, pose_in_model=seq.poses_gt[0].astype(np.float32), n_keypts=300, depth_gpu=depth, normal_gpu=normals)
+        fm.register(fr, k)
+        bundler.process_new_frame(fr)
+        frames.append(fr)
+        errs.append(S.pose_error(fr.pose_in_model, seq.poses_gt[k]))
+        assert len(bundler.local_frames) <= max_BA_frames
+        assert len(bundler.frames) <= bundler.window_size + 3
+    return seq, bundler, frames, np.array(errs)
+
+
+def check_session(seq, bundler, frames, errs, n_frames):
+    assert bundler.n_ba_calls == n_frames - 1                       # every frame after the first is bundle-adjusted
+    assert [f.id for f in frames] == list(range(n_frames))
+    # keyframes: frame 0 plus frames at least min_rot away from every earlier keyframe (Bundler.cpp:185-219)
+    kf = bundler.keyframes
+    assert kf[0].id == 0 and len(kf) >= n_frames // 3
+    for a in range(len(kf)):
+        for b in range(a):
+            ang = np.rad2deg(S.rotation_angle(kf[a].pose_in_model[:3, :3], kf[b].pose_in_model[:3, :3]))
+            assert ang >= 10.0 - 0.6       # poses moved a little in later BA calls after the frame became a keyframe
+    # tracking stays on the ground truth (1 mm feature noise, 5 % outliers, Huber): no drift over the orbit
+    assert errs[:, 0].max() < np.deg2rad(0.5) and errs[:, 1].max() < 0.005, errs.max(0)
+
+
+def test_c1_sliding_window_oracle(oracle, tmp_path):
+    n = 24
+    seq, bundler, frames, errs = run_session(OracleOptimizer(oracle), n, tmp_path=str(tmp_path))
+    check_session(seq, bundler, frames, errs, n)
+    # pose files: poses/<id>.txt holds ob_in_cam with 10 significant digits (Bundler.cpp:362-377)
+    for k in (1, n - 1):
+        M = load_pose_txt(os.path.join(str(tmp_path), "%04d.txt" % k))
+        # the file is written right after the frame's own BA call; later calls may still move a keyframe's pose
+        assert M.shape == (4, 4) and np.allclose(M[3], [0, 0, 0, 1])
+        r, t = S.pose_error(np.linalg.inv(M), seq.poses_gt[k])
+        assert r < np.deg2rad(0.5) and t < 0.003
+
+
+def test_pose_txt_format_and_kabsch():
+    M = np.eye(4, dtype=np.float32)
+    M[0, 3], M[1, 2] = 0.123456789, -1e-5
+    txt = format_pose_txt(M)
+    rows = txt.rstrip("\n").split("\n")
+    assert len(rows) == 4 and len({len(r) for r in rows}) == 1            # Eigen pads every column to one width
+    assert rows[0].split() == ["1", "0", "0", "0.123456791"]            # float -> %.10g
+    assert rows[1].split()[2] == "-9.999999747e-06"
+    assert np.allclose(np.array([[float(c) for c in r.split()] for r in rows]), M, rtol=1e-9, atol=0)
+    # Kabsch (Utils.cpp:180-214): recovers a rigid motion, repairs a reflection, identity on degenerate input
+    rng = np.random.default_rng(0)
+    P = rng.normal(size=(50, 3)).astype(np.float32)
+    T = S.se3_exp(np.array([0.2, -0.1, 0.3]), np.array([0.01, 0.02, -0.03]))
+    Q = P @ T[:3, :3].T + T[:3, 3]
+    est = solve_rigid_transform_between_points(P, Q)
+    assert np.abs(est - T).max() < 1e-5
+    flat = P.copy(); flat[:, 2] = 0                                        # planar points: SVD may return a reflection
+    est = solve_rigid_transform_between_points(flat, flat @ T[:3, :3].T + T[:3, 3])
+    assert abs(np.linalg.det(est[:3, :3]) - 1) < 1e-4 and np.abs(est - T).max() < 1e-4
+    assert np.array_equal(solve_rigid_transform_between_points(P[:2], Q[:2]), np.eye(4, dtype=np.float32))
+    bad = P.copy(); bad[0, 0] = np.nan
+    assert np.array_equal(solve_rigid_transform_between_points(bad, Q), np.eye(4, dtype=np.float32))
+
+
+@pytest.mark.gpu
+def test_c1_sliding_window_hip_vs_oracle(oracle, tmp_path):
+    import torch
+    from bundletrack_amd.optimizer import OptimizerGpu, Workspace
+    dev = torch.device("cuda:0")
+    n = 60
+    par = ParityOptimizer(OptimizerGpu(workspace=Workspace()), OracleOptimizer(oracle), S.pose_error)
+    seq, bundler, frames, errs = run_session(par, n, tmp_path=str(tmp_path), to_device=lambda a: torch.from_numpy(a).to(dev))
+    assert len(par.diffs) == n - 1
+    d = np.array(par.diffs)
+    # A converged window sits on the reference's PCG guard (r.z <= 1e-6 => no step, SolverBundling.cu:728-818): r.z
+    # hovers at 0.9-1.1e-6 and last-bit rounding decides whether one more ~1e-4 step is taken in an iteration.  The
+    # oracle's own two summation orders disagree on those calls (scripts/dbg_session.py), so they are held to 3e-4.
+    print("BA calls: %d, median diff %.2e, over 1e-4: %s" % (len(d), np.median(d), np.round(d[d >= 1e-4], 6).tolist()))
+    assert np.median(d) < 1e-5 and (d < 1e-4).mean() >= 0.9 and d.max() < 3e-4, d
+    check_session(seq, bundler, frames, errs, n)
