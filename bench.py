@@ -38,7 +38,8 @@ CONFIGS = {
 def _gen(args):
     from bundletrack_amd import synthetic as S
     K, m, seed, masked = args
-    pb = S.make_problem(K, m, seed, background=not masked, full_res=False)
+    angles = S.pruned_pool_angles(60, 30, seed) if K == 30 else None        # c4: 60-keyframe pool pruned to 30 (greedy-rot) before the timed region
+    pb = S.make_problem(K, m, seed, background=not masked, full_res=False, angles=angles)
     campos, normals, intr = S.analytic_cache(pb)
     zn = np.concatenate([pb.cache_depth[..., None], pb.cache_normals[..., :3]], -1).astype(np.float32)       # compact cache: (z, nx, ny, nz)
     return dict(campos=campos, normals=normals, intr=intr, corr=pb.corr, poses=pb.poses_init, zn=zn, K=pb.K, H=pb.H, W=pb.W)
@@ -80,6 +81,22 @@ def cpu_baseline(cfg, inst, budget_s=20.0):
             "sample": f"{best[1]} full solves (7 GN x 5 PCG) of one {cfg['desc']} instance in {best[2]:.1f} s; "
                       f"1 thread: {out['1t'][0]:.2f} it/s, {nmt} threads: {out['all'][0]:.2f} it/s (gcc -O3 AVX2 + OpenMP, oracle/btba_oracle.c)",
             "host_cpus": ncpu}
+
+
+def measured_copy_bandwidth(torch, dev, nbytes=1 << 30, reps=10):
+    """Device-to-device copy bandwidth of this box (read + write bytes / time), SURVEY.md 8(d): fractions are quoted
+    against the nominal 8 TB/s AND against what the part actually streams."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -209,6 +226,10 @@ def main():
                                        "boundary (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"}
             if traffic:
                 res["roofline"]["hbm_traffic_GBps"] = round(traffic / (avg_ms * 1e-3) / 1e9, 1)
+            if world == 1:
+                copy_bw = measured_copy_bandwidth(torch, dev)
+                res["roofline"]["peak_measured_copy"] = round(copy_bw, 1)
+                res["roofline"]["frac_of_measured_copy"] = round(achieved / copy_bw, 4)
             res["kernels_ms_per_step"] = {
                 "dense_sweep": round(st["ms_dense_sweep"] / args.steps, 4), "sparse_sweep": round(st["ms_sparse_sweep"] / args.steps, 4),
                 "system_solve": round(st["ms_system_solve"] / args.steps, 4), "solve_region": round(st["ms_solve"] / args.steps, 4),

@@ -29,7 +29,7 @@ ENTRYJ_DTYPE = np.dtype(
 EXPORTED_SYMBOLS = [
     "btba_params_default", "btba_strerror", "btba_last_hip_error", "btba_version",
     "btba_workspace_create", "btba_workspace_create_on_stream", "btba_workspace_destroy", "btba_workspace_sync",
-    "btba_optimize_frames", "btba_build_cache", "btba_solve_batch", "btba_collect_stats",
+    "btba_optimize_frames", "btba_optimize_frames_keyed", "btba_frame_cache_clear", "btba_build_cache", "btba_solve_batch", "btba_collect_stats",
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
     "btba_process_depth", "btba_depth_to_normals",
@@ -56,7 +56,7 @@ class Stats(C.Structure):
         ("ms_dense_sweep", C.c_float), ("ms_sparse_sweep", C.c_float), ("ms_system_solve", C.c_float),
         ("n_dense_launches", C.c_int32), ("n_sparse_launches", C.c_int32), ("n_solve_launches", C.c_int32),
         ("bytes_dense_alg", C.c_int64), ("bytes_sparse_alg", C.c_int64),
-        ("fused_sweeps", C.c_int32), ("reserved_", C.c_int32),
+        ("fused_sweeps", C.c_int32), ("cache_frames_built", C.c_int32),
     ]
 
     def as_dict(self):
@@ -116,6 +116,10 @@ def lib() -> C.CDLL:
         L.btba_optimize_frames.argtypes = [
             C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_void_p,
             C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Stats)]
+        L.btba_optimize_frames_keyed.argtypes = [
+            C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_void_p,
+            C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Stats)]
+        L.btba_frame_cache_clear.argtypes = [C.c_void_p]
         L.btba_build_cache.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.btba_solve_batch.argtypes = [

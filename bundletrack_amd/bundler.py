@@ -202,7 +202,7 @@ class Bundler:
     """
 
     def __init__(self, optimizer, feature_manager, K, H, W, *, window_size=5, max_BA_frames=15, min_rot_deg=10.0,
-                 min_feat_num=0, min_fm_edges_newframe=5, pose_dir=None):
+                 min_feat_num=0, min_fm_edges_newframe=5, pose_dir=None, persistent_frame_cache=False):
         self.opt, self.fm = optimizer, feature_manager
         self.K, self.H, self.W = np.asarray(K, np.float32), int(H), int(W)
         self.window_size = int(window_size)                        # bundle.window_size
@@ -213,6 +213,10 @@ class Bundler:
         self.newframe = None
         self.need_reinit = False
         self.pose_dir = pose_dir
+        self.persistent_frame_cache = bool(persistent_frame_cache)     # hand Frame ids to the optimiser as cache keys
+        if self.persistent_frame_cache and getattr(optimizer, "workspace", None) is not None:
+            from .optimizer import frame_cache_clear
+            frame_cache_clear(optimizer.workspace)                     # frame ids restart at 0 with every tracking session
         self.n_ba_calls = 0
         self.last_window = None
 
@@ -268,9 +272,10 @@ class Bundler:
         if not win.run_ba:
             return
         poses = np.stack([np.asarray(f.pose_in_model, np.float32) for f in win.frames])
+        extra = {"frame_keys": [f.id for f in win.frames]} if self.persistent_frame_cache else {}
         self.opt.optimizeFrames(win.corr, win.n_match_per_pair, len(win.frames), self.H, self.W,
                                 [f.depth_gpu for f in win.frames], [f.color_gpu for f in win.frames],
-                                [f.normal_gpu for f in win.frames], poses, self.K)
+                                [f.normal_gpu for f in win.frames], poses, self.K, **extra)
         self.n_ba_calls += 1
         for f, T in zip(win.frames, poses):
             f.pose_in_model = np.array(T, np.float32)

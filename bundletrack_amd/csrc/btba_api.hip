@@ -71,6 +71,16 @@ struct btba_workspace {
     hipStream_t aux_stream = nullptr;  // second half of a batch runs here (software pipelining across instances)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
+    // persistent frame cache (btba_optimize_frames_keyed): compact (z, n) frames, their valid-pixel lists and counts
+    // live in pool slots that survive across calls; a keyframe is cached once, not once per BA call.
+    struct FrameSlot { uint64_t key = 0; const float *depth = nullptr, *normal = nullptr; uint64_t stamp = 0; bool live = false; int32_t n_valid = 0; };
+    DevBuf pool_zn, pool_lists, pool_counts, pool_nvalid, pool_map;
+    std::vector<FrameSlot> pool_slots;
+    int pool_H = 0, pool_W = 0, pool_npix = 0;
+    float pool_downscale = 0.0f, pool_K[9] = {0};
+    uint64_t pool_stamp = 0;
+    uint64_t pool_hits = 0, pool_misses = 0;
+
     hipEvent_t get_event()
     {
         if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
@@ -149,7 +159,8 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto &ep : ws->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs,
-                       &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts };
+                       &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts,
+                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map };
     for (auto b : bufs) b->release();
     if (ws->aux_stream) (void)hipStreamDestroy(ws->aux_stream);
     if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
@@ -276,7 +287,11 @@ static int pick_tiles(const btba_params *prm, int B, int Pd, int npix)
 
 static void scaled_intrinsics(int H, int W, int Hd, int Wd, const float *K, float intr[4], Mat4 *Kinv);
 
-struct ZnSpec { const float *zn = nullptr; int H = 0, W = 0; const float *K = nullptr; };     // compact cache + the full-res geometry it encodes
+struct ZnSpec {      // compact cache + the full-res geometry it encodes
+    const float *zn = nullptr; int H = 0, W = 0; const float *K = nullptr;
+    const int *frame_slot = nullptr;                       // persistent cache: device int[N], frame -> pool slot (B == 1 only)
+    const uint32_t *lists = nullptr; const int *counts = nullptr;   // valid-pixel lists already built per slot
+};
 
 static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int N, int Hd, int Wd, const float *intr,
                          const float *campos, const float *normals, const ZnSpec &Z, const btba_entryj *corr, int64_t corr_stride,
@@ -395,11 +410,17 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     }
     // per-frame valid-pixel lists for the compact dense sweep (once per solve; the frames do not change across iterations)
     const bool compaction = use_zn && use_dense && (prm->flags & BTBA_FLAG_COMPACTION);
-    if (compaction) {
+    const uint32_t *lists_base = Z.lists;
+    const int *counts_base = Z.counts;
+    if (compaction && !lists_base) {
         if ((rc = ws->valid_lists.ensure(sizeof(uint32_t) * (size_t)B * N * npix))) return rc;
         if ((rc = ws->valid_counts.ensure(sizeof(int) * (size_t)B * N))) return rc;
-        k_valid_lists<<<B * N, kBlock, 0, ws->stream>>>(npix, reinterpret_cast<const float4 *>(Z.zn), ws->valid_lists.as<uint32_t>(), ws->valid_counts.as<int>());
+        k_valid_lists<<<B * N, 1024, 0, ws->stream>>>(npix, reinterpret_cast<const float4 *>(Z.zn), ws->valid_lists.as<uint32_t>(), ws->valid_counts.as<int>(), nullptr);
+        lists_base = ws->valid_lists.as<uint32_t>();
+        counts_base = ws->valid_counts.as<int>();
     }
+    if (Z.frame_slot && B != 1) return BTBA_EINVAL;
+    D.frame_slot = Z.frame_slot;
     // Software pipelining across instances: the batch is split in two halves on two streams, so one half's
     // latency-bound k_system_solve (B/2 workgroups on a 256-CU chip) and its sparse sweep overlap the other
     // half's dense sweep.  Halves never touch each other's data; fork/join events keep the caller's stream
@@ -428,8 +449,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             const size_t b0 = (size_t)H.b0;
             const float *campos_h = campos ? campos + 4 * b0 * N * npix : nullptr, *normals_h = normals ? normals + 4 * b0 * N * npix : nullptr;
             const float4 *zn_h = use_zn ? reinterpret_cast<const float4 *>(Z.zn) + b0 * N * npix : nullptr;
-            const uint32_t *vl_h = compaction ? ws->valid_lists.as<uint32_t>() + b0 * N * npix : nullptr;
-            const int *vc_h = compaction ? ws->valid_counts.as<int>() + b0 * N : nullptr;
+            const uint32_t *vl_h = compaction ? lists_base + b0 * N * npix : nullptr;
+            const int *vc_h = compaction ? counts_base + b0 * N : nullptr;
             const float4 *corr_h = corr ? reinterpret_cast<const float4 *>(corr) + 2 * b0 * (size_t)corr_stride : nullptr;
             const uint32_t *off_h = pair_offsets ? pair_offsets + b0 * (P + 1) : nullptr;
             float *x_h = ws->x.as<float>() + 6 * b0 * N, *T_h = ws->T.as<float>() + 16 * b0 * N, *Ti_h = ws->Tinv.as<float>() + 16 * b0 * N;
@@ -598,9 +619,12 @@ int btba_build_cache(btba_workspace *ws, int n_frames, int H, int W, const float
     return BTBA_OK;
 }
 
-int btba_optimize_frames(btba_workspace *ws_in, const btba_params *params_in, int n_frames, int H, int W, const float *K,
+static int pool_resolve(btba_workspace *ws, int N, int H, int W, int Hd, int Wd, const float *K, float downscale, const uint64_t *keys,
+                        const float *const *depth_dev, const float *const *normal_dev, std::vector<int32_t> &nv_out, int *n_built);
+
+static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params_in, int n_frames, int H, int W, const float *K,
                          const btba_entryj *corres_host, uint32_t n_corres, const int *n_match_per_pair,
-                         const float *const *depth_dev, const float *const *normal_dev,
+                         const float *const *depth_dev, const float *const *normal_dev, const uint64_t *frame_keys,
                          const int32_t *dense_pairs, int n_dense_pairs, float *poses, btba_stats *stats)
 {
     (void)n_match_per_pair;   // stored and never read by the reference either (SBA.cpp:85)
@@ -648,13 +672,22 @@ int btba_optimize_frames(btba_workspace *ws_in, const btba_params *params_in, in
     if (kept && (e = hipMemcpyAsync(ws->corr.p, upload, sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
     if ((e = hipMemcpyAsync(ws->offsets.p, offsets.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
     if ((e = hipMemcpyAsync(ws->poses.p, poses, sizeof(float) * 16 * N, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
-    // pageable sources are staged by the runtime before hipMemcpyAsync returns; the sync only serves the upload timer
+    // the sources (caller's arrays, `offsets`, `scattered`) outlive the synchronising end of this call; the sync only serves the upload timer
     if ((prm.flags & BTBA_FLAG_TIME_KERNELS) && (e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
     const auto tu1 = std::chrono::steady_clock::now();
 
     float intr[4];
     const bool compact = !(prm.flags & BTBA_FLAG_FLOAT4_CACHE);        // compact (z, n) cache: identical results, half the bytes
-    if (compact) rc = btba_build_cache_zn(ws, N, H, W, K, prm.image_downscale, depth_dev, normal_dev, ws->campos.as<float>(), ws->nvalid.as<int32_t>(), intr);
+    const bool keyed = frame_keys != nullptr;
+    if (keyed && (!compact || !ws_in)) return finish(BTBA_EINVAL);     // the persistent cache lives in a caller-owned workspace
+    std::vector<int32_t> nv_keyed;
+    int n_built = N;
+    if (keyed) {
+        Mat4 Kinv_unused;
+        scaled_intrinsics(H, W, Hd, Wd, K, intr, &Kinv_unused);
+        rc = pool_resolve(ws, N, H, W, Hd, Wd, K, prm.image_downscale, frame_keys, depth_dev, normal_dev, nv_keyed, &n_built);
+    }
+    else if (compact) rc = btba_build_cache_zn(ws, N, H, W, K, prm.image_downscale, depth_dev, normal_dev, ws->campos.as<float>(), ws->nvalid.as<int32_t>(), intr);
     else rc = btba_build_cache(ws, N, H, W, K, prm.image_downscale, depth_dev, normal_dev, ws->campos.as<float>(), ws->normals.as<float>(), ws->nvalid.as<int32_t>(), intr);
     if (rc) return finish(rc);
 
@@ -665,8 +698,11 @@ int btba_optimize_frames(btba_workspace *ws_in, const btba_params *params_in, in
         pairs_ptr = dense_pairs; n_pairs_dense = n_dense_pairs;
     } else if (prm.pair_policy == BTBA_PAIRS_TARGET_MORE_VALID) {
         std::vector<int32_t> nv(N);
-        if ((e = hipMemcpyAsync(nv.data(), ws->nvalid.p, sizeof(int32_t) * N, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) return hip_fail(e);
-        if ((e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
+        if (keyed) nv = nv_keyed;
+        else {
+            if ((e = hipMemcpyAsync(nv.data(), ws->nvalid.p, sizeof(int32_t) * N, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) return hip_fail(e);
+            if ((e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
+        }
         for (int i = 0; i < N; i++)
             for (int j = i + 1; j < N; j++) {
                 if (nv[i] >= nv[j]) { pairs.push_back(i); pairs.push_back(j); }   // ties: i<j (SolverBundling.cu:25-33)
@@ -681,13 +717,17 @@ int btba_optimize_frames(btba_workspace *ws_in, const btba_params *params_in, in
     ws->always_time_region = true;
     ZnSpec Z;
     if (compact) {
-        Z.zn = ws->campos.as<float>(); Z.H = H; Z.W = W; Z.K = K;
+        Z.zn = keyed ? ws->pool_zn.as<float>() : ws->campos.as<float>(); Z.H = H; Z.W = W; Z.K = K;
+        if (keyed) { Z.frame_slot = ws->pool_map.as<int>(); Z.lists = ws->pool_lists.as<uint32_t>(); Z.counts = ws->pool_counts.as<int>(); }
         if (!(prm.flags & (BTBA_FLAG_COMPACTION | BTBA_FLAG_NO_COMPACTION))) {
             // a tracker's frames are masked to the object: walk valid-pixel lists when under 60 % of the pixels carry a depth.
             // (the cache builder counted them; this call is synchronous anyway, so the 4*N-byte read-back costs nothing extra)
             std::vector<int32_t> nv(N);
-            if ((e = hipMemcpyAsync(nv.data(), ws->nvalid.p, sizeof(int32_t) * N, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) return hip_fail(e);
-            if ((e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
+            if (keyed) nv = nv_keyed;
+            else {
+                if ((e = hipMemcpyAsync(nv.data(), ws->nvalid.p, sizeof(int32_t) * N, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) return hip_fail(e);
+                if ((e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
+            }
             long tot = 0;
             for (int v : nv) tot += v;
             if (tot * 10 < (long)N * npix * 6) prm.flags |= BTBA_FLAG_COMPACTION;
@@ -705,12 +745,124 @@ int btba_optimize_frames(btba_workspace *ws_in, const btba_params *params_in, in
     std::memcpy(poses, out.data(), sizeof(float) * out.size());
     if (stats) {
         S.n_corr = kept;
+        S.cache_frames_built = n_built;
         S.bytes_sparse_alg = (int64_t)32 * kept;
         S.ms_upload = std::chrono::duration<float, std::milli>(tu1 - tu0).count();
         S.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         *stats = S;
     }
     return finish(BTBA_OK);
+}
+
+int btba_optimize_frames(btba_workspace *ws, const btba_params *params, int n_frames, int H, int W, const float *K,
+                         const btba_entryj *corres_host, uint32_t n_corres, const int *n_match_per_pair,
+                         const float *const *depth_dev, const float *const *normal_dev,
+                         const int32_t *dense_pairs, int n_dense_pairs, float *poses, btba_stats *stats)
+{
+    return optimize_frames_impl(ws, params, n_frames, H, W, K, corres_host, n_corres, n_match_per_pair, depth_dev, normal_dev, nullptr,
+                                dense_pairs, n_dense_pairs, poses, stats);
+}
+
+int btba_optimize_frames_keyed(btba_workspace *ws, const btba_params *params, int n_frames, int H, int W, const float *K,
+                               const btba_entryj *corres_host, uint32_t n_corres, const int *n_match_per_pair,
+                               const float *const *depth_dev, const float *const *normal_dev, const uint64_t *frame_keys,
+                               const int32_t *dense_pairs, int n_dense_pairs, float *poses, btba_stats *stats)
+{
+    if (!ws || !frame_keys) return BTBA_EINVAL;
+    return optimize_frames_impl(ws, params, n_frames, H, W, K, corres_host, n_corres, n_match_per_pair, depth_dev, normal_dev, frame_keys,
+                                dense_pairs, n_dense_pairs, poses, stats);
+}
+
+int btba_frame_cache_clear(btba_workspace *ws)
+{
+    if (!ws) return BTBA_EINVAL;
+    for (auto &sl : ws->pool_slots) sl = btba_workspace::FrameSlot{};
+    return BTBA_OK;
+}
+
+// Persistent frame cache: map every frame of this call to a pool slot, building only the frames that are not cached
+// yet (same key AND same device buffers) -- in a tracker that is the one new frame, the keyframes were cached by
+// earlier calls (the reference re-caches all K frames on every call, LossGPU.cu:74-78).  Least-recently-used slots
+// are recycled.  Leaves the slot map on the device (ws->pool_map) and the per-frame valid counts in nv_out.
+static int pool_resolve(btba_workspace *ws, int N, int H, int W, int Hd, int Wd, const float *K, float downscale, const uint64_t *keys,
+                        const float *const *depth_dev, const float *const *normal_dev, std::vector<int32_t> &nv_out, int *n_built)
+{
+    const int npix = Hd * Wd;
+    int rc;
+    const bool same_geometry = ws->pool_H == H && ws->pool_W == W && ws->pool_npix == npix && ws->pool_downscale == downscale &&
+                               std::memcmp(ws->pool_K, K, sizeof ws->pool_K) == 0;
+    const size_t want_slots = std::max<size_t>(32, 2 * (size_t)N);
+    if (!same_geometry || ws->pool_slots.size() < (size_t)N) {
+        const size_t cap = std::max(want_slots, ws->pool_slots.size());
+        if ((rc = ws->pool_zn.ensure(sizeof(float) * 4 * cap * npix))) return rc;
+        if ((rc = ws->pool_lists.ensure(sizeof(uint32_t) * cap * npix))) return rc;
+        if ((rc = ws->pool_counts.ensure(sizeof(int) * cap))) return rc;
+        if ((rc = ws->pool_nvalid.ensure(sizeof(int32_t) * cap))) return rc;
+        ws->pool_slots.assign(cap, btba_workspace::FrameSlot{});
+        ws->pool_H = H; ws->pool_W = W; ws->pool_npix = npix; ws->pool_downscale = downscale;
+        std::memcpy(ws->pool_K, K, sizeof ws->pool_K);
+    }
+    const size_t cap = ws->pool_slots.size();
+    std::vector<int> slot_of(N, -1);
+    std::vector<char> taken(cap, 0);
+    for (int k = 0; k < N; k++) {
+        if (!depth_dev[k] || !normal_dev[k]) return BTBA_EINVAL;
+        for (int q = 0; q < k; q++) if (keys[q] == keys[k]) return BTBA_EINVAL;          // a frame appears once per window
+        for (size_t sidx = 0; sidx < cap; sidx++) {
+            const auto &sl = ws->pool_slots[sidx];
+            if (sl.live && sl.key == keys[k] && sl.depth == depth_dev[k] && sl.normal == normal_dev[k]) { slot_of[k] = (int)sidx; taken[sidx] = 1; break; }
+        }
+    }
+    std::vector<int> miss;
+    for (int k = 0; k < N; k++) {
+        if (slot_of[k] >= 0) { ws->pool_hits++; continue; }
+        size_t best = cap;
+        for (size_t sidx = 0; sidx < cap; sidx++) {
+            if (taken[sidx]) continue;
+            if (!ws->pool_slots[sidx].live) { best = sidx; break; }
+            if (best == cap || ws->pool_slots[sidx].stamp < ws->pool_slots[best].stamp) best = sidx;
+        }
+        if (best == cap) return BTBA_ENOMEM;       // cannot happen: cap >= 2N
+        slot_of[k] = (int)best; taken[best] = 1;
+        miss.push_back(k);
+        ws->pool_misses++;
+    }
+    ws->pool_stamp++;
+    for (int k = 0; k < N; k++) ws->pool_slots[slot_of[k]].stamp = ws->pool_stamp;
+    *n_built = (int)miss.size();
+    const int M = (int)miss.size();
+    if (M > 0) {
+        // staging: [M depth pointers][M normal pointers][M int32 destination slots]
+        const size_t bytes = sizeof(void *) * 2 * (size_t)M + sizeof(int32_t) * (size_t)M;
+        if ((rc = ws->ptrs.ensure(bytes))) return rc;
+        std::vector<unsigned char> stage(bytes);
+        auto **pp = reinterpret_cast<const float **>(stage.data());
+        auto *ps = reinterpret_cast<int32_t *>(stage.data() + sizeof(void *) * 2 * (size_t)M);
+        for (int m = 0; m < M; m++) { pp[m] = depth_dev[miss[m]]; pp[M + m] = normal_dev[miss[m]]; ps[m] = slot_of[miss[m]]; }
+        HIP_TRY(hipMemcpyAsync(ws->ptrs.p, stage.data(), bytes, hipMemcpyHostToDevice, ws->stream));
+        for (int m = 0; m < M; m++) HIP_TRY(hipMemsetAsync(ws->pool_nvalid.as<int32_t>() + ps[m], 0, sizeof(int32_t), ws->stream));
+        const int *slots_dev = reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(ws->ptrs.p) + sizeof(void *) * 2 * (size_t)M);
+        size_t tslot;
+        if ((rc = time_begin(ws, true, 4, &tslot))) return rc;
+        k_build_cache_zn<<<dim3((npix + kBlock - 1) / kBlock, M), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, ws->ptrs.as<const float *>(), ws->ptrs.as<const float *>() + M,
+                                                                                        ws->pool_zn.as<float4>(), ws->pool_nvalid.as<int32_t>(), slots_dev);
+        k_valid_lists<<<M, 1024, 0, ws->stream>>>(npix, ws->pool_zn.as<const float4>(), ws->pool_lists.as<uint32_t>(), ws->pool_counts.as<int>(), slots_dev);
+        if ((rc = time_end(ws, tslot))) return rc;
+        HIP_TRY(hipGetLastError());
+        std::vector<int32_t> nvh(cap);
+        HIP_TRY(hipMemcpyAsync(nvh.data(), ws->pool_nvalid.p, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, ws->stream));
+        HIP_TRY(hipStreamSynchronize(ws->stream));          // also keeps `stage` alive until the copy has landed
+        for (int m = 0; m < M; m++) {
+            auto &sl = ws->pool_slots[ps[m]];
+            sl.live = true; sl.key = keys[miss[m]]; sl.depth = depth_dev[miss[m]]; sl.normal = normal_dev[miss[m]]; sl.n_valid = nvh[ps[m]];
+        }
+    }
+    nv_out.resize(N);
+    for (int k = 0; k < N; k++) nv_out[k] = ws->pool_slots[slot_of[k]].n_valid;
+    if ((rc = ws->pool_map.ensure(sizeof(int) * (size_t)N))) return rc;
+    HIP_TRY(hipMemcpyAsync(ws->pool_map.p, slot_of.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice, ws->stream));
+    HIP_TRY(hipStreamSynchronize(ws->stream));              // slot_of is a local
+    return BTBA_OK;
 }
 
 int btba_matrices_to_poses(btba_workspace *ws, int n, const float *T_dev, float *x_dev)
@@ -777,7 +929,7 @@ int btba_build_cache_zn(btba_workspace *ws, int n_frames, int H, int W, const fl
     size_t slot;
     if ((rc = time_begin(ws, true, 4, &slot))) return rc;
     k_build_cache_zn<<<dim3((npix + kBlock - 1) / kBlock, n_frames), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, ws->ptrs.as<const float *>(), ws->ptrs.as<const float *>() + n_frames,
-                                                                                            reinterpret_cast<float4 *>(zn_dev), n_valid_dev);
+                                                                                            reinterpret_cast<float4 *>(zn_dev), n_valid_dev, nullptr);
     if ((rc = time_end(ws, slot))) return rc;
     HIP_TRY(hipGetLastError());
     return BTBA_OK;

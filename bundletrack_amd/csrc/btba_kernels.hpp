@@ -64,7 +64,11 @@ struct SolveDims {
     float zn_ki[16];     // full-resolution intrinsicsInv (4x4 embedding, generic cofactor inverse)
     float zn_scale_w, zn_scale_h;   // (W-1)/(Wd-1), (H-1)/(Hd-1) of the nearest-neighbour resample
     int zn_simple;       // 1: zero skew and affine last row (ki[1]=ki[3]=ki[4]=ki[7]=ki[12]=ki[13]=ki[14]=0)
+    // persistent frame cache: frame f of the solve lives in pool slot frame_slot[f] (nullptr: slot == f, contiguous cache)
+    const int *frame_slot;
 };
+
+__device__ __forceinline__ size_t frame_slot_of(const SolveDims &D, size_t f) { return D.frame_slot ? (size_t)D.frame_slot[f] : f; }
 
 // canonical pair index -> (i, j), i < j, outer i
 __device__ __forceinline__ void pair_from_index(int p, int n, int &i, int &j)
@@ -190,10 +194,11 @@ __device__ __forceinline__ unsigned zn_src_coord(int c, float scale)
 
 // grid (ceil(npix/256), n_frames): CUDACache::storeFrame for all frames, compact output.
 __global__ void __launch_bounds__(kBlock) k_build_cache_zn(int W, int H, int Wd, int Hd, const float *const *__restrict__ depth, const float *const *__restrict__ normals,
-                                                          float4 *__restrict__ zn_out, int *__restrict__ n_valid)
+                                                          float4 *__restrict__ zn_out, int *__restrict__ n_valid, const int *__restrict__ out_slot)
 {
 #pragma clang fp contract(off)
     const int f = blockIdx.y;
+    const int fo = out_slot ? out_slot[f] : f;        // where frame f is stored (persistent cache: a pool slot)
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     const int npix = Wd * Hd;
     int valid = 0;
@@ -207,13 +212,13 @@ __global__ void __launch_bounds__(kBlock) k_build_cache_zn(int W, int H, int Wd,
             const size_t s = (size_t)yi * W + xi;
             const float d = depth[f][s];
             const float4 nr = reinterpret_cast<const float4 *>(normals[f])[s];
-            zn_out[(size_t)f * npix + o] = make_float4(d, nr.x, nr.y, nr.z);
+            zn_out[(size_t)fo * npix + o] = make_float4(d, nr.x, nr.y, nr.z);
             valid = ((double)d >= 0.1) ? 1 : 0;
         }
     }
     if (n_valid) {
         const unsigned long long b = __ballot(valid);
-        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&n_valid[f], __popcll(b));
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&n_valid[fo], __popcll(b));
     }
 }
 
@@ -469,30 +474,67 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
 }
 
 // Ordered list of the pixels of every frame that carry a depth (>= 0.1 m, the cache builder's validity rule).
-// grid (B * K) x 256.  The dense sweep walks this list instead of all Wd x Hd source pixels: a tracker's frames
+// grid (B * K) x 1024.  The dense sweep walks this list instead of all Wd x Hd source pixels: a tracker's frames
 // are masked to the object (~5 % of the image, src/Frame.cpp:342-358), so 95 % of the source stream disappears.
-// Deterministic order (ascending pixel index): ballot + mbcnt prefix inside a wave, fixed wave order.
-__global__ void __launch_bounds__(kBlock) k_valid_lists(int npix, const float4 *__restrict__ zn, uint32_t *__restrict__ lists, int *__restrict__ counts)
+// Deterministic order (ascending pixel index).
+constexpr int kListTrips = 32;        // ballots a wave keeps in scalar registers: frames up to 16 * 64 * 32 = 32 768 cached pixels
+__global__ void __launch_bounds__(1024) k_valid_lists(int npix, const float4 *__restrict__ zn, uint32_t *__restrict__ lists, int *__restrict__ counts,
+                                                     const int *__restrict__ slots)
 {
-    __shared__ int wave_cnt[4];
-    const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // one workgroup of 16 waves per frame; wave w owns the contiguous segment [w seg, (w+1) seg) and reads it in
+    // coalesced 64-pixel trips, all loads in flight at once; the per-trip ballots stay in SGPRs, so after the 16
+    // wave totals have been exchanged through LDS the lists are written without reading the frame again.
+    __shared__ int wave_tot[16];
+    const int f = slots ? slots[blockIdx.x] : (int)blockIdx.x;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
     const float4 *z = zn + (size_t)f * npix;
     uint32_t *out = lists + (size_t)f * npix;
-    int base = 0;
-    for (int s0 = 0; s0 < npix; s0 += kBlock) {
-        const int s = s0 + (int)threadIdx.x;
-        const bool v = (s < npix) && ((double)z[s].x >= 0.1);
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
-        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
+    const int seg = (((npix + 15) / 16) + 63) & ~63, trips = seg / 64;
+    const int s_wave = wave * seg;
+    int total = 0;
+    if (trips <= kListTrips) {
+        unsigned long long m[kListTrips];
+#pragma unroll
+        for (int k = 0; k < kListTrips; k++) {
+            const int s = s_wave + k * 64 + lane;
+            const bool v = (k < trips) && (s < npix) && (z[min(s, npix - 1)].x >= 0.1f);      // (double)d >= 0.1  <=>  d >= 0.1f
+            m[k] = __builtin_amdgcn_ballot_w64(v);
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kListTrips; k++) cnt += __popcll(m[k]);
+        if (lane == 0) wave_tot[wave] = cnt;
         __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; w++) off += wave_cnt[w];
-        if (v) out[off + before] = (uint32_t)s;
-        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        int base = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const int t = wave_tot[w]; if (w < wave) base += t; total += t; }
+#pragma unroll
+        for (int k = 0; k < kListTrips; k++) {
+            const unsigned long long b = m[k];
+            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0));
+            if ((b >> lane) & 1ull) out[base + before] = (uint32_t)(s_wave + k * 64 + lane);
+            base += __popcll(b);
+        }
+    } else {                          // large caches: same scheme, the frame is read twice
+        int cnt = 0;
+        for (int k = 0; k < trips; k++) {
+            const int s = s_wave + k * 64 + lane;
+            cnt += __popcll(__builtin_amdgcn_ballot_w64((s < npix) && (z[min(s, npix - 1)].x >= 0.1f)));
+        }
+        if (lane == 0) wave_tot[wave] = cnt;
         __syncthreads();
+        int base = 0;
+        for (int w = 0; w < 16; w++) { const int t = wave_tot[w]; if (w < wave) base += t; total += t; }
+        for (int k = 0; k < trips; k++) {
+            const int s = s_wave + k * 64 + lane;
+            const bool v = (s < npix) && (z[min(s, npix - 1)].x >= 0.1f);
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(v);
+            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0));
+            if (v) out[base + before] = (uint32_t)s;
+            base += __popcll(b);
+        }
     }
-    if (threadIdx.x == 0) counts[f] = base;
+    if (threadIdx.x == 0) counts[f] = total;
 }
 
 // The same sweep on the compact cache: ONE 16-byte load per source pixel and per tap (5 loads instead of 10),
@@ -522,12 +564,13 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
     C.normal_thresh = D.normal_thresh; C.dist2_thresh = D.dist_thresh * D.dist_thresh;
     C.delta = D.robust_delta; C.delta2 = D.robust_delta * D.robust_delta; C.w_dense = D.w_dense;
     C.W = D.width; C.H = D.height;
-    const float4 *zn_t = zn + (fb + fi) * (size_t)D.npix, *zn_s = zn + (fb + fj) * (size_t)D.npix;
+    const size_t slot_t = frame_slot_of(D, fb + fi), slot_s = frame_slot_of(D, fb + fj);
+    const float4 *zn_t = zn + slot_t * (size_t)D.npix, *zn_s = zn + slot_s * (size_t)D.npix;
     // LISTS: walk the source frame's ordered list of pixels that carry a depth (masked scenes: ~5 % of the image);
     // otherwise walk all pixels with incrementally advanced coordinates.  Two instantiations rather than one loop
     // with both: the kernel sits at the 96-VGPR / 5-waves-per-SIMD boundary and the merged loop measured 8 % slower.
-    const int n_src = LISTS ? valid_counts[fb + fj] : D.npix;
-    const uint32_t *list = LISTS ? valid_lists + (fb + fj) * (size_t)D.npix : nullptr;
+    const int n_src = LISTS ? valid_counts[slot_s] : D.npix;
+    const uint32_t *list = LISTS ? valid_lists + slot_s * (size_t)D.npix : nullptr;
     const int per = (n_src + D.dense_tiles - 1) / D.dense_tiles;
     const int lo = min(n_src, per * tile), hi = min(n_src, per * (tile + 1));
     const float inv_w = 1.0f / (float)D.width;

@@ -93,10 +93,12 @@ class OptimizerGpu:
         self.last_stats: dict | None = None
 
     def optimizeFrames(self, global_corres, n_match_per_pair, n_frames, H, W, depths_gpu, colors_gpu, normals_gpu, poses, K,
-                       dense_pairs=None):
+                       dense_pairs=None, frame_keys=None):
         """global_corres: ENTRYJ_DTYPE array; depths_gpu[k]: CUDA float32 [H,W]; normals_gpu[k]: CUDA float32
         [H,W,4]; colors_gpu: ignored (weight 0 in the reference, SBA.cpp:32); poses: float32 [n_frames,4,4]
-        camera->model, updated IN PLACE like the reference's non-const reference argument; K: [3,3]."""
+        camera->model, updated IN PLACE like the reference's non-const reference argument; K: [3,3].
+        frame_keys (optional, one stable integer id per frame, e.g. Frame::_id): keep the frames' caches in the
+        workspace across calls (btba_optimize_frames_keyed) -- only frames not seen before are cached."""
         del colors_gpu
         corr = np.ascontiguousarray(global_corres, ENTRYJ_DTYPE)
         if len(depths_gpu) != n_frames or len(normals_gpu) != n_frames:
@@ -114,16 +116,28 @@ class OptimizerGpu:
             dp = np.ascontiguousarray(dense_pairs, np.int32).reshape(-1, 2)
         st = Stats()
         dptr, nptr = _ptr_array(depths_gpu), _ptr_array(normals_gpu)
-        rc = lib().btba_optimize_frames(
-            self.workspace.handle if self.workspace else None, C.byref(self.params), n_frames, H, W, Kf.ctypes.data,
-            corr.ctypes.data if corr.shape[0] else None, corr.shape[0], nm.ctypes.data if nm is not None else None,
-            C.cast(dptr, C.c_void_p), C.cast(nptr, C.c_void_p),
-            dp.ctypes.data if dp is not None else None, dp.shape[0] if dp is not None else 0,
-            P.ctypes.data, C.byref(st))
+        head = (self.workspace.handle if self.workspace else None, C.byref(self.params), n_frames, H, W, Kf.ctypes.data,
+                corr.ctypes.data if corr.shape[0] else None, corr.shape[0], nm.ctypes.data if nm is not None else None,
+                C.cast(dptr, C.c_void_p), C.cast(nptr, C.c_void_p))
+        tail = (dp.ctypes.data if dp is not None else None, dp.shape[0] if dp is not None else 0, P.ctypes.data, C.byref(st))
+        if frame_keys is None:
+            rc = lib().btba_optimize_frames(*head, *tail)
+        else:
+            keys = np.ascontiguousarray(frame_keys, np.uint64)
+            if keys.shape != (n_frames,):
+                raise ValueError("need one key per frame")
+            if self.workspace is None:
+                raise ValueError("the persistent frame cache lives in a Workspace: construct OptimizerGpu(workspace=...)")
+            rc = lib().btba_optimize_frames_keyed(*head, keys.ctypes.data, *tail)
         check(rc, "btba_optimize_frames")
         self.last_stats = st.as_dict()
         np.asarray(poses)[...] = P.reshape(n_frames, 4, 4)
         return poses
+
+
+def frame_cache_clear(ws: Workspace) -> None:
+    """Drop every frame kept by optimizeFrames(..., frame_keys=...) in this workspace."""
+    check(lib().btba_frame_cache_clear(ws.handle), "btba_frame_cache_clear")
 
 
 def build_cache(ws: Workspace, depths_gpu, normals_gpu, H, W, K, image_downscale=4.0):

@@ -147,14 +147,17 @@ def _sample_surface(rng: np.random.Generator, n: int) -> tuple[np.ndarray, np.nd
 def make_problem(n_frames: int, corr_per_pair: int, seed: int, *, background: bool = True,
                  H: int = 480, W: int = 640, downscale: int = 4, full_res: bool = True,
                  rot_step_deg=(10.0, 12.0), perturb_deg: float = 2.0, perturb_m: float = 0.005,
-                 noise_m: float = 0.001, outlier_frac: float = 0.05, K: np.ndarray | None = None) -> Problem:
+                 noise_m: float = 0.001, outlier_frac: float = 0.05, K: np.ndarray | None = None,
+                 angles: np.ndarray | None = None) -> Problem:
     """orbit of `n_frames` keyframes (consecutive rotation 10-12 deg), GT
     poses perturbed by U(+-2 deg, +-5 mm) (frame 0 exact), `corr_per_pair` surface points per
     frame pair (+N(0, 1 mm), 5 % outliers displaced 2-5 cm, shuffled inside the pair)."""
     rng = np.random.default_rng(seed)
     K = NOCS_K if K is None else np.asarray(K, np.float64)
     steps = np.deg2rad(rng.uniform(rot_step_deg[0], rot_step_deg[1], size=n_frames - 1))
-    angles = np.concatenate([[0.0], np.cumsum(steps)])
+    if angles is None:
+        angles = np.concatenate([[0.0], np.cumsum(steps)])
+    assert len(angles) == n_frames
     poses_gt = np.stack([orbit_pose(a) for a in angles])
     # model frame = frame 0's view of the object is arbitrary; keep object at the model origin.
     poses_init = poses_gt.copy()
@@ -218,6 +221,19 @@ def make_problem(n_frames: int, corr_per_pair: int, seed: int, *, background: bo
     return Problem(K=K.astype(np.float32), H=H, W=W, depth=depth, normals=normals, corr=corr,
                    n_match_per_pair=np.asarray(counts, np.int32), poses_init=poses_init.astype(np.float32),
                    poses_gt=poses_gt, cache_depth=cache_depth, cache_normals=cache_normals, downscale=downscale)
+
+
+def pruned_pool_angles(pool_size: int, keep: int, seed: int, rot_step_deg=(10.0, 12.0)) -> np.ndarray:
+    """a pool of `pool_size` keyframes on the orbit plus one new frame, pruned to `keep`
+    frames by the reference's greedy-rotation subset selection (Bundler.cpp:222-274); returns their orbit angles."""
+    from .bundler import FrameRef, KeyframeMemory
+    rng = np.random.default_rng(seed)
+    steps = np.deg2rad(rng.uniform(rot_step_deg[0], rot_step_deg[1], size=pool_size))
+    ang = np.concatenate([[0.0], np.cumsum(steps)])
+    frames = [FrameRef(id=k, pose_in_model=orbit_pose(a).astype(np.float32)) for k, a in enumerate(ang)]
+    mem = KeyframeMemory(max_BA_frames=keep, keyframes=frames[:pool_size])
+    chosen = mem.select_keyframes_for_ba(frames[pool_size])
+    return np.array([ang[f.id] for f in chosen])
 
 
 def config_seed(config: int, instance: int = 0) -> int:

@@ -112,7 +112,7 @@ typedef struct btba_stats {
     int64_t bytes_dense_alg;      /* algorithmic bytes of ONE dense sweep launch  (64 * Pd * npix * B) */
     int64_t bytes_sparse_alg;     /* algorithmic bytes of ONE sparse sweep launch (32 * C)             */
     int32_t fused_sweeps;         /* 1: sparse + dense sweeps ran as ONE launch (timed as ms_dense_sweep) */
-    int32_t reserved_;
+    int32_t cache_frames_built;   /* optimize_frames: frames cached in this call (n_frames unless keyed and already cached) */
 } btba_stats;
 
 /* Per-instance, per-GN-iteration trace record (floats), written when BTBA_FLAG_TRACE is set.
@@ -166,6 +166,23 @@ BTBA_API int btba_optimize_frames(btba_workspace *ws, const btba_params *params,
                          const float *const *depth_dev, const float *const *normal_dev,
                          const int32_t *dense_pairs, int n_dense_pairs,
                          float *poses_rowmajor, btba_stats *stats);
+
+/* btba_optimize_frames with a PERSISTENT frame cache.  frame_keys[k] is a caller-chosen id
+ * of frame k that is stable across calls (the tracker's Frame::_id, Frame.h:61).  A frame whose (key, depth pointer,
+ * normal pointer) was cached by an earlier call on the same workspace, with the same H, W, K and image_downscale, is
+ * NOT cached again: its compact (z, n) pixels, its valid-pixel list and count stay in a pool slot of the workspace
+ * (least-recently-used slots are recycled; pool = max(32, 2 n_frames) slots).  In a tracker only the new frame is
+ * built per call, the keyframes were cached when they were new -- the reference re-caches all K frames every call
+ * (LossGPU.cu:74-78).  The caller must not modify a frame's device buffers while it is cached under the same key
+ * (keyframes are immutable after Frame's constructor, Frame.cpp:107-149); btba_frame_cache_clear drops everything.
+ * Results are bit-identical to btba_optimize_frames.  ws must not be NULL; BTBA_FLAG_FLOAT4_CACHE is rejected. */
+BTBA_API int btba_optimize_frames_keyed(btba_workspace *ws, const btba_params *params,
+                         int n_frames, int H, int W, const float *K_rowmajor,
+                         const btba_entryj *corres_host, uint32_t n_corres, const int *n_match_per_pair,
+                         const float *const *depth_dev, const float *const *normal_dev, const uint64_t *frame_keys,
+                         const int32_t *dense_pairs, int n_dense_pairs,
+                         float *poses_rowmajor, btba_stats *stats);
+BTBA_API int btba_frame_cache_clear(btba_workspace *ws);
 
 /* Frame cache build alone (CUDACache::CUDACache + storeFrame, CUDACache.cpp:14-38,76-88).
  * Outputs (device): campos float4[n_frames][Hd*Wd], normals float4[n_frames][Hd*Wd],

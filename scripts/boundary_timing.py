@@ -17,7 +17,19 @@ def main():
         depths = [torch.from_numpy(pb.depth[k]).to(dev) for k in range(K)]
         normals = [torch.from_numpy(pb.normals[k]).to(dev) for k in range(K)]
         opt = OptimizerGpu(workspace=ws)
-        walls = []
+        walls, walls_keyed = [], []
+        for rep in range(45):       # persistent frame cache, steady state of a tracker: one new frame per call, K-1 cached
+            poses = pb.poses_init.copy()
+            keys = list(range(K - 1)) + [1000 + rep]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            opt.optimizeFrames(pb.corr, pb.n_match_per_pair, K, pb.H, pb.W, depths, None, normals, poses, pb.K, frame_keys=keys)
+            dt = time.perf_counter() - t0
+            if 5 <= rep < 25: walls_keyed.append(dt)
+            if rep == 25: opt.params.flags |= _lib.FLAG_TIME_KERNELS
+            assert rep == 0 or opt.last_stats["cache_frames_built"] == 1
+        st_keyed = opt.last_stats
+        opt.params.flags &= ~_lib.FLAG_TIME_KERNELS
         for timed in (False, True):
             if timed: opt.params.flags |= _lib.FLAG_TIME_KERNELS
             for rep in range(25):
@@ -33,7 +45,9 @@ def main():
         rows.append(dict(K=K, corr_per_pair=m, n_corr=int(len(pb.corr)), frame="%dx%d" % (pb.W, pb.H), valid_fraction=round(float((pb.depth >= 0.1).mean()), 4),
                          wall_ms_median=round(float(np.median(walls)), 4), wall_ms_min=round(float(walls.min()), 4),
                          gn_iters_per_s=round(7e3 / float(np.median(walls)), 1),
+                         wall_ms_median_keyed=round(float(np.median(np.array(walls_keyed) * 1e3)), 4),
                          stats_ms={k: round(float(v), 4) for k, v in st.items() if k.startswith("ms_")},
+                         stats_ms_keyed={k: round(float(v), 4) for k, v in st_keyed.items() if k.startswith("ms_")},
                          entryj_bytes=int(len(pb.corr)) * 32, err_vs_gt=float(err)))
         print(json.dumps(rows[-1]), flush=True)
 

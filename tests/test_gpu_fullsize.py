@@ -46,10 +46,12 @@ def sparse_objective(pb, poses, delta=0.005):
 @pytest.mark.parametrize("cfg", [
     dict(name="c2", K=10, m=1000, wd=0.0, config=2),      # K=10, 1k corr/pair, feature residuals only
     dict(name="c3", K=15, m=2000, wd=1.0, config=3),      # K=15, 2k corr/pair, feature + dense ICP + Huber (the headline)
-    dict(name="c4", K=30, m=4000, wd=1.0, config=4),      # K=30, 4k corr/pair
+    dict(name="c4", K=30, m=4000, wd=1.0, config=4),      # K=30, 4k corr/pair, 60-keyframe pool pruned to 30 by greedy-rot
 ], ids=lambda c: c["name"])
 def test_baseline_configs_match_oracle(gpu, oracle, cfg):
-    pb = S.make_problem(cfg["K"], cfg["m"], S.config_seed(cfg["config"]), background=True, full_res=False)
+    seed = S.config_seed(cfg["config"])
+    angles = S.pruned_pool_angles(60, 30, seed) if cfg["name"] == "c4" else None
+    pb = S.make_problem(cfg["K"], cfg["m"], seed, background=True, full_res=False, angles=angles)
     out, tv, caches = run_gpu(gpu, [pb], weight_dense_depth=cfg["wd"])
     campos, normals, intr = caches[0]
     ref = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=cfg["wd"]))

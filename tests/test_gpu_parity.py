@@ -459,3 +459,62 @@ def test_valid_pixel_compaction(gpu, oracle, small_problem, small_problem_masked
             for k in range(pb.n_frames):
                 r, t = S.pose_error(outs[0][k], outs[1][k])
                 assert r < 2e-5 and t < 2e-5
+
+
+def sub_problem(pb, frames):
+    """The BA window made of `frames` (indices into pb, ascending): correspondences re-indexed pair-major."""
+    idx = {f: k for k, f in enumerate(frames)}
+    keep = np.isin(pb.corr["imgIdx_i"], frames) & np.isin(pb.corr["imgIdx_j"], frames)
+    corr = pb.corr[keep].copy()
+    corr["imgIdx_i"] = [idx[i] for i in corr["imgIdx_i"]]
+    corr["imgIdx_j"] = [idx[j] for j in corr["imgIdx_j"]]
+    return corr, pb.poses_init[frames].copy()
+
+
+@pytest.mark.parametrize("background", [False, True], ids=["masked", "full"])
+def test_persistent_frame_cache(gpu, background):
+    """btba_optimize_frames_keyed: frames cached by earlier calls are not cached again and the
+    results are bit-identical to the stateless entry point, for sliding windows, recycled slots and changed buffers."""
+    from bundletrack_amd.optimizer import Workspace, frame_cache_clear
+    pb = S.make_problem(7, 120, seed=71, background=background)
+    d, n = upload_frames(gpu, pb)
+    ws = Workspace()
+    keyed, plain = gpu.OptimizerGpu(workspace=ws), gpu.OptimizerGpu(workspace=gpu.ws)
+    windows = [[0, 1, 2, 3], [0, 1, 2, 3], [1, 2, 3, 4], [0, 2, 4, 5], [3, 4, 5, 6], [0, 1, 2, 3]]
+    built = []
+    for w in windows:
+        corr, p0 = sub_problem(pb, w)
+        pa, pk = p0.copy(), p0.copy()
+        plain.optimizeFrames(corr, None, len(w), pb.H, pb.W, [d[f] for f in w], None, [n[f] for f in w], pa, pb.K)
+        keyed.optimizeFrames(corr, None, len(w), pb.H, pb.W, [d[f] for f in w], None, [n[f] for f in w], pk, pb.K, frame_keys=[100 + f for f in w])
+        assert np.array_equal(pa, pk), w
+        built.append(keyed.last_stats["cache_frames_built"])
+        assert plain.last_stats["cache_frames_built"] == len(w)
+    assert built == [4, 0, 1, 1, 1, 0]                       # only frames never seen before are cached
+    # the same key on a different device buffer is a different frame: rebuilt, and the result follows the new data
+    w = [0, 1, 2, 3]
+    corr, p0 = sub_problem(pb, w)
+    d_alt = [d[f] for f in w]; n_alt = [n[f] for f in w]
+    d_alt[2] = d[2].clone(); n_alt[2] = n[2].clone()
+    pk = p0.copy()
+    keyed.optimizeFrames(corr, None, 4, pb.H, pb.W, d_alt, None, n_alt, pk, pb.K, frame_keys=[100 + f for f in w])
+    assert keyed.last_stats["cache_frames_built"] == 1
+    # more distinct frames than pool slots (32): least-recently-used slots are recycled, results stay exact
+    for rep in range(12):
+        keys = [1000 + 4 * rep + k for k in range(4)]
+        pk2 = p0.copy()
+        keyed.optimizeFrames(corr, None, 4, pb.H, pb.W, [d[f] for f in w], None, [n[f] for f in w], pk2, pb.K, frame_keys=keys)
+        assert keyed.last_stats["cache_frames_built"] == 4 and np.array_equal(pk2, pk)
+    # clear: everything is rebuilt
+    frame_cache_clear(ws)
+    keyed.optimizeFrames(corr, None, 4, pb.H, pb.W, [d[f] for f in w], None, [n[f] for f in w], p0.copy(), pb.K, frame_keys=[100 + f for f in w])
+    assert keyed.last_stats["cache_frames_built"] == 4
+    # argument errors: duplicate keys, reference-layout cache, no workspace
+    with pytest.raises(_lib.BtbaError):
+        keyed.optimizeFrames(corr, None, 4, pb.H, pb.W, [d[f] for f in w], None, [n[f] for f in w], p0.copy(), pb.K, frame_keys=[1, 2, 2, 3])
+    f4 = gpu.OptimizerGpu(workspace=ws)
+    f4.params.flags |= _lib.FLAG_FLOAT4_CACHE
+    with pytest.raises(_lib.BtbaError):
+        f4.optimizeFrames(corr, None, 4, pb.H, pb.W, [d[f] for f in w], None, [n[f] for f in w], p0.copy(), pb.K, frame_keys=[1, 2, 3, 4])
+    with pytest.raises(ValueError):
+        gpu.OptimizerGpu(workspace=None).optimizeFrames(corr, None, 4, pb.H, pb.W, [d[f] for f in w], None, [n[f] for f in w], p0.copy(), pb.K, frame_keys=[1, 2, 3, 4])

@@ -13,10 +13,11 @@ from bundletrack_amd.bundler import Bundler, FrameRef, format_pose_txt, load_pos
 from helpers import OracleOptimizer, ParityOptimizer
 
 
-def run_session(optimizer, n_frames, tmp_path=None, to_device=None, max_BA_frames=5):
+def run_session(optimizer, n_frames, tmp_path=None, to_device=None, max_BA_frames=5, persistent_frame_cache=False):
     seq = S.SyntheticSequence(n_frames=n_frames, seed=S.config_seed(1))
     fm = S.SyntheticFeatureManager(seq, corr_per_pair=300)
-    bundler = Bundler(optimizer, fm, seq.K, seq.H, seq.W, window_size=5, max_BA_frames=max_BA_frames, pose_dir=tmp_path)
+    bundler = Bundler(optimizer, fm, seq.K, seq.H, seq.W, window_size=5, max_BA_frames=max_BA_frames, pose_dir=tmp_path,
+                      persistent_frame_cache=persistent_frame_cache)
     errs, frames = [], []
     for k in range(n_frames):
         depth, normals = seq.render(k)
@@ -99,3 +100,25 @@ def test_c1_sliding_window_hip_vs_oracle(oracle, tmp_path):
     print("BA calls: %d, median diff %.2e, over 1e-4: %s" % (len(d), np.median(d), np.round(d[d >= 1e-4], 6).tolist()))
     assert np.median(d) < 1e-5 and (d < 1e-4).mean() >= 0.9 and d.max() < 3e-4, d
     check_session(seq, bundler, frames, errs, n)
+
+
+@pytest.mark.gpu
+def test_session_with_persistent_frame_cache_is_identical():
+    """The tracker hands Frame ids to the optimiser as cache keys: one frame is cached per BA call instead of up to
+    five, and every pose of the session is bit-identical to the stateless path."""
+    import torch
+    from bundletrack_amd.optimizer import OptimizerGpu, Workspace
+    dev = torch.device("cuda:0")
+    up = lambda a: torch.from_numpy(a).to(dev)
+    n = 30
+    a_opt, b_opt = OptimizerGpu(workspace=Workspace()), OptimizerGpu(workspace=Workspace())
+    built = []
+    orig = b_opt.optimizeFrames
+    def counting(*a, **k):
+        r = orig(*a, **k); built.append(b_opt.last_stats["cache_frames_built"]); return r
+    b_opt.optimizeFrames = counting
+    _, _, fa, _ = run_session(a_opt, n, to_device=up)
+    _, _, fb, _ = run_session(b_opt, n, to_device=up, persistent_frame_cache=True)
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x.pose_in_model, y.pose_in_model)
+    assert built[0] == 2 and all(c == 1 for c in built[1:]), built      # first call: frames 0 and 1; afterwards only the new frame
