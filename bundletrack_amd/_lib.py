@@ -29,7 +29,7 @@ ENTRYJ_DTYPE = np.dtype(
 EXPORTED_SYMBOLS = [
     "btba_params_default", "btba_strerror", "btba_last_hip_error", "btba_version",
     "btba_workspace_create", "btba_workspace_create_on_stream", "btba_workspace_destroy", "btba_workspace_sync",
-    "btba_optimize_frames", "btba_optimize_frames_keyed", "btba_frame_cache_clear", "btba_build_cache", "btba_solve_batch", "btba_collect_stats",
+    "btba_optimize_frames", "btba_optimize_frames_keyed", "btba_frame_cache_clear", "btba_ransac_pairs", "btba_build_cache", "btba_solve_batch", "btba_collect_stats",
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
     "btba_process_depth", "btba_depth_to_normals",

@@ -17,6 +17,7 @@
 #include "../../include/btba.h"
 #include "btba_kernels.hpp"
 #include "btba_image.hpp"
+#include "btba_ransac.hpp"
 
 using namespace btba;
 
@@ -75,6 +76,7 @@ struct btba_workspace {
     // live in pool slots that survive across calls; a keyframe is cached once, not once per BA call.
     struct FrameSlot { uint64_t key = 0; const float *depth = nullptr, *normal = nullptr; uint64_t stamp = 0; bool live = false; int32_t n_valid = 0; };
     DevBuf pool_zn, pool_lists, pool_counts, pool_nvalid, pool_map;
+    DevBuf ransac;                                          // btba_ransac_pairs staging (points, samples, per-trial poses and counts, results)
     std::vector<FrameSlot> pool_slots;
     int pool_H = 0, pool_W = 0, pool_npix = 0;
     float pool_downscale = 0.0f, pool_K[9] = {0};
@@ -160,7 +162,7 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts,
-                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map };
+                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->ransac };
     for (auto b : bufs) b->release();
     if (ws->aux_stream) (void)hipStreamDestroy(ws->aux_stream);
     if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
@@ -963,6 +965,66 @@ int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, int n_ins
     Z.zn = zn_dev; Z.H = H; Z.W = W; Z.K = K;
     return solve_enqueue(ws, params, n_instances, n_frames, Hd, Wd, intr, nullptr, nullptr, Z, corr_dev, corr_stride,
                          pair_offsets_dev, max_corr_per_pair, dense_pairs, dense_pairs ? n_dense_pairs : -1, poses_dev, trace_dev);
+}
+
+
+// ---- correspondence RANSAC ---------------------------------------------------------
+int btba_ransac_pairs(btba_workspace *ws, int n_pairs, const float *ptsA_host, const float *ptsB_host, const int32_t *n_pts,
+                      int n_trials, float dist_thres, const int32_t *samples_host, uint64_t seed,
+                      int32_t *inlier_ids_out, int32_t *n_inliers_out, int32_t *best_trial_out, float *best_pose_out,
+                      int32_t *trial_counts_out, float *trial_poses_out)
+{
+    if (!ws || n_pairs < 1 || !n_pts || n_trials < 1 || !(dist_thres >= 0.0f) || !inlier_ids_out || !n_inliers_out) return BTBA_EINVAL;
+    std::vector<int32_t> offsets(n_pairs + 1, 0);
+    for (int p = 0; p < n_pairs; p++) {
+        if (n_pts[p] < 0) return BTBA_EINVAL;
+        offsets[p + 1] = offsets[p] + n_pts[p];
+    }
+    const size_t T = (size_t)offsets[n_pairs], NT = (size_t)n_pairs * n_trials;
+    if (T && (!ptsA_host || !ptsB_host)) return BTBA_EINVAL;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t o = 0;
+    const size_t o_a = o; o += al(16 * (T ? T : 1));
+    const size_t o_b = o; o += al(16 * (T ? T : 1));
+    const size_t o_off = o; o += al(4 * (size_t)(n_pairs + 1));
+    const size_t o_smp = o; o += al(samples_host ? 12 * NT : 4);
+    const size_t o_pose = o; o += al(48 * NT);
+    const size_t o_cnt = o; o += al(4 * NT);
+    const size_t o_best = o; o += al(8 * (size_t)n_pairs);
+    const size_t o_ids = o; o += al(4 * (T ? T : 1));
+    const size_t o_nin = o; o += al(4 * (size_t)n_pairs);
+    const size_t o_bt = o; o += al(4 * (size_t)n_pairs);
+    const size_t o_bp = o; o += al(64 * (size_t)n_pairs);
+    int rc;
+    if ((rc = ws->ransac.ensure(o))) return rc;
+    unsigned char *base = ws->ransac.as<unsigned char>();
+    if (T) {
+        HIP_TRY(hipMemcpyAsync(base + o_a, ptsA_host, 16 * T, hipMemcpyHostToDevice, ws->stream));
+        HIP_TRY(hipMemcpyAsync(base + o_b, ptsB_host, 16 * T, hipMemcpyHostToDevice, ws->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(base + o_off, offsets.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, ws->stream));
+    if (samples_host) HIP_TRY(hipMemcpyAsync(base + o_smp, samples_host, 12 * NT, hipMemcpyHostToDevice, ws->stream));
+    HIP_TRY(hipMemsetAsync(base + o_best, 0, 8 * (size_t)n_pairs, ws->stream));
+    RansacDims D{};
+    D.n_pairs = n_pairs; D.n_trials = n_trials; D.dist_thres = dist_thres; D.seed = seed; D.has_samples = samples_host ? 1 : 0;
+    k_ransac_vote<<<dim3((n_trials + 255) / 256, n_pairs), 256, 0, ws->stream>>>(
+        D, reinterpret_cast<const float4 *>(base + o_a), reinterpret_cast<const float4 *>(base + o_b), reinterpret_cast<const int *>(base + o_off),
+        reinterpret_cast<const int *>(base + o_smp), reinterpret_cast<float *>(base + o_pose), reinterpret_cast<int *>(base + o_cnt),
+        reinterpret_cast<unsigned long long *>(base + o_best));
+    k_ransac_extract<<<n_pairs, 256, 0, ws->stream>>>(
+        D, reinterpret_cast<const float4 *>(base + o_a), reinterpret_cast<const float4 *>(base + o_b), reinterpret_cast<const int *>(base + o_off),
+        reinterpret_cast<const float *>(base + o_pose), reinterpret_cast<const unsigned long long *>(base + o_best),
+        reinterpret_cast<int *>(base + o_ids), reinterpret_cast<int *>(base + o_nin), reinterpret_cast<int *>(base + o_bt), reinterpret_cast<float *>(base + o_bp));
+    HIP_TRY(hipGetLastError());
+    // the inlier lists are written only up to each pair's count: fetch counts first, ids after
+    HIP_TRY(hipMemcpyAsync(n_inliers_out, base + o_nin, 4 * (size_t)n_pairs, hipMemcpyDeviceToHost, ws->stream));
+    if (T) HIP_TRY(hipMemcpyAsync(inlier_ids_out, base + o_ids, 4 * T, hipMemcpyDeviceToHost, ws->stream));
+    if (best_trial_out) HIP_TRY(hipMemcpyAsync(best_trial_out, base + o_bt, 4 * (size_t)n_pairs, hipMemcpyDeviceToHost, ws->stream));
+    if (best_pose_out) HIP_TRY(hipMemcpyAsync(best_pose_out, base + o_bp, 64 * (size_t)n_pairs, hipMemcpyDeviceToHost, ws->stream));
+    if (trial_counts_out) HIP_TRY(hipMemcpyAsync(trial_counts_out, base + o_cnt, 4 * NT, hipMemcpyDeviceToHost, ws->stream));
+    if (trial_poses_out) HIP_TRY(hipMemcpyAsync(trial_poses_out, base + o_pose, 48 * NT, hipMemcpyDeviceToHost, ws->stream));
+    HIP_TRY(hipStreamSynchronize(ws->stream));
+    return BTBA_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,88 @@
+"""Correspondence RANSAC on the MI355X (btba_ransac_pairs) and the caller logic around it.
+
+Mirrors SiftManager::runRansacMultiPairGPU (src/FeatureManager.cpp:659-741) -> ransacMultiPairGPU
+(src/cuda/cuda_ransac.cu:1228-1323): matches are moved into the model frame with the frames' current poses, every
+frame pair votes n_trials 3-point rigid hypotheses, the inliers of the best one survive, and a pair left with fewer
+than 5 matches loses all of them."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+
+def _pts4(p) -> np.ndarray:
+    p = np.asarray(p, np.float32)
+    if p.ndim != 2 or p.shape[1] not in (3, 4):
+        raise ValueError("points must be [n,3] or [n,4]")
+    if p.shape[1] == 3:
+        p = np.concatenate([p, np.ones((p.shape[0], 1), np.float32)], 1)
+    return np.ascontiguousarray(p, np.float32)
+
+
+def ransac_multi_pair(ws, ptsA, ptsB, n_trials: int = 2000, inlier_dist: float = 0.01, samples=None, seed: int = 0,
+                      want_trials: bool = False) -> list[dict]:
+    """ptsA[p], ptsB[p]: [n_p,3|4] model-frame points of frame pair p (A is moved onto B).  samples: optional
+    int32 [n_pairs, n_trials, 3].  Returns one dict per pair: inlier_ids (ascending), best_trial (-1: none),
+    best_pose [4,4], and with want_trials also counts [n_trials] and poses [n_trials,3,4]."""
+    if len(ptsA) != len(ptsB) or len(ptsA) == 0:
+        raise ValueError("need the same, non-zero number of point sets on both sides")
+    A = [_pts4(a) for a in ptsA]
+    B = [_pts4(b) for b in ptsB]
+    n_pts = np.array([a.shape[0] for a in A], np.int32)
+    if any(a.shape != b.shape for a, b in zip(A, B)):
+        raise ValueError("a pair's two point sets must have the same length")
+    n_pairs, T = len(A), int(n_pts.sum())
+    a_all = np.concatenate(A) if T else np.zeros((1, 4), np.float32)
+    b_all = np.concatenate(B) if T else np.zeros((1, 4), np.float32)
+    smp = None
+    if samples is not None:
+        smp = np.ascontiguousarray(samples, np.int32)
+        if smp.shape != (n_pairs, n_trials, 3):
+            raise ValueError("samples must be int32 [n_pairs, n_trials, 3]")
+    ids = np.zeros(max(T, 1), np.int32)
+    n_in = np.zeros(n_pairs, np.int32)
+    best = np.zeros(n_pairs, np.int32)
+    pose = np.zeros((n_pairs, 16), np.float32)
+    counts = np.zeros((n_pairs, n_trials), np.int32) if want_trials else None
+    poses = np.zeros((n_pairs, n_trials, 12), np.float32) if want_trials else None
+    f = lib().btba_ransac_pairs
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_uint64,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    check(f(ws.handle, n_pairs, a_all.ctypes.data, b_all.ctypes.data, n_pts.ctypes.data, int(n_trials), float(inlier_dist),
+            smp.ctypes.data if smp is not None else None, int(seed), ids.ctypes.data, n_in.ctypes.data, best.ctypes.data,
+            pose.ctypes.data, counts.ctypes.data if want_trials else None, poses.ctypes.data if want_trials else None),
+          "btba_ransac_pairs")
+    out, o = [], 0
+    for p in range(n_pairs):
+        r = dict(inlier_ids=ids[o:o + n_in[p]].copy(), best_trial=int(best[p]), best_pose=pose[p].reshape(4, 4).copy())
+        if want_trials:
+            r["counts"], r["poses"] = counts[p], poses[p].reshape(n_trials, 3, 4)
+        out.append(r)
+        o += int(n_pts[p])
+    return out
+
+
+def run_ransac_multi_pair(ws, pairs, matches: dict, n_trials: int = 2000, inlier_dist: float = 0.01, seed: int = 0) -> None:
+    """SiftManager::runRansacMultiPairGPU.  pairs: [(frameA, frameB)] (A newer); matches[(A.id, B.id)] = (ptA_cam,
+    ptB_cam) is replaced IN PLACE by its RANSAC inliers, or emptied when fewer than 5 survive (:733-737)."""
+    keys, A, B = [], [], []
+    for fa, fb in pairs:
+        key = (fa.id, fb.id)
+        pa, pb = matches.get(key, (np.zeros((0, 3), np.float32),) * 2)
+        Ta, Tb = np.asarray(fa.pose_in_model, np.float32), np.asarray(fb.pose_in_model, np.float32)
+        keys.append(key)
+        A.append(np.asarray(pa, np.float32) @ Ta[:3, :3].T + Ta[:3, 3])          # pcl::transformPointWithNormal, fp32
+        B.append(np.asarray(pb, np.float32) @ Tb[:3, :3].T + Tb[:3, 3])
+    if not keys:
+        return
+    res = ransac_multi_pair(ws, A, B, n_trials=n_trials, inlier_dist=inlier_dist, seed=seed)
+    for key, r in zip(keys, res):
+        pa, pb = matches.get(key, (np.zeros((0, 3), np.float32),) * 2)
+        keep = r["inlier_ids"]
+        if len(keep) < 5:
+            matches[key] = (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+        else:
+            matches[key] = (np.asarray(pa, np.float32)[keep], np.asarray(pb, np.float32)[keep])

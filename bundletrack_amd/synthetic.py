@@ -306,8 +306,9 @@ class SyntheticFeatureManager:
     would have pruned by RANSAC beforehand are pruned here with one residual gate."""
 
     def __init__(self, seq: SyntheticSequence, corr_per_pair: int = 300, *, noise_m: float = 0.001, outlier_frac: float = 0.05,
-                 inlier_dist: float = 0.01):
+                 inlier_dist: float = 0.01, ransac=None):
         self.seq, self.m, self.noise_m, self.outlier_frac, self.inlier_dist = seq, corr_per_pair, noise_m, outlier_frac, inlier_dist
+        self.ransac = ransac              # optional callable(pairs, matches): SiftManager::findCorres ends in runRansacBetween (:191)
         self.matches: dict = {}
         self._inv = np.linalg.inv(seq.poses_gt)
         self.gt_index: dict = {}          # frame id -> index into the sequence (ids are re-assigned by Bundler)
@@ -347,6 +348,8 @@ class SyntheticFeatureManager:
             dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
             pa[idx] += dirs * rng.uniform(0.02, 0.05, size=(n_out, 1))
         self.matches[key] = (pa.astype(np.float32), pb.astype(np.float32))
+        if self.ransac is not None:
+            self.ransac([(frameA, frameB)], self.matches)
 
     def procrustes_by_correspondence(self, frameA, frameB) -> np.ndarray:
         from .bundler import solve_rigid_transform_between_points

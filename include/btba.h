@@ -261,6 +261,28 @@ BTBA_API int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, 
                                  const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair,
                                  const int32_t *dense_pairs, int n_dense_pairs, float *poses_dev, float *trace_dev);
 
+/* ---- correspondence RANSAC (the step before correspondences enter BA) ------------
+ * Replaces ransacMultiPairGPU (src/cuda/cuda_ransac.cu:1228-1323) as called by SiftManager::runRansacMultiPairGPU
+ * (FeatureManager.cpp:659-741): for every frame pair, n_trials 3-point rigid hypotheses ptsA -> ptsB, inlier vote with
+ * |ptB - pose ptA| <= dist_thres, the inliers of the best trial.
+ *   ptsA_host / ptsB_host : float4 (x, y, z, 1) points of ALL pairs back to back (model frame, as the reference uploads
+ *                           them); pair p owns n_pts[p] consecutive points.
+ *   samples_host          : NULL, or int32 [n_pairs][n_trials][3] explicit sample indices (the rand_list of
+ *                           ransacMultiPairKernel, :1105).  NULL: drawn on the device as round(u (n-1)) from a counter
+ *                           hash of (seed, pair, trial, draw) -- the reference uses a cuRAND stream per trial, which is
+ *                           not reproducible outside cuRAND.  Trials with repeated / negative / out-of-range indices
+ *                           or (near-)collinear samples are skipped.
+ *   inlier_ids_out        : int32, same layout as the points: pair p's ascending inlier indices in its first
+ *                           n_inliers_out[p] entries.  best_trial_out[p] = -1 when no trial was usable.
+ *   best_pose_out         : may be NULL; float [n_pairs][16] row-major 4x4 of the winning 3-point hypothesis.
+ *   trial_counts_out / trial_poses_out : may be NULL; int32 [n_pairs][n_trials], float [n_pairs][n_trials][12] (3x4).
+ * Best trial = most inliers, lowest trial id among equals (the reference: whichever thread writes last).
+ * Deterministic; synchronous (results valid on return). */
+BTBA_API int btba_ransac_pairs(btba_workspace *ws, int n_pairs, const float *ptsA_host, const float *ptsB_host, const int32_t *n_pts,
+                               int n_trials, float dist_thres, const int32_t *samples_host, uint64_t seed,
+                               int32_t *inlier_ids_out, int32_t *n_inliers_out, int32_t *best_trial_out, float *best_pose_out,
+                               int32_t *trial_counts_out, float *trial_poses_out);
+
 #ifdef __cplusplus
 }
 #endif

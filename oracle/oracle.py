@@ -55,8 +55,8 @@ class OrcTrace(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "btba_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("btba_oracle.c", "btba_oracle_ransac.c", "Makefile"))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
@@ -254,3 +254,49 @@ def depth_to_normals(depth, K):
     normals = np.zeros((H, W, 4), np.float32); xyz = np.zeros((H, W, 4), np.float32)
     lib().orc_depth_to_normals(_p(d), W, H, _p(Ki), _p(normals), _p(xyz))
     return normals, xyz
+
+
+# ---- correspondence RANSAC (oracle/btba_oracle_ransac.c) ------------------------------------------------
+
+def _pts4(p):
+    p = np.asarray(p, np.float32)
+    if p.ndim == 2 and p.shape[1] == 3:
+        p = np.concatenate([p, np.ones((p.shape[0], 1), np.float32)], 1)
+    return np.ascontiguousarray(p, np.float32)
+
+
+def procrustes(src, dst):
+    """procrustesKernel (cuda_ransac.cu:999-1102): (ok, pose[4,4], gap)."""
+    s, d = _pts4(src), _pts4(dst)
+    pose = np.zeros(16, np.float32)
+    gap = C.c_float(0)
+    f = lib().orc_procrustes
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+    ok = f(s.ctypes.data, d.ctypes.data, s.shape[0], pose.ctypes.data, C.byref(gap))
+    return bool(ok), pose.reshape(4, 4), float(gap.value)
+
+
+def ransac_draw(seed, pair, trial, draw, n_pts):
+    f = lib().orc_ransac_draw
+    f.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    f.restype = C.c_int32
+    return int(f(seed, pair, trial, draw, n_pts))
+
+
+def ransac_pair(ptsA, ptsB, n_trials, dist_thres, samples=None, seed=0, pair_id=0):
+    """One frame pair of ransacMultiPairGPU.  Returns dict(inlier_ids, best_trial, best_pose, counts, poses)."""
+    a, b = _pts4(ptsA), _pts4(ptsB)
+    n = a.shape[0]
+    ids = np.zeros(max(n, 1), np.int32)
+    n_in, best = C.c_int32(0), C.c_int32(-1)
+    bp = np.zeros(16, np.float32)
+    counts = np.zeros(n_trials, np.int32)
+    poses = np.zeros((n_trials, 16), np.float32)
+    smp = None if samples is None else np.ascontiguousarray(samples, np.int32).reshape(n_trials, 3)
+    f = lib().orc_ransac_pair
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_int,
+                  C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p]
+    f(a.ctypes.data, b.ctypes.data, n, n_trials, dist_thres, smp.ctypes.data if smp is not None else None, seed, pair_id,
+      ids.ctypes.data, C.byref(n_in), C.byref(best), bp.ctypes.data, counts.ctypes.data, poses.ctypes.data)
+    return dict(inlier_ids=ids[: n_in.value].copy(), best_trial=int(best.value), best_pose=bp.reshape(4, 4), counts=counts,
+                poses=poses.reshape(n_trials, 4, 4))

@@ -13,9 +13,9 @@ from bundletrack_amd.bundler import Bundler, FrameRef, format_pose_txt, load_pos
 from helpers import OracleOptimizer, ParityOptimizer
 
 
-def run_session(optimizer, n_frames, tmp_path=None, to_device=None, max_BA_frames=5, persistent_frame_cache=False):
+def run_session(optimizer, n_frames, tmp_path=None, to_device=None, max_BA_frames=5, persistent_frame_cache=False, ransac=None):
     seq = S.SyntheticSequence(n_frames=n_frames, seed=S.config_seed(1))
-    fm = S.SyntheticFeatureManager(seq, corr_per_pair=300)
+    fm = S.SyntheticFeatureManager(seq, corr_per_pair=300, ransac=ransac)
     bundler = Bundler(optimizer, fm, seq.K, seq.H, seq.W, window_size=5, max_BA_frames=max_BA_frames, pose_dir=tmp_path,
                       persistent_frame_cache=persistent_frame_cache)
     errs, frames = [], []
@@ -122,3 +122,23 @@ def test_session_with_persistent_frame_cache_is_identical():
     for x, y in zip(fa, fb):
         assert np.array_equal(x.pose_in_model, y.pose_in_model)
     assert built[0] == 2 and all(c == 1 for c in built[1:]), built      # first call: frames 0 and 1; afterwards only the new frame
+
+
+@pytest.mark.gpu
+def test_session_with_device_ransac():
+    """The whole device-side chain of a tracked frame: RANSAC prunes every pair's matches (the 5 % gross outliers go,
+    nothing else), Kabsch initialises the pose, bundle adjustment with the persistent frame cache refines the window."""
+    import torch
+    from bundletrack_amd.optimizer import OptimizerGpu, Workspace
+    from bundletrack_amd.ransac import run_ransac_multi_pair
+    dev = torch.device("cuda:0")
+    ws = Workspace()
+    sizes = []
+    def ransac(pairs, matches):
+        run_ransac_multi_pair(ws, pairs, matches, n_trials=2000, inlier_dist=0.01, seed=17)
+        sizes.extend(len(matches[(a.id, b.id)][0]) for a, b in pairs)
+    n = 24
+    seq, bundler, frames, errs = run_session(OptimizerGpu(workspace=ws), n, to_device=lambda a: torch.from_numpy(a).to(dev),
+                                             persistent_frame_cache=True, ransac=ransac)
+    check_session(seq, bundler, frames, errs, n)
+    assert min(sizes) >= 280 and max(sizes) <= 290, (min(sizes), max(sizes))     # 300 matches, 15 planted outliers, 1 mm noise vs 10 mm gate
