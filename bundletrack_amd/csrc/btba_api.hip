@@ -381,7 +381,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.tr_pcg = L.off_pcg; D.tr_delta = L.off_delta; D.tr_dpair = L.off_dense_pair; D.tr_A = L.off_A; D.tr_clk = L.off_clk;
 
     const size_t n = 6 * (size_t)N, ld = 4 * (((n + 3) / 4) | 1);
-    const size_t lds_core = (n * ld + 6 * ld + 16 + 16 * (size_t)N + 4 * (size_t)D.n_dense_pairs + (size_t)N + 1 + (size_t)P) * sizeof(float);
+    const size_t lds_core = (n * ld + 6 * ld + 16 + 16 * (size_t)N + 4 * (size_t)D.n_dense_pairs + (size_t)N + 1 + (size_t)P + 288) * sizeof(float);
     const size_t lds_pairs = ((size_t)P * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals) * sizeof(float);
     const size_t lds_limit = 160 * 1024;
     D.pairsum_in_lds = (lds_core + lds_pairs <= 64 * 1024) ? 1 : 0;   // keep two workgroups per CU when it fits

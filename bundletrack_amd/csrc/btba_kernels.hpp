@@ -723,6 +723,29 @@ __device__ __forceinline__ float sparse_cross_entry(const float *rec, int r, int
     return (rr == cc ? tr : 0.0f) - Mij[cc * 3 + rr];
 }
 
+// Linear form of sparse_diag_entry / sparse_cross_entry: value = c1 rec[i1 + e es] + c2 rec[i2 + e es].
+// Returned as int4 (i1 | es << 8, i2, bits(c1), bits(c2)); es = record offset per endpoint (0 for n and cross blocks).
+__device__ __forceinline__ int4 sparse_entry_descriptor(bool cross, int r, int c)
+{
+    const int br = r / 3, bc = c / 3, rr = r % 3, cc = c % 3;
+    int i1 = 0, i2 = 0, es = 0;
+    float c1 = 0.0f, c2 = 0.0f;
+    const int k = 3 - rr - cc;
+    const float sgn = ((cc - rr + 3) % 3 == 1) ? -1.0f : 1.0f;        // skew(v, rr, cc) = sgn v[k] for rr != cc
+    if (br == 0 && bc == 0) { if (rr == cc) { i1 = 0; c1 = 1.0f; } }
+    else if (br == 0 && bc == 1) { if (rr != cc) { i1 = (cross ? 4 : 1) + k; c1 = -sgn; es = cross ? 0 : 3; } }
+    else if (br == 1 && bc == 0) { if (rr != cc) { i1 = 1 + k; c1 = sgn; es = cross ? 0 : 3; } }
+    else if (rr == cc) {                                               // tr(M) - M_rr = the other two diagonal entries
+        const int a = (rr + 1) % 3, b = (rr + 2) % 3;
+        const int dg[3] = { 0, 3, 5 };
+        i1 = cross ? 19 + 4 * a : 7 + dg[a]; i2 = cross ? 19 + 4 * b : 7 + dg[b]; c1 = 1.0f; c2 = 1.0f; es = cross ? 0 : 6;
+    } else {
+        const int lo = rr < cc ? rr : cc, hi = rr < cc ? cc : rr;
+        i1 = cross ? 19 + cc * 3 + rr : 7 + lo * 3 - lo * (lo - 1) / 2 + (hi - lo); c1 = -1.0f; es = cross ? 0 : 6;
+    }
+    return make_int4(i1 | (es << 8), i2, __float_as_int(c1), __float_as_int(c2));
+}
+
 __device__ __forceinline__ float block_sum(float v, float *scratch)
 {
     // all threads must call; returns the workgroup total to every thread
@@ -769,10 +792,13 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     int *dense_pairs_lds = reinterpret_cast<int *>(vT + 16 * N);   // (target, source) of every dense pair: 2 Pd ints
     int *adj_off_l = dense_pairs_lds + 2 * D.n_dense_pairs, *adj_l = adj_off_l + (N + 1);      // adjacency staged in LDS
     int *pair_ij_l = adj_l + 2 * D.n_dense_pairs;                  // canonical pair p -> (i << 8 | j): P ints
+    // every entry of a sparse 6x6 block is  c1 rec[i1 + e es] + c2 rec[i2 + e es]  of the pair's 44 moment sums (e = which
+    // end of the pair): 36 descriptors for diagonal blocks + 36 for cross blocks, so the assembly loops are branch-free
+    int *entry_lut = pair_ij_l + D.n_pairs;                        // 72 x 4 ints
     // reduced pair sums: in LDS when they fit (address space known at compile time -> ds_* instructions, not flat_*),
     // otherwise in an L2-resident global scratch (K = 30)
     float *ps;
-    if (LDS_PAIRS) ps = reinterpret_cast<float *>(pair_ij_l + D.n_pairs);
+    if (LDS_PAIRS) ps = reinterpret_cast<float *>(entry_lut + 288);
     else ps = pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals);
     float *pd = ps + (size_t)D.n_pairs * kSparseVals;          // model-frame dense pair sums (S, g, count)
     float *pdr = pd + (size_t)D.n_dense_pairs * kDenseVals;     // camera-frame sums as the sweep produced them
@@ -783,6 +809,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     for (int e = tid; e < 16 * N; e += nthr) vT[e] = T[16 * (size_t)b * N + e];
     for (int e = tid; e < D.n_dense_pairs; e += nthr) { const int2 ij = dense_pairs[e]; dense_pairs_lds[2 * e] = ij.x; dense_pairs_lds[2 * e + 1] = ij.y; }
     for (int e = tid; e < D.n_pairs; e += nthr) { int i, j; pair_from_index(e, N, i, j); pair_ij_l[e] = (i << 8) | j; }
+    if (tid < 72) { const int4 d = sparse_entry_descriptor(tid >= 36, (tid % 36) / 6, tid % 6); entry_lut[4 * tid] = d.x; entry_lut[4 * tid + 1] = d.y; entry_lut[4 * tid + 2] = d.z; entry_lut[4 * tid + 3] = d.w; }
     if (D.use_dense) {
         for (int e = tid; e < N + 1; e += nthr) adj_off_l[e] = adj_off[e];
         for (int e = tid; e < 2 * D.n_dense_pairs; e += nthr) adj_l[e] = adj[e];
@@ -877,7 +904,12 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
         const int i = pair_ij_l[p] >> 8, j = pair_ij_l[p] & 255;
         if (i == 0) continue;
         float v = 0.0f;
-        if (D.use_sparse) v -= D.w_sparse * sparse_cross_entry(ps + (size_t)p * kSparseVals, r, c);
+        if (D.use_sparse) {
+            const int *dl = entry_lut + 4 * (36 + e % 36);
+            const int4 d = make_int4(dl[0], dl[1], dl[2], dl[3]);
+            const float *rec = ps + (size_t)p * kSparseVals;
+            v = -D.w_sparse * (__int_as_float(d.z) * rec[d.x & 255] + __int_as_float(d.w) * rec[d.y & 255]);
+        }
         A[(6 * i + r) * ld + 6 * j + c] = v;
         A[(6 * j + c) * ld + 6 * i + r] = v;
     }
@@ -895,45 +927,61 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             A[(6 * ij.y + c) * ld + 6 * ij.x + r] -= s;
         }
     }
-    // Phase B2: diagonal blocks, rhs, preconditioner: thread per (frame k >= 1, entry)
-    for (int e = tid; e < (N - 1) * 36; e += nthr) {
+    // Phase B2: diagonal blocks: TWO lanes per (frame k >= 1, entry), each sums half of the frame's pairs in fixed order
+    for (int t = tid; t < 2 * (N - 1) * 36; t += nthr) {
+        const int e = t >> 1, half = t & 1;
         const int k = 1 + e / 36, r = (e % 36) / 6, c = e % 6;
         float v = 0.0f;
         if (D.use_sparse) {
-            for (int m = 0; m < N; m++) {
+            const int *dl = entry_lut + 4 * (e % 36);
+            const int4 d = make_int4(dl[0], dl[1], dl[2], dl[3]);
+            const int es = d.x >> 8;
+            const float c1 = __int_as_float(d.z), c2 = __int_as_float(d.w);
+            const int m0 = half ? N / 2 : 0, m1 = half ? N : N / 2;
+            float acc = 0.0f;
+            for (int m = m0; m < m1; m++) {
                 if (m == k) continue;
                 const int i = m < k ? m : k, j = m < k ? k : m;
-                v += D.w_sparse * sparse_diag_entry(ps + (size_t)pair_index(i, j, N) * kSparseVals, k == i ? 0 : 1, r, c);
+                const float *rec = ps + (size_t)pair_index(i, j, N) * kSparseVals + (k == i ? 0 : es);
+                acc += c1 * rec[d.x & 255] + c2 * rec[d.y & 255];
             }
+            v = D.w_sparse * acc;
         }
         if (D.use_dense) {
             const int t21 = tri21(r, c);
-            for (int q = adj_off_l[k]; q < adj_off_l[k + 1]; q++) v += pd[(size_t)(adj_l[q] >> 1) * kDenseVals + t21];
+            const int q0 = adj_off_l[k], q1 = adj_off_l[k + 1], qm = q0 + (q1 - q0) / 2;
+            float acc = 0.0f;
+            for (int q = half ? qm : q0; q < (half ? q1 : qm); q++) acc += pd[(size_t)(adj_l[q] >> 1) * kDenseVals + t21];
+            v += acc;
         }
-        A[(6 * k + r) * ld + 6 * k + c] = v;
+        v += __shfl_xor(v, 1, 64);                       // partner lane = same entry, other half (t and t^1 share a wave)
+        if (!half) A[(6 * k + r) * ld + 6 * k + c] = v;
     }
-    for (int e = tid; e < n; e += nthr) {
+    // right-hand side and Jacobi diagonal: FOUR lanes per unknown, each sums a quarter of the frame's pairs
+    for (int t = tid; t < 4 * n; t += nthr) {
+        const int e = t >> 2, part = t & 3;
         const int k = e / 6, r = e % 6;
         float rhs = 0.0f, md = 0.0f;
         if (k > 0) {
             if (D.use_sparse) {
-                for (int m = 0; m < N; m++) {
+                const int m0 = (N * part) / 4, m1 = (N * (part + 1)) / 4;
+                const int o_i = (r < 3) ? 28 + r : 31 + r - 3, o_j = (r < 3) ? 28 + r : 34 + r - 3;       // rhs slots of the i / j end
+                const int p_i = (r < 3) ? 37 : 38 + r - 3, p_j = (r < 3) ? 37 : 41 + r - 3;              // preconditioner slots
+                for (int m = m0; m < m1; m++) {
                     if (m == k) continue;
                     const int i = m < k ? m : k, j = m < k ? k : m;
                     const float *rec = ps + (size_t)pair_index(i, j, N) * kSparseVals;
-                    if (k == i) {
-                        rhs += (r < 3) ? -rec[28 + r] : -rec[31 + r - 3];
-                        md += (r < 3) ? rec[37] : rec[38 + r - 3];
-                    } else {
-                        rhs += (r < 3) ? rec[28 + r] : rec[34 + r - 3];
-                        md += (r < 3) ? rec[37] : rec[41 + r - 3];
-                    }
+                    const bool is_i = (k == i);
+                    const float g = rec[is_i ? o_i : o_j];
+                    rhs += is_i ? -g : g;
+                    md += rec[is_i ? p_i : p_j];
                 }
                 rhs *= D.w_sparse;
             }
             if (D.use_dense) {
+                const int q0 = adj_off_l[k], nq = adj_off_l[k + 1] - q0;
                 float jtr = 0.0f;
-                for (int q = adj_off_l[k]; q < adj_off_l[k + 1]; q++) {
+                for (int q = q0 + (nq * part) / 4; q < q0 + (nq * (part + 1)) / 4; q++) {
                     const int a = adj_l[q];
                     const float g = pd[(size_t)(a >> 1) * kDenseVals + 21 + r];
                     jtr += (a & 1) ? g : -g;            // source frame: row_j = a;  target frame: row_i = -a
@@ -941,9 +989,13 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
                 rhs -= jtr;
             }
         }
-        vb[e] = rhs;
-        vM[e] = (k > 0) ? ((md > kEps) ? 1.0f / md : 1.0f) : 0.0f;
-        vd[e] = 0.0f;
+        rhs += __shfl_xor(rhs, 1, 64); md += __shfl_xor(md, 1, 64);        // the four lanes of an unknown sit in one wave
+        rhs += __shfl_xor(rhs, 2, 64); md += __shfl_xor(md, 2, 64);
+        if (part == 0) {
+            vb[e] = rhs;
+            vM[e] = (k > 0) ? ((md > kEps) ? 1.0f / md : 1.0f) : 0.0f;
+            vd[e] = 0.0f;
+        }
     }
     for (int e = n + tid; e < ld; e += nthr) vp[e] = 0.0f;      // pad of p: read by the 16-byte mat-vec chunks
     __syncthreads();
