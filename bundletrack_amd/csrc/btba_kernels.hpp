@@ -172,17 +172,20 @@ __global__ void __launch_bounds__(kBlock) k_build_cache(int W, int H, int Wd, in
 // intrinsicsInv * (x d, y d, d, d).  Storing only d and re-evaluating that expression with the SAME fp32
 // operations (no contraction) where it is consumed gives bit-identical camera-space points while halving the
 // bytes and the load instructions of the dense sweep (one 16-byte load per tap instead of two).
+// Camera-space point of a cached pixel from its depth.  General intrinsics: the cache builder's arithmetic, term by
+// term (cx, cy = (float) full-resolution column / row of the cached pixel).  SIMPLE (zero skew, affine last row -- every
+// pinhole K): x = K^-1[0][0] (xi d) + K^-1[0][2] d = d (K^-1[0][0] xi + K^-1[0][2]) with the bracket tabulated per
+// column (cx) / row (cy): three multiplies per point instead of nine operations; differs from the builder's rounding
+// sequence by at most 1 ulp per coordinate.
 template <bool SIMPLE>
-__device__ __forceinline__ float3 zn_backproject(const float *ki, float fxi, float fyi, float d)
+__device__ __forceinline__ float3 zn_backproject(const float *ki, float cx, float cy, float d)
 {
 #pragma clang fp contract(off)
-    // fxi, fyi = (float) of the full-res pixel the cache pixel was resampled from (LDS look-up tables).
     // (double)d >= 0.1  <=>  d >= 0.1f  (0.1f is the smallest float above 0.1); below it the reference stores zeros,
     // and with d := 0 every product below is an exact zero as well, so one select replaces three.
     d = (d >= 0.1f) ? d : 0.0f;
-    const float vx = fxi * d, vy = fyi * d;
-    if (SIMPLE)   // the zero terms of the general form add exact zeros
-        return make_float3(ki[0] * vx + ki[2] * d, ki[5] * vy + ki[6] * d, ki[15] * d);
+    if (SIMPLE) return make_float3(cx * d, cy * d, ki[15] * d);
+    const float vx = cx * d, vy = cy * d;
     return make_float3(ki[0] * vx + ki[1] * vy + ki[2] * d + ki[3] * d, ki[4] * vx + ki[5] * vy + ki[6] * d + ki[7] * d,
                        ki[12] * vx + ki[13] * vy + ki[14] * d + ki[15] * d);
 }
@@ -354,11 +357,11 @@ __device__ __forceinline__ PixelGeom pixel_geom(const DenseCtx &C, const float4 
     xform_point(M, cs.x, cs.y, cs.z, g.qx, g.qy, g.qz);
     const float rqz = fast_rcp(g.qz);
     float u = g.qx * C.fx * rqz + C.cx, v = g.qy * C.fy * rqz + C.cy;
-    // NaN / inf / huge coordinates of rejected pixels must not reach the int conversion
-    g.valid = g.valid && (fabsf(u) < 1.0e6f) && (fabsf(v) < 1.0e6f);
+    // in-image test of the rounded coordinates (SolverBundlingDenseUtil.h:91-94) without rounding them:
+    // 0 <= (int)roundf(u) < W  <=>  -0.5 < u < W - 0.5  (round half away from zero; W - 0.5 is exact in fp32).
+    // NaN / inf coordinates of rejected pixels fail the comparisons, so nothing non-finite reaches the int conversions.
+    g.valid = g.valid && (u > -0.5f) && (u < (float)C.W - 0.5f) && (v > -0.5f) && (v < (float)C.H - 0.5f);
     u = g.valid ? u : 0.0f; v = g.valid ? v : 0.0f;
-    const int sx = (int)roundf(u), sy = (int)roundf(v);
-    g.valid = g.valid && (sx >= 0 && sy >= 0 && sx < C.W && sy < C.H);
     // bilinear taps (ICPUtil.h:83-110): out-of-image taps get weight 0, weights renormalised per row, then per column
     const float fx0 = floorf(u), fy0 = floorf(v);
     const int x0 = (int)fx0, y0 = (int)fy0;
@@ -398,10 +401,10 @@ __device__ __forceinline__ void pixel_accumulate(const DenseCtx &C, const PixelG
     const float res = ok ? -(dx * nix + dy * niy + dz * niz) : 0.0f;
     const float e = res * res;
     const float wgt = ok ? C.w_dense * ((e <= C.delta2) ? 1.0f : C.delta * fast_rsq(e)) : 0.0f;
-    // camera-frame row a' = [-n_i ; n_i x q]; rejected pixels contribute exact zeros (0 * NaN would poison the sums)
-    float a[6] = { -nix, -niy, -niz, niy * g.qz - niz * g.qy, niz * g.qx - nix * g.qz, nix * g.qy - niy * g.qx };
-#pragma unroll
-    for (int r = 0; r < 6; r++) a[r] = ok ? a[r] : 0.0f;
+    // camera-frame row a' = [-n_i ; n_i x q]; rejected pixels contribute exact zeros: their blended normal is zeroed
+    // (0 * NaN would poison the sums if a target normal were not finite; q is finite whenever the poses are)
+    const float mx = ok ? nix : 0.0f, my = ok ? niy : 0.0f, mz = ok ? niz : 0.0f;
+    const float a[6] = { -mx, -my, -mz, my * g.qz - mz * g.qy, mz * g.qx - mx * g.qz, mx * g.qy - my * g.qx };
     int k = 0;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
@@ -545,10 +548,13 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
                                                float *__restrict__ partials, int tile, int p, int b, float *red,
                                                const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts, float *lut)
 {
-    // lut[0 .. Wd) = (float) full-res column of cache column x, lut[Wd .. Wd+Hd) the same for rows: five VALU
-    // instructions (int->float, mul, add, float->uint, uint->float) per coordinate become one LDS read
-    for (int e = (int)threadIdx.x; e < D.width + D.height; e += kBlock)
-        lut[e] = (float)(e < D.width ? zn_src_coord(e, D.zn_scale_w) : zn_src_coord(e - D.width, D.zn_scale_h));
+    // lut[0 .. Wd) = (float) full-res column of cache column x, lut[Wd .. Wd+Hd) the same for rows (SIMPLE: already
+    // folded with the inverse intrinsics): the per-coordinate arithmetic becomes one LDS read
+    for (int e = (int)threadIdx.x; e < D.width + D.height; e += kBlock) {
+        const bool is_x = e < D.width;
+        const float c = (float)(is_x ? zn_src_coord(e, D.zn_scale_w) : zn_src_coord(e - D.width, D.zn_scale_h));
+        lut[e] = SIMPLE ? (is_x ? D.zn_ki[0] * c + D.zn_ki[2] : D.zn_ki[5] * c + D.zn_ki[6]) : c;      // see zn_backproject
+    }
     __syncthreads();
     const float *lut_x = lut, *lut_y = lut + D.width;
     const int2 ij = dense_pairs[p];
