@@ -393,11 +393,11 @@ __device__ __forceinline__ void pixel_accumulate(const DenseCtx &C, const PixelG
     const float nix = g.c00 * n00.x + g.c10 * n10.x + g.c01 * n01.x + g.c11 * n11.x;
     const float niy = g.c00 * n00.y + g.c10 * n10.y + g.c01 * n01.y + g.c11 * n11.y;
     const float niz = g.c00 * n00.z + g.c10 * n10.z + g.c01 * n01.z + g.c11 * n11.z;
-    bool ok = g.valid && (ciz > C.depth_min && ciz < C.depth_max);
     const float dx = g.qx - cix, dy = g.qy - ciy, dz = g.qz - ciz;
     const float dist2 = dx * dx + dy * dy + dz * dz;
     const float dn = g.nqx * nix + g.nqy * niy + g.nqz * niz;
-    ok = ok && (dn >= C.normal_thresh) && (dist2 <= C.dist2_thresh);
+    // `&`, not `&&`: short-circuit evaluation turns into nested exec-mask branches with a block of zeroing moves on each
+    const bool ok = g.valid & (ciz > C.depth_min) & (ciz < C.depth_max) & (dn >= C.normal_thresh) & (dist2 <= C.dist2_thresh);
     const float res = ok ? -(dx * nix + dy * niy + dz * niz) : 0.0f;
     const float e = res * res;
     const float wgt = ok ? C.w_dense * ((e <= C.delta2) ? 1.0f : C.delta * fast_rsq(e)) : 0.0f;
@@ -570,7 +570,10 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
     C.normal_thresh = D.normal_thresh; C.dist2_thresh = D.dist_thresh * D.dist_thresh;
     C.delta = D.robust_delta; C.delta2 = D.robust_delta * D.robust_delta; C.w_dense = D.w_dense;
     C.W = D.width; C.H = D.height;
-    const size_t slot_t = frame_slot_of(D, fb + fi), slot_s = frame_slot_of(D, fb + fj);
+    // wave-uniform by construction; readfirstlane tells the compiler, so the frame bases live in SGPRs and the tap
+    // gathers use the scalar-base + 32-bit-offset addressing form
+    const size_t slot_t = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fi));
+    const size_t slot_s = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fj));
     const float4 *zn_t = zn + slot_t * (size_t)D.npix, *zn_s = zn + slot_s * (size_t)D.npix;
     // LISTS: walk the source frame's ordered list of pixels that carry a depth (masked scenes: ~5 % of the image);
     // otherwise walk all pixels with incrementally advanced coordinates.  Two instantiations rather than one loop
@@ -608,7 +611,10 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
         const float3 cp = zn_backproject<SIMPLE>(D.zn_ki, lut_x[px], lut_y[py], zs.x);
         const PixelGeom g = pixel_geom(C, make_float4(cp.x, cp.y, cp.z, 1.0f), make_float4(zs.y, zs.z, zs.w, 0.0f));
         if (__builtin_amdgcn_ballot_w64(g.valid) == 0ull) continue;
-        const float4 z00 = zn_t[g.i00], z10 = zn_t[g.i10], z01 = zn_t[g.i01], z11 = zn_t[g.i11];
+        // 32-bit byte offsets from a scalar base: one shift per tap instead of a 64-bit shift-add (a frame is far below 4 GB)
+        const char *zt = reinterpret_cast<const char *>(zn_t);
+        const float4 z00 = *reinterpret_cast<const float4 *>(zt + ((unsigned)g.i00 << 4)), z10 = *reinterpret_cast<const float4 *>(zt + ((unsigned)g.i10 << 4));
+        const float4 z01 = *reinterpret_cast<const float4 *>(zt + ((unsigned)g.i01 << 4)), z11 = *reinterpret_cast<const float4 *>(zt + ((unsigned)g.i11 << 4));
         const float xia = lut_x[g.xa], xib = lut_x[g.xb], yia = lut_y[g.ya], yib = lut_y[g.yb];
         const float3 c00 = zn_backproject<SIMPLE>(D.zn_ki, xia, yia, z00.x), c10 = zn_backproject<SIMPLE>(D.zn_ki, xib, yia, z10.x);
         const float3 c01 = zn_backproject<SIMPLE>(D.zn_ki, xia, yib, z01.x), c11 = zn_backproject<SIMPLE>(D.zn_ki, xib, yib, z11.x);
