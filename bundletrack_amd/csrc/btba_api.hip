@@ -278,8 +278,10 @@ static int pick_tiles(const btba_params *prm, int B, int Pd, int npix)
 {
     if (prm->dense_tiles > 0) return prm->dense_tiles;
     if (Pd == 0) return 1;
+    // measured with the fused sweep launch at c3 (scripts/ab_dense.py): B=32 2.27 / 2.40 / 2.39 ms per step for 4 / 5 / 6
+    // tiles, B=8 0.871 / 0.886 / 0.874 / 0.900 for 4 / 5 / 6 / 8; a single instance wants 10-15 (0.486 ms) to fill the chip
     const long blocks = (long)B * Pd;
-    int want = (int)((16384 + blocks - 1) / blocks);          // measured at c3 x 32: 482 / 418 / 408 us for 2 / 3 / 5 tiles
+    int want = blocks >= 512 ? 4 : (int)((2048 + blocks - 1) / blocks);
     const int cap = (npix + kBlock - 1) / kBlock;
     if (want > cap) want = cap;
     if (want < 2) want = 2;
@@ -462,9 +464,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             float *tr_h = trace ? trace + b0 * (size_t)D.n_gn * D.trace_record : nullptr;
             size_t slot;
             const unsigned n_d = (unsigned)tiles * D.n_dense_pairs * H.nb, n_s = (unsigned)chunks * P * H.nb;
-            // measured (c3): fused vs separate step time  B=1 0.565 / 0.642 ms, B=8 1.156 / 1.226 ms, B=32 3.573 / 3.557 ms:
-            // at large batches both sweeps are limited by the same L2<->fabric path and do not overlap, so fuse only small ones
-            const bool fuse = use_sparse && use_dense && n_s >= 64 && n_d >= 64 && (H.nb <= 16 || (prm->flags & BTBA_FLAG_FUSE)) &&
+            // one interleaved launch of both sweeps: the dense workgroups are VALU-bound, the sparse ones stream HBM, and the
+            // two fill each other's idle pipes -- measured at c3 (scripts/ab_dense.py, fused vs separate step time):
+            // B=1 0.486 / 0.554 ms, B=8 0.871 / 0.950 ms, B=32 2.271 / 2.380 ms
+            const bool fuse = use_sparse && use_dense && n_s >= 64 && n_d >= 64 &&
                               !(prm->flags & (BTBA_FLAG_NO_FUSE | BTBA_FLAG_DENSE_2PIX | BTBA_FLAG_DENSE_4WAVE));
             if (fuse) {
                 // one launch: HBM-streaming sparse workgroups interleaved with the VALU-bound dense ones

@@ -71,7 +71,7 @@ enum {
                                       btba_optimize_frames decides by itself from the valid-pixel counts unless one of the two is set;
                                       btba_solve_batch_zn (asynchronous, no read-back) uses lists only when this flag is set */
     BTBA_FLAG_FLOAT4_CACHE = 256, /* btba_optimize_frames: build the reference-layout float4 cache instead of the compact one */
-    BTBA_FLAG_FUSE         = 128, /* always do (default: only for batches of <= 16 instances, where it is measured faster) */
+    BTBA_FLAG_FUSE         = 128, /* accepted for compatibility: fusing is the default whenever both sweeps run */
     BTBA_FLAG_OVERLAP      = 32   /* split a batch over two streams (main + low-priority) so one half's k_system_solve
                                      overlaps the other half's dense sweep; per-kernel timings then overlap too */
 };

@@ -1,4 +1,4 @@
-"""A/B of dense-sweep variants and tile counts at the bench workload (c3 x B).  GPU box only."""
+"""A/B of fused / separate sweeps and tile counts at the bench workload (c3 x B, compact cache).  GPU box only."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,21 +16,21 @@ def main():
         pick = [inst[b % 4] for b in range(B)]
         bs0 = BatchSolver(ws)
         corr, offs, mx = bs0.pack_correspondences([p["corr"] for p in pick], 15)
-        cam_d = torch.from_numpy(np.stack([p["campos"] for p in pick])).to(dev); nrm_d = torch.from_numpy(np.stack([p["normals"] for p in pick])).to(dev)
+        zn_d = torch.from_numpy(np.stack([p["zn"] for p in pick])).to(dev)
         corr_d = torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(dev); offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
         poses0 = torch.from_numpy(np.stack([p["poses"] for p in pick])).to(dev)
         ref = None
-        for name, flag in (("default", 0), ("no-fuse", 64)):
-            for tiles in ((3, 5, 8) if B > 1 else (15, 25)):
+        for name, flag in (("no-fuse", 64), ("fuse", 128)):
+            for tiles in ((3, 4, 5, 6, 8) if B > 1 else (5, 8, 10, 15)):
                 bs = BatchSolver(ws, dense_tiles=tiles)
                 bs.params.flags |= _lib.FLAG_TIME_KERNELS | flag
                 poses_d = poses0.clone()
                 for _ in range(2):
-                    poses_d.copy_(poses0); bs.solve(cam_d, nrm_d, pick[0]["intr"], corr_d, offs_d, mx, poses_d)
+                    poses_d.copy_(poses0); bs.solve_zn(zn_d, pick[0]["H"], pick[0]["W"], pick[0]["K"], corr_d, offs_d, mx, poses_d)
                 ws.sync(); ws.collect_stats()
                 t0 = time.perf_counter()
                 for _ in range(5):
-                    poses_d.copy_(poses0); bs.solve(cam_d, nrm_d, pick[0]["intr"], corr_d, offs_d, mx, poses_d)
+                    poses_d.copy_(poses0); bs.solve_zn(zn_d, pick[0]["H"], pick[0]["W"], pick[0]["K"], corr_d, offs_d, mx, poses_d)
                 ws.sync(); dt = (time.perf_counter() - t0) / 5
                 st = ws.collect_stats()
                 out = poses_d.cpu().numpy()
