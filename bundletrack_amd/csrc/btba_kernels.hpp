@@ -398,12 +398,16 @@ __device__ __forceinline__ void pixel_accumulate(const DenseCtx &C, const PixelG
     const float dn = g.nqx * nix + g.nqy * niy + g.nqz * niz;
     // `&`, not `&&`: short-circuit evaluation turns into nested exec-mask branches with a block of zeroing moves on each
     const bool ok = g.valid & (ciz > C.depth_min) & (ciz < C.depth_max) & (dn >= C.normal_thresh) & (dist2 <= C.dist2_thresh);
-    const float res = ok ? -(dx * nix + dy * niy + dz * niz) : 0.0f;
+    // rejected pixels contribute exact zeros.  Bit masks, not `ok ? x : 0`: the compiler turns a run of such selects into
+    // an exec-mask branch with a block of zeroing moves on the other path; AND-ing with 0 / ~0 stays straight-line and is
+    // NaN-safe (0 * NaN would poison the sums if a target normal were not finite; q is finite whenever the poses are)
+    const unsigned keep = ok ? 0xFFFFFFFFu : 0u;
+    auto masked = [keep](float x) { return __uint_as_float(__float_as_uint(x) & keep); };
+    const float res = masked(-(dx * nix + dy * niy + dz * niz));
     const float e = res * res;
-    const float wgt = ok ? C.w_dense * ((e <= C.delta2) ? 1.0f : C.delta * fast_rsq(e)) : 0.0f;
-    // camera-frame row a' = [-n_i ; n_i x q]; rejected pixels contribute exact zeros: their blended normal is zeroed
-    // (0 * NaN would poison the sums if a target normal were not finite; q is finite whenever the poses are)
-    const float mx = ok ? nix : 0.0f, my = ok ? niy : 0.0f, mz = ok ? niz : 0.0f;
+    const float wgt = masked(C.w_dense * ((e <= C.delta2) ? 1.0f : C.delta * fast_rsq(e)));
+    // camera-frame row a' = [-n_i ; n_i x q]
+    const float mx = masked(nix), my = masked(niy), mz = masked(niz);
     const float a[6] = { -mx, -my, -mz, my * g.qz - mz * g.qy, mz * g.qx - mx * g.qz, mx * g.qy - my * g.qx };
     int k = 0;
 #pragma unroll
@@ -413,7 +417,7 @@ __device__ __forceinline__ void pixel_accumulate(const DenseCtx &C, const PixelG
         for (int c = r; c < 6; c++) acc[k++] += wa * a[c];
         acc[21 + r] += wa * res;
     }
-    acc[27] += ok ? 1.0f : 0.0f;
+    acc[27] += masked(1.0f);
 }
 
 // 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).  Lane = consecutive source pixel (coalesced
