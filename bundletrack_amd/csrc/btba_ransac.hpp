@@ -8,8 +8,8 @@
 //              host side                     SiftManager::runRansacMultiPairGPU, FeatureManager.cpp:659-741
 // Design here: ONE vote launch for all pairs -- a lane owns a trial, builds its hypothesis in registers (Horn's
 // closed form: the optimal rotation is the dominant eigenvector of a symmetric 4x4, found by cyclic Jacobi; no
-// 3x3 SVD, no reflection case, no "R is not valid" failure) and walks the pair's points, which every lane reads
-// at the same index (scalar loads, no LDS staging, no flag matrix, no float atomics); the best trial is an
+// 3x3 SVD, no reflection case, no "R is not valid" failure) and walks the pair's points, staged through LDS in tiles
+// that every lane reads at the same index (broadcast reads; no flag matrix, no float atomics); the best trial is an
 // integer atomicMax on (count << 32 | ~trial): deterministic, lowest trial id among equals.  A second small
 // launch re-evaluates the winning pose and writes the ordered inlier list (ballot compaction).
 #pragma once
@@ -163,9 +163,22 @@ __global__ void __launch_bounds__(256) k_ransac_vote(RansacDims D, const float4 
             good = ransac_procrustes3(s, d, P, gap) && gap >= 1e-4f;        // (near-)collinear samples do not define a motion
         }
     }
-    // every lane walks the same point index: uniform addresses -> scalar loads, one fetch per wave
-    if (__builtin_amdgcn_ballot_w64(good) != 0ull)
-        for (int i = 0; i < n; i++) cnt += ransac_is_inlier(P, A[i], B[i], D.dist_thres) ? 1 : 0;
+    // the pair's points go through LDS in tiles of 256 (coalesced 16-byte loads by the whole workgroup); every lane then
+    // reads the SAME point -- an LDS broadcast, conflict-free -- and tests it against its own hypothesis.  (First version:
+    // uniform-address scalar loads straight from global memory; the dependent s_load latency made it 3-4x slower.)
+    __shared__ float4 tileA[256], tileB[256];
+    const bool any_good = __syncthreads_or(good ? 1 : 0) != 0;
+    if (any_good)
+        for (int base = 0; base < n; base += 256) {
+            const int i_ld = min(base + (int)threadIdx.x, n - 1);
+            tileA[threadIdx.x] = A[i_ld];
+            tileB[threadIdx.x] = B[i_ld];
+            __syncthreads();
+            const int m = min(256, n - base);
+#pragma unroll 4
+            for (int i = 0; i < m; i++) cnt += ransac_is_inlier(P, tileA[i], tileB[i], D.dist_thres) ? 1 : 0;
+            __syncthreads();
+        }
     cnt = good ? cnt : 0;
     if (trial < D.n_trials) {
         counts[(size_t)pair * D.n_trials + trial] = cnt;

@@ -22,21 +22,25 @@ def _pts4(p) -> np.ndarray:
     return np.ascontiguousarray(p, np.float32)
 
 
-def ransac_multi_pair(ws, ptsA, ptsB, n_trials: int = 2000, inlier_dist: float = 0.01, samples=None, seed: int = 0,
-                      want_trials: bool = False) -> list[dict]:
-    """ptsA[p], ptsB[p]: [n_p,3|4] model-frame points of frame pair p (A is moved onto B).  samples: optional
-    int32 [n_pairs, n_trials, 3].  Returns one dict per pair: inlier_ids (ascending), best_trial (-1: none),
-    best_pose [4,4], and with want_trials also counts [n_trials] and poses [n_trials,3,4]."""
+def pack_points(ptsA, ptsB):
+    """Per-pair point lists -> the C ABI's layout: (float4 A points back to back, float4 B points, int32 n_pts[n_pairs])."""
     if len(ptsA) != len(ptsB) or len(ptsA) == 0:
         raise ValueError("need the same, non-zero number of point sets on both sides")
     A = [_pts4(a) for a in ptsA]
     B = [_pts4(b) for b in ptsB]
-    n_pts = np.array([a.shape[0] for a in A], np.int32)
     if any(a.shape != b.shape for a, b in zip(A, B)):
         raise ValueError("a pair's two point sets must have the same length")
-    n_pairs, T = len(A), int(n_pts.sum())
+    n_pts = np.array([a.shape[0] for a in A], np.int32)
+    T = int(n_pts.sum())
     a_all = np.concatenate(A) if T else np.zeros((1, 4), np.float32)
     b_all = np.concatenate(B) if T else np.zeros((1, 4), np.float32)
+    return a_all, b_all, n_pts
+
+
+def ransac_packed(ws, a_all, b_all, n_pts, n_trials: int = 2000, inlier_dist: float = 0.01, samples=None, seed: int = 0,
+                  want_trials: bool = False) -> list[dict]:
+    """btba_ransac_pairs on already packed points (see pack_points)."""
+    n_pairs, T = len(n_pts), int(np.sum(n_pts))
     smp = None
     if samples is not None:
         smp = np.ascontiguousarray(samples, np.int32)
@@ -63,6 +67,15 @@ def ransac_multi_pair(ws, ptsA, ptsB, n_trials: int = 2000, inlier_dist: float =
         out.append(r)
         o += int(n_pts[p])
     return out
+
+
+def ransac_multi_pair(ws, ptsA, ptsB, n_trials: int = 2000, inlier_dist: float = 0.01, samples=None, seed: int = 0,
+                      want_trials: bool = False) -> list[dict]:
+    """ptsA[p], ptsB[p]: [n_p,3|4] model-frame points of frame pair p (A is moved onto B).  samples: optional
+    int32 [n_pairs, n_trials, 3].  Returns one dict per pair: inlier_ids (ascending), best_trial (-1: none),
+    best_pose [4,4], and with want_trials also counts [n_trials] and poses [n_trials,3,4]."""
+    a_all, b_all, n_pts = pack_points(ptsA, ptsB)
+    return ransac_packed(ws, a_all, b_all, n_pts, n_trials, inlier_dist, samples, seed, want_trials)
 
 
 def run_ransac_multi_pair(ws, pairs, matches: dict, n_trials: int = 2000, inlier_dist: float = 0.01, seed: int = 0) -> None:
