@@ -304,7 +304,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
 {
     if (!ws || !prm || B < 1 || N < 2 || Hd < 2 || Wd < 2 || !intr || !poses) return BTBA_EINVAL;
     if (prm->n_gn_iters < 1 || prm->n_pcg_iters < 0) return BTBA_EINVAL;   // MLIB_ASSERT, CUDASolverBundling.cpp:194
-    if (N > 40) return BTBA_EINVAL;                                         // 6N x 6N system must fit one CU's LDS
+    if (N > BTBA_MAX_FRAMES) return BTBA_EINVAL;                            // the 6N x 6N system must fit one CU's 160 KB of LDS
     const int P = N * (N - 1) / 2;
     const bool use_sparse = prm->weight_sparse > 0.0f && corr && pair_offsets && max_corr_per_pair > 0;
     // dense pair list

@@ -1028,11 +1028,11 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
 
     BTBA_STAMP(5);
     // Phase C: Jacobi-preconditioned CG, SolverBundling.cu:575-818 (frame 0 entries stay 0).
-    // ONE wave runs it: <= 240 unknowns = <= 4 rows per lane, vectors live in registers, the two dot products per
+    // ONE wave runs it: <= 186 unknowns = <= 3 rows per lane (4 provisioned), vectors live in registers, the two dot products per
     // step are DPP wave sums, only p travels through LDS.  No workgroup barrier inside the iteration (the
     // 16-wave version spent ~6 k cycles per step in barriers; this one ~1 k).
     if (tid < 64) {
-        constexpr int kMaxRows = 4;                     // n = 6N <= 240 (N <= 40 is enforced by the host)
+        constexpr int kMaxRows = 4;                     // n = 6N <= 186 (N <= BTBA_MAX_FRAMES = 31 is enforced by the host)
         const int lane = tid;
         float r_[kMaxRows], m_[kMaxRows], p_[kMaxRows], d_[kMaxRows];
         float part = 0.0f;

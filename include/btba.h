@@ -97,6 +97,11 @@ typedef struct btba_params {
 
 /* Timing / diagnostics filled by the solve entry points (all times in milliseconds, measured
  * with hipEvents on the workspace stream; per-kernel fields need BTBA_FLAG_TIME_KERNELS). */
+/* Largest window: the 6N x 6N normal matrix of an instance lives in one CU's 160 KB of LDS (186 x 188 floats at N = 31).
+ * The reference ships max_BA_frames = 15 (config_ycbineoat.yml:27) and spins forever above 85 frames
+ * (SolverBundling.cu:621-625); here a larger window is BTBA_EINVAL. */
+#define BTBA_MAX_FRAMES 31
+
 typedef struct btba_stats {
     int32_t n_instances, n_frames, n_pairs, n_dense_pairs;
     int64_t n_corr;               /* total correspondences over all instances                          */

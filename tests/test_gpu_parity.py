@@ -518,3 +518,60 @@ def test_persistent_frame_cache(gpu, background):
         f4.optimizeFrames(corr, None, 4, pb.H, pb.W, [d[f] for f in w], None, [n[f] for f in w], p0.copy(), pb.K, frame_keys=[1, 2, 3, 4])
     with pytest.raises(ValueError):
         gpu.OptimizerGpu(workspace=None).optimizeFrames(corr, None, 4, pb.H, pb.W, [d[f] for f in w], None, [n[f] for f in w], p0.copy(), pb.K, frame_keys=[1, 2, 3, 4])
+
+
+def test_edge_shapes_through_the_boundary(gpu, oracle):
+    """Sizes at the edges of what the boundary accepts, each against the oracle: the largest window (N = 31, the 186
+    unknowns whose normal matrix fits one CU's LDS), a frame size that is not a multiple of the downscale, ragged correspondence
+    segments (empty pairs next to full ones), frames without a single valid pixel, and N = 41 rejected with a status."""
+    opt = gpu.OptimizerGpu(workspace=gpu.ws)
+
+    def run(pb, corr=None, depth=None, normals=None):
+        corr = pb.corr if corr is None else corr
+        depth = pb.depth if depth is None else depth
+        normals = pb.normals if normals is None else normals
+        d = [gpu.torch.from_numpy(depth[k]).to(gpu.dev) for k in range(pb.n_frames)]
+        n = [gpu.torch.from_numpy(normals[k]).to(gpu.dev) for k in range(pb.n_frames)]
+        caches = [oracle.build_cache(depth[k], normals[k], pb.K, pb.downscale) for k in range(pb.n_frames)]
+        ref = oracle.solve(np.stack([c["campos"] for c in caches]), np.stack([c["normals"] for c in caches]), caches[0]["intr"], corr, pb.poses_init)
+        poses = pb.poses_init.copy()
+        opt.optimizeFrames(corr, None, pb.n_frames, pb.H, pb.W, d, None, n, poses, pb.K)
+        worst = max(max(S.pose_error(poses[k], ref.poses[k])) for k in range(pb.n_frames))
+        assert np.isfinite(poses).all()
+        return worst, poses, d, n
+
+    # N = 31 (BTBA_MAX_FRAMES) on small frames (128 x 96 -> 32 x 24 cache; intrinsics scaled with the image)
+    Ks = S.NOCS_K.copy(); Ks[:2] *= 0.2
+    big = S.make_problem(31, 12, seed=91, background=False, H=96, W=128, K=Ks, rot_step_deg=(5.0, 6.0))
+    worst, _, dN, nN = run(big)
+    print(f"N=31: worst pose diff {worst:.2e}")
+    assert worst < TOL_R, worst                          # 465 pairs of 12 matches, 186 unknowns
+    with pytest.raises(_lib.BtbaError) as e:             # N = 32 does not fit; a status, not `while(1);` (SolverBundling.cu:621-625)
+        opt.optimizeFrames(big.corr[:0], None, 32, big.H, big.W, dN + dN[:1], None, nN + nN[:1], np.tile(np.eye(4, dtype=np.float32), (32, 1, 1)), big.K)
+    assert e.value.status == _lib.BTBA_EINVAL
+    # 53 x 37 frames: int(W / 4) = 13, int(H / 4) = 9 (LossGPU.cu:56-57), nearest-neighbour resample with fractional scales
+    Ko = S.NOCS_K.copy(); Ko[0] *= 53 / 640; Ko[1] *= 37 / 480
+    odd = S.make_problem(4, 150, seed=92, background=True, H=37, W=53, K=Ko)
+    worst, _, _, _ = run(odd)
+    assert worst < TOL_R, worst
+    # ragged segments: two pairs lose every correspondence, one keeps a single one
+    pb = S.make_problem(5, 200, seed=93, background=False)
+    keep = np.ones(len(pb.corr), bool)
+    i, j = pb.corr["imgIdx_i"], pb.corr["imgIdx_j"]
+    keep[(i == 0) & (j == 1)] = False
+    keep[(i == 2) & (j == 3)] = False
+    one = np.nonzero((i == 1) & (j == 4))[0]
+    keep[one[1:]] = False
+    worst, _, _, _ = run(pb, corr=pb.corr[keep])
+    assert worst < TOL_R, worst
+    # a window whose frames carry no depth at all: the dense term vanishes, the feature term alone drives the solve
+    zd, zn = np.zeros_like(pb.depth), np.zeros_like(pb.normals)
+    worst, poses_nodepth, _, _ = run(pb, depth=zd, normals=zn)
+    assert worst < TOL_R, worst
+    sparse_only = gpu.OptimizerGpu(workspace=gpu.ws)
+    sparse_only.params.weight_dense_depth = 0.0
+    p2 = pb.poses_init.copy()
+    d = [gpu.torch.from_numpy(pb.depth[k]).to(gpu.dev) for k in range(pb.n_frames)]
+    n = [gpu.torch.from_numpy(pb.normals[k]).to(gpu.dev) for k in range(pb.n_frames)]
+    sparse_only.optimizeFrames(pb.corr, None, pb.n_frames, pb.H, pb.W, d, None, n, p2, pb.K)
+    assert max(max(S.pose_error(poses_nodepth[k], p2[k])) for k in range(pb.n_frames)) < 2e-6
