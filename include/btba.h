@@ -60,20 +60,21 @@ enum {
 };
 
 enum {
-    BTBA_FLAG_TRACE        = 1,   /* record per-GN-iterate trace (btba_trace_layout)                    */
-    BTBA_FLAG_TIME_KERNELS = 2,   /* bracket every sweep / solve launch with hipEvents (btba_stats)    */
-    BTBA_FLAG_NO_GRAPH     = 4,   /* launch kernels eagerly instead of replaying the captured hipGraph */
-    BTBA_FLAG_DENSE_2PIX   = 8,   /* tuning: dense sweep variant with two pixels per lane per trip     */
-    BTBA_FLAG_DENSE_4WAVE  = 16,  /* tuning: one pixel per trip, registers capped for 4 waves per SIMD (spills) */
-    BTBA_FLAG_NO_FUSE      = 64,  /* never launch the sparse and the dense sweep as one interleaved launch */
-    BTBA_FLAG_NO_COMPACTION = 512, /* compact cache: always walk all Wd x Hd source pixels */
-    BTBA_FLAG_COMPACTION   = 1024, /* compact cache: walk each source frame's ordered list of pixels that carry a depth (masked scenes).
-                                      btba_optimize_frames decides by itself from the valid-pixel counts unless one of the two is set;
-                                      btba_solve_batch_zn (asynchronous, no read-back) uses lists only when this flag is set */
-    BTBA_FLAG_FLOAT4_CACHE = 256, /* btba_optimize_frames: build the reference-layout float4 cache instead of the compact one */
-    BTBA_FLAG_FUSE         = 128, /* accepted for compatibility: fusing is the default whenever both sweeps run */
-    BTBA_FLAG_OVERLAP      = 32   /* split a batch over two streams (main + low-priority) so one half's k_system_solve
-                                     overlaps the other half's dense sweep; per-kernel timings then overlap too */
+    BTBA_FLAG_TRACE         = 1,    /* record per-GN-iterate trace (btba_trace_layout)                            */
+    BTBA_FLAG_TIME_KERNELS  = 2,    /* bracket every sweep / solve launch with hipEvents (btba_stats)             */
+    BTBA_FLAG_RESERVED_4    = 4,    /* unused                                                                     */
+    BTBA_FLAG_DENSE_2PIX    = 8,    /* tuning, reference-layout cache only: dense sweep with two pixels per lane per trip */
+    BTBA_FLAG_DENSE_4WAVE   = 16,   /* tuning, reference-layout cache only: registers capped for 4 waves per SIMD */
+    BTBA_FLAG_OVERLAP       = 32,   /* split a batch over two streams (main + low-priority) so one half's k_system_solve
+                                       overlaps the other half's sweeps; per-kernel timings then overlap too (+4 % at c3 x 32) */
+    BTBA_FLAG_NO_FUSE       = 64,   /* launch the sparse and the dense sweep separately (default: ONE interleaved launch) */
+    BTBA_FLAG_FUSE          = 128,  /* accepted for compatibility: fusing is the default whenever both sweeps run  */
+    BTBA_FLAG_FLOAT4_CACHE  = 256,  /* btba_optimize_frames: build the reference-layout float4 cache instead of the compact one */
+    BTBA_FLAG_NO_COMPACTION = 512,  /* compact cache: always walk all Wd x Hd source pixels                        */
+    BTBA_FLAG_COMPACTION    = 1024  /* compact cache: walk each source frame's ordered list of pixels that carry a depth
+                                       (masked scenes).  btba_optimize_frames decides by itself from the valid-pixel counts
+                                       unless one of the two is set; btba_solve_batch_zn (asynchronous, no read-back) uses
+                                       lists only when this flag is set */
 };
 
 /* Solver parameters.  Defaults = shipping config of the reference:
