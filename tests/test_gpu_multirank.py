@@ -1,0 +1,35 @@
+"""bench.py's N > 1 path on the GPU box: two ranks launched exactly as the driver launches them
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2`).  A gpurun box has one GPU, so
+both ranks share it (bench.py maps LOCAL_RANK modulo the device count) and the closing all-gather runs on gloo
+(BTBA_DIST_BACKEND) -- RCCL refuses two ranks on one device; on a real node the same code runs one rank per GPU on nccl.
+Checks the contract: one JSON line from rank 0, whole-job value = all ranks' iterations / slowest rank's time."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_through_torchrun():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, BTBA_DIST_BACKEND="gloo", BTBA_BENCH_NPROC="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--instances", "4", "--distinct", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                           # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert len(d["per_rank"]) == 2
+    total = sum(r["gn_iters"] for r in d["per_rank"])
+    slowest = max(r["seconds"] for r in d["per_rank"])
+    assert total == 2 * 4 * 7 * 3                                    # ranks x instances x GN iterations x steps
+    assert abs(d["value"] - total / slowest) <= 1e-3 * d["value"]
+    assert d["config"]["instances_per_gpu"] == 4
