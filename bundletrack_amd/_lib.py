@@ -93,6 +93,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+HOST_DRIVER = os.path.join(os.path.dirname(_PKG), "tests", "cpp", "host_driver")
+
+
+def build_host_cpp(force: bool = False, verbose: bool = False) -> str:
+    """Compile the C++ host layer (bundletrack_amd/cpp) and its test driver against libbtba.so."""
+    root = os.path.dirname(_PKG)
+    srcs = [os.path.join(root, "tests", "cpp", "host_driver.cpp"), os.path.join(_PKG, "cpp", "btba_host.cpp")]
+    deps = srcs + [os.path.join(_PKG, "cpp", "btba_host.hpp"), HEADER, LIB_PATH]
+    if not force and os.path.exists(HOST_DRIVER) and os.path.getmtime(HOST_DRIVER) >= max(os.path.getmtime(d) for d in deps):
+        return HOST_DRIVER
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-o", HOST_DRIVER] + srcs + [
+        "-L" + _PKG, "-lbtba", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+        "-Wl,-rpath," + _PKG, "-Wl,-rpath,$ORIGIN/../../bundletrack_amd", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_DRIVER
+
+
 _lib = None
 
 

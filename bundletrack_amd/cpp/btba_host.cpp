@@ -1,0 +1,129 @@
+// btba_host.cpp -- see btba_host.hpp.  Plain C++17 on top of include/btba.h.
+#include "btba_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace btba {
+
+OptimizerGpu::OptimizerGpu(std::shared_ptr<Config> yml1) : yml(std::move(yml1))
+{
+    if (!yml) yml = std::make_shared<Config>();
+    const int rc = btba_workspace_create(&ws_, nullptr);
+    if (rc != BTBA_OK) throw Error(rc, "btba_workspace_create");
+}
+
+OptimizerGpu::~OptimizerGpu() { btba_workspace_destroy(ws_); }
+
+void OptimizerGpu::optimizeFrames(const std::vector<EntryJ> &global_corres, const std::vector<int> &n_match_per_pair, int n_frames, int H, int W,
+                                  const std::vector<float *> &depths_gpu, const std::vector<uchar4 *> & /*colors_gpu*/, const std::vector<float4 *> &normals_gpu,
+                                  std::vector<Matrix4f> &poses, const Matrix3f &K)
+{
+    if ((int)depths_gpu.size() != n_frames || (int)normals_gpu.size() != n_frames || (int)poses.size() != n_frames) throw Error(BTBA_EINVAL, "optimizeFrames");
+    btba_params prm;
+    btba_params_default(&prm);
+    prm.n_gn_iters = yml->num_iter_outter;                      // CUDASolverBundling.cpp:193
+    prm.n_pcg_iters = yml->num_iter_inner;
+    prm.robust_delta = yml->robust_delta;
+    prm.image_downscale = yml->image_downscale;                 // LossGPU.cu:55
+    prm.dense_dist_thresh = yml->p2p_max_dist;                  // CUDASolverBundling.cpp:93
+    prm.dense_normal_thresh = std::cos(yml->p2p_max_normal_angle / 180.0 * M_PI);      // :94
+    float Krm[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Krm[3 * r + c] = K(r, c);
+    std::vector<float> P(16 * (size_t)n_frames);                // column-major Eigen -> row-major float4x4, LossGPU.cu:88-97
+    for (int i = 0; i < n_frames; i++) for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) P[16 * (size_t)i + 4 * r + c] = poses[i](r, c);
+    std::vector<const float *> depth(n_frames), nrm(n_frames);
+    for (int i = 0; i < n_frames; i++) { depth[i] = depths_gpu[i]; nrm[i] = reinterpret_cast<const float *>(normals_gpu[i]); }
+    int rc;
+    if (persistent_frame_cache) {
+        if ((int)frame_ids.size() != n_frames) throw Error(BTBA_EINVAL, "optimizeFrames: frame_ids");
+        rc = btba_optimize_frames_keyed(ws_, &prm, n_frames, H, W, Krm, global_corres.data(), (uint32_t)global_corres.size(), n_match_per_pair.data(),
+                                        depth.data(), nrm.data(), frame_ids.data(), nullptr, 0, P.data(), &last_stats);
+    } else {
+        rc = btba_optimize_frames(ws_, &prm, n_frames, H, W, Krm, global_corres.data(), (uint32_t)global_corres.size(), n_match_per_pair.data(),
+                                  depth.data(), nrm.data(), nullptr, 0, P.data(), &last_stats);
+    }
+    if (rc != BTBA_OK) throw Error(rc, "btba_optimize_frames");
+    for (int i = 0; i < n_frames; i++) for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) poses[i](r, c) = P[16 * (size_t)i + 4 * r + c];      // :121-130
+}
+
+float rotationGeodesicDistance(const Matrix4f &A, const Matrix4f &B)
+{
+    float tr = 0.0f;                                            // trace(R1 R2^T) = sum_ij R1_ij R2_ij
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) tr += A(i, j) * B(i, j);
+    float tmp = (tr - 1.0f) / 2.0f;
+    tmp = std::max(std::min(1.0f, tmp), -1.0f);
+    return std::acos(tmp);
+}
+
+Window marshalWindow(std::vector<std::shared_ptr<Frame>> local_frames, const std::map<std::pair<int, int>, Correspondences> &matches,
+                     const std::shared_ptr<Frame> &newframe, int min_fm_edges_newframe)
+{
+    Window w;
+    std::sort(local_frames.begin(), local_frames.end(), [](const std::shared_ptr<Frame> &a, const std::shared_ptr<Frame> &b) { return a->_id < b->_id; });   // :286
+    for (size_t i = 0; i < local_frames.size(); i++)
+        for (size_t j = i + 1; j < local_frames.size(); j++) {
+            const auto &frameA = local_frames[j], &frameB = local_frames[i];
+            const auto it = matches.find({ frameA->_id, frameB->_id });
+            int m = 0;
+            if (it != matches.end()) {
+                m = (int)(it->second.ptA_cam.size() / 3);
+                for (int k = 0; k < m; k++) {
+                    EntryJ e;
+                    e.imgIdx_i = (uint32_t)i; e.imgIdx_j = (uint32_t)j;                      // :311-316: pos_j = ptA, pos_i = ptB
+                    for (int c = 0; c < 3; c++) { e.pos_j[c] = it->second.ptA_cam[3 * k + c]; e.pos_i[c] = it->second.ptB_cam[3 * k + c]; }
+                    w.global_corres.push_back(e);
+                    if (frameA == newframe || frameB == newframe) w.n_edges_newframe++;
+                }
+            }
+            w.n_match_per_pair.push_back(m);
+        }
+    w.frames = std::move(local_frames);
+    w.run_ba = w.n_edges_newframe > min_fm_edges_newframe;
+    if (!w.run_ba) newframe->_status = Frame::NO_BA;
+    return w;
+}
+
+bool KeyframeMemory::checkAndAddKeyframe(const std::shared_ptr<Frame> &frame)
+{
+    if (frame->_id == 0) { _keyframes.push_back(frame); return true; }
+    if (frame->_status != Frame::OTHER) return false;
+    if (frame->_n_keypts < yml->keyframe_min_feat_num) return false;
+    for (const auto &kf : _keyframes) {
+        float rot_diff = rotationGeodesicDistance(frame->_pose_in_model, kf->_pose_in_model);
+        rot_diff = rot_diff * 180.0f / (float)M_PI;
+        if (rot_diff < yml->keyframe_min_rot) return false;
+    }
+    _keyframes.push_back(frame);
+    return true;
+}
+
+std::vector<std::shared_ptr<Frame>> KeyframeMemory::selectKeyFramesForBA(const std::shared_ptr<Frame> &newframe)
+{
+    std::vector<std::shared_ptr<Frame>> frames = { newframe };       // insertion order (the reference: a std::set in pointer order)
+    auto has = [&](const std::shared_ptr<Frame> &f) { return std::find(frames.begin(), frames.end(), f) != frames.end(); };
+    auto by_id = [](const std::shared_ptr<Frame> &a, const std::shared_ptr<Frame> &b) { return a->_id < b->_id; };
+    if ((int)(_keyframes.size() + frames.size()) <= yml->max_BA_frames) {
+        for (const auto &kf : _keyframes) if (!has(kf)) frames.push_back(kf);
+        std::sort(frames.begin(), frames.end(), by_id);
+        return frames;
+    }
+    if (!has(_keyframes[0])) frames.push_back(_keyframes[0]);
+    while ((int)frames.size() < yml->max_BA_frames) {                // "greedy_rot"
+        float best_dist = std::numeric_limits<float>::max();
+        std::shared_ptr<Frame> best_kf;
+        for (const auto &kf : _keyframes) {
+            if (has(kf)) continue;
+            float cum_dist = 0.0f;
+            for (const auto &f : frames) cum_dist += rotationGeodesicDistance(kf->_pose_in_model, f->_pose_in_model);
+            if (cum_dist < best_dist) { best_dist = cum_dist; best_kf = kf; }
+        }
+        if (!best_kf) break;
+        frames.push_back(best_kf);
+    }
+    std::sort(frames.begin(), frames.end(), by_id);
+    return frames;
+}
+
+}  // namespace btba

@@ -1,0 +1,119 @@
+// btba_host.hpp -- the host side above the C ABI, in C++ like the reference's own host code.
+//
+// Mirrors, name for name and argument for argument, what sits on either side of the optimiser boundary in
+// wenbowen123/BundleTrack:
+//   OptimizerGpu::optimizeFrames                        src/cuda/LossGPU.h:40-52, LossGPU.cu:53-139
+//   Bundler::optimizeGPU's marshalling                  src/Bundler.cpp:286-347   (marshalWindow)
+//   Bundler::checkAndAddKeyframe / selectKeyFramesForBA src/Bundler.cpp:185-274   (KeyframeMemory)
+//   Utils::rotationGeodesicDistance                     src/Utils.cpp:42-47
+//   Utils::solveRigidTransformBetweenPoints             src/Utils.cpp:180-214     (only declared here: needs an SVD; the
+//                                                        Python mirror in bundletrack_amd/bundler.py carries it)
+// The reference builds these on Eigen, yaml-cpp and PCL, none of which exist in this image, so the two value types
+// the interface needs are defined here with Eigen's conventions (column-major storage, (row, col) access): a
+// maintainer swaps `btba::Matrix4f` for `Eigen::Matrix4f` and `btba::Config` for the YAML node and nothing else
+// changes.  Only libbtba.so's C ABI (include/btba.h) is called: plain host C++ (g++), no
+// device code, no torch; HIP contributes the float4 / uchar4 pixel types only.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include <hip/hip_vector_types.h>     // float4, uchar4: the device pixel types of the reference's signatures (plain structs on the host)
+
+#include "../../include/btba.h"
+
+namespace btba {
+
+struct Matrix4f {                      // Eigen::Matrix4f: column-major
+    float d[16];
+    float &operator()(int r, int c) { return d[c * 4 + r]; }
+    float operator()(int r, int c) const { return d[c * 4 + r]; }
+    static Matrix4f Identity() { Matrix4f M{}; for (int k = 0; k < 4; k++) M(k, k) = 1.0f; return M; }
+};
+struct Matrix3f {                      // Eigen::Matrix3f: column-major
+    float d[9];
+    float &operator()(int r, int c) { return d[c * 3 + r]; }
+    float operator()(int r, int c) const { return d[c * 3 + r]; }
+};
+
+using EntryJ = btba_entryj;            // src/cuda/SIFTImageManager.h:44-59, 32 bytes
+
+// The keys of config_ycbineoat.yml the path reads (at their shipping values): bundle.* :23-36, p2p.* :63-65
+struct Config {
+    int num_iter_outter = 7, num_iter_inner = 5;
+    float robust_delta = 0.005f, image_downscale = 4.0f;
+    float p2p_max_dist = 0.02f, p2p_max_normal_angle = 45.0f;
+    int max_BA_frames = 15, min_fm_edges_newframe = 5;
+    float keyframe_min_rot = 10.0f;
+    int keyframe_min_feat_num = 0;
+};
+
+class Error : public std::runtime_error {       // the reference exits / spins instead (cutil_inline_runtime.h:261-269)
+public:
+    int status;
+    Error(int status_, const std::string &where) : std::runtime_error(where + ": " + btba_strerror(status_)), status(status_) {}
+};
+
+class OptimizerGpu {
+public:
+    std::shared_ptr<Config> yml;
+    btba_stats last_stats{};
+    bool persistent_frame_cache = false;         // hand frame ids to btba_optimize_frames_keyed (needs frame_ids below)
+    std::vector<uint64_t> frame_ids;             // Frame::_id of every window frame, when persistent_frame_cache is set
+
+    explicit OptimizerGpu(std::shared_ptr<Config> yml1);
+    ~OptimizerGpu();
+    OptimizerGpu(const OptimizerGpu &) = delete;
+    OptimizerGpu &operator=(const OptimizerGpu &) = delete;
+
+    // LossGPU.h:50.  poses: camera -> model, updated in place; colors_gpu ignored (weight 0, SBA.cpp:32).
+    void optimizeFrames(const std::vector<EntryJ> &global_corres, const std::vector<int> &n_match_per_pair, int n_frames, int H, int W,
+                        const std::vector<float *> &depths_gpu, const std::vector<uchar4 *> &colors_gpu, const std::vector<float4 *> &normals_gpu,
+                        std::vector<Matrix4f> &poses, const Matrix3f &K);
+
+private:
+    btba_workspace *ws_ = nullptr;               // grow-only scratch kept across calls (the reference reallocates everything)
+};
+
+// ---- the caller's side -------------------------------------------------------------------------------------
+struct Frame {                                   // the fields of Frame (src/Frame.h:45-96) the BA caller touches
+    enum Status { FAIL, NO_BA, OTHER };
+    int _id = 0;
+    Status _status = OTHER;
+    Matrix4f _pose_in_model = Matrix4f::Identity();
+    int _n_keypts = 0;
+    float *_depth_gpu = nullptr;
+    float4 *_normal_gpu = nullptr;
+    uchar4 *_color_gpu = nullptr;
+};
+
+float rotationGeodesicDistance(const Matrix4f &A, const Matrix4f &B);           // rotation blocks only, radians (Utils.cpp:42-47)
+
+struct Correspondences { std::vector<float> ptA_cam, ptB_cam; };                // xyz triples; A = the newer frame
+
+struct Window {                                                                  // what optimizeGPU hands to optimizeFrames
+    std::vector<std::shared_ptr<Frame>> frames;                                  // sorted by id: index 0 is never moved
+    std::vector<EntryJ> global_corres;
+    std::vector<int> n_match_per_pair;
+    int n_edges_newframe = 0;
+    bool run_ba = false;                                                         // false <=> newframe->_status = NO_BA (:343-347)
+};
+// Bundler.cpp:286-347.  matches: keyed by (newer frame id, older frame id) like _fm->_matches[{frameA, frameB}].
+Window marshalWindow(std::vector<std::shared_ptr<Frame>> local_frames, const std::map<std::pair<int, int>, Correspondences> &matches,
+                     const std::shared_ptr<Frame> &newframe, int min_fm_edges_newframe);
+
+class KeyframeMemory {
+public:
+    std::vector<std::shared_ptr<Frame>> _keyframes;
+    explicit KeyframeMemory(std::shared_ptr<Config> yml1) : yml(std::move(yml1)) {}
+    bool checkAndAddKeyframe(const std::shared_ptr<Frame> &frame);                                     // Bundler.cpp:185-219
+    std::vector<std::shared_ptr<Frame>> selectKeyFramesForBA(const std::shared_ptr<Frame> &newframe);  // :222-274, sorted by id
+private:
+    std::shared_ptr<Config> yml;
+};
+
+}  // namespace btba

@@ -1,0 +1,129 @@
+// host_driver.cpp -- test driver for the C++ host layer (bundletrack_amd/cpp/btba_host.*): what Bundler.cpp does with
+// OptimizerGpu, on a problem dumped by the Python tests.  Built by __graft_entry__.build().
+//   host_driver ba <problem.bin> <poses_out.bin>        window -> marshalWindow -> OptimizerGpu::optimizeFrames (GPU)
+//   host_driver keyframes <poses.bin> <ids_out.bin>     checkAndAddKeyframe over a pose sequence + selectKeyFramesForBA (CPU)
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <random>
+
+#include "../../bundletrack_amd/cpp/btba_host.hpp"
+
+using namespace btba;
+
+template <class T> static void rd(std::ifstream &f, T *p, size_t n) { f.read(reinterpret_cast<char *>(p), sizeof(T) * n); if (!f) throw std::runtime_error("short read"); }
+#define HIP_OK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { std::fprintf(stderr, "HIP error %d at %s:%d\n", (int)e_, __FILE__, __LINE__); return 3; } } while (0)
+
+static Matrix4f from_rowmajor(const float *m) { Matrix4f M; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) M(r, c) = m[4 * r + c]; return M; }
+
+static int run_ba(const char *in, const char *out)
+{
+    std::ifstream f(in, std::ios::binary);
+    int32_t hdr[4];
+    rd(f, hdr, 4);
+    const int N = hdr[0], H = hdr[1], W = hdr[2], C = hdr[3];
+    float Krm[9];
+    rd(f, Krm, 9);
+    std::vector<EntryJ> corr(C);
+    rd(f, corr.data(), C);
+    std::vector<float> P(16 * (size_t)N);
+    rd(f, P.data(), P.size());
+    Matrix3f K;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) K(r, c) = Krm[3 * r + c];
+    // frames with non-contiguous ids, handed over in shuffled order: marshalWindow sorts by id (Bundler.cpp:286)
+    std::vector<std::shared_ptr<Frame>> frames(N);
+    std::vector<float> buf((size_t)H * W * 4);
+    for (int k = 0; k < N; k++) {
+        auto fr = std::make_shared<Frame>();
+        fr->_id = 10 * k + 3;
+        fr->_pose_in_model = from_rowmajor(&P[16 * (size_t)k]);
+        rd(f, buf.data(), (size_t)H * W);
+        HIP_OK(hipMalloc(reinterpret_cast<void **>(&fr->_depth_gpu), sizeof(float) * H * W));
+        HIP_OK(hipMemcpy(fr->_depth_gpu, buf.data(), sizeof(float) * H * W, hipMemcpyHostToDevice));
+        rd(f, buf.data(), (size_t)H * W * 4);
+        HIP_OK(hipMalloc(reinterpret_cast<void **>(&fr->_normal_gpu), sizeof(float) * 4 * H * W));
+        HIP_OK(hipMemcpy(fr->_normal_gpu, buf.data(), sizeof(float) * 4 * H * W, hipMemcpyHostToDevice));
+        frames[k] = fr;
+    }
+    std::map<std::pair<int, int>, Correspondences> matches;     // _fm->_matches[{frameA (newer), frameB}]
+    for (const EntryJ &e : corr) {
+        auto &m = matches[{ frames[e.imgIdx_j]->_id, frames[e.imgIdx_i]->_id }];
+        for (int c = 0; c < 3; c++) { m.ptA_cam.push_back(e.pos_j[c]); m.ptB_cam.push_back(e.pos_i[c]); }
+    }
+    auto yml = std::make_shared<Config>();
+    std::vector<std::shared_ptr<Frame>> local = frames;
+    std::mt19937 rng(5);
+    std::shuffle(local.begin(), local.end(), rng);
+    Window w = marshalWindow(local, matches, frames[N - 1], yml->min_fm_edges_newframe);
+    if (!w.run_ba) { std::fprintf(stderr, "window gated: NO_BA\n"); return 4; }
+    std::vector<float> result;
+    for (int pass = 0; pass < 3; pass++) {                      // stateless call, then twice with the persistent frame cache
+        OptimizerGpu *opt_ptr = nullptr;
+        static std::unique_ptr<OptimizerGpu> keyed;
+        std::unique_ptr<OptimizerGpu> plain;
+        if (pass == 0) { plain.reset(new OptimizerGpu(yml)); opt_ptr = plain.get(); }
+        else { if (!keyed) { keyed.reset(new OptimizerGpu(yml)); keyed->persistent_frame_cache = true; } opt_ptr = keyed.get(); }
+        std::vector<float *> depths_gpu; std::vector<uchar4 *> colors_gpu; std::vector<float4 *> normals_gpu; std::vector<Matrix4f> poses;
+        opt_ptr->frame_ids.clear();
+        for (const auto &fr : w.frames) {
+            depths_gpu.push_back(fr->_depth_gpu); colors_gpu.push_back(fr->_color_gpu); normals_gpu.push_back(fr->_normal_gpu);
+            poses.push_back(from_rowmajor(&P[16 * (size_t)((fr->_id - 3) / 10)]));
+            opt_ptr->frame_ids.push_back((uint64_t)fr->_id);
+        }
+        opt_ptr->optimizeFrames(w.global_corres, w.n_match_per_pair, (int)w.frames.size(), H, W, depths_gpu, colors_gpu, normals_gpu, poses, K);
+        std::printf("pass %d: frames cached in this call %d, solve %.3f ms\n", pass, opt_ptr->last_stats.cache_frames_built, opt_ptr->last_stats.ms_solve);
+        for (const Matrix4f &M : poses) for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) result.push_back(M(r, c));
+        if (pass == 2) keyed.reset();
+    }
+    // error path: a status becomes an exception, nothing exits
+    try {
+        OptimizerGpu bad(yml);
+        std::vector<Matrix4f> one(1, Matrix4f::Identity());
+        bad.optimizeFrames({}, {}, 1, H, W, { frames[0]->_depth_gpu }, { nullptr }, { frames[0]->_normal_gpu }, one, K);
+        return 5;
+    } catch (const Error &e) { if (e.status != BTBA_EINVAL) return 6; }
+    std::ofstream o(out, std::ios::binary);
+    o.write(reinterpret_cast<const char *>(result.data()), sizeof(float) * result.size());
+    for (auto &fr : frames) { (void)hipFree(fr->_depth_gpu); (void)hipFree(fr->_normal_gpu); }
+    return 0;
+}
+
+static int run_keyframes(const char *in, const char *out)
+{
+    std::ifstream f(in, std::ios::binary);
+    int32_t hdr[2];
+    rd(f, hdr, 2);
+    const int M = hdr[0];
+    auto yml = std::make_shared<Config>();
+    yml->max_BA_frames = hdr[1];
+    std::vector<float> P(16 * (size_t)M);
+    rd(f, P.data(), P.size());
+    KeyframeMemory mem(yml);
+    std::vector<int32_t> res;
+    std::shared_ptr<Frame> last;
+    for (int k = 0; k < M; k++) {
+        auto fr = std::make_shared<Frame>();
+        fr->_id = k; fr->_n_keypts = 100;
+        fr->_pose_in_model = from_rowmajor(&P[16 * (size_t)k]);
+        if (k < M - 1) res.push_back(mem.checkAndAddKeyframe(fr) ? 1 : 0);
+        last = fr;
+    }
+    res.push_back(-1);
+    for (const auto &fr : mem.selectKeyFramesForBA(last)) res.push_back(fr->_id);
+    std::ofstream o(out, std::ios::binary);
+    o.write(reinterpret_cast<const char *>(res.data()), sizeof(int32_t) * res.size());
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    try {
+        if (argc == 4 && !std::strcmp(argv[1], "ba")) return run_ba(argv[2], argv[3]);
+        if (argc == 4 && !std::strcmp(argv[1], "keyframes")) return run_keyframes(argv[2], argv[3]);
+    } catch (const std::exception &e) { std::fprintf(stderr, "host_driver: %s\n", e.what()); return 2; }
+    std::fprintf(stderr, "usage: host_driver ba|keyframes <in> <out>\n");
+    return 1;
+}
