@@ -865,19 +865,24 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     // M = [[R_i, 0], [[t_i]x R_i, R_i]] with T_i the TARGET frame's pose of this iterate.
     // One (pair, upper-triangle entry) per lane + one (pair, g row) per lane; S' held in registers.
     if (D.use_dense) {
-        auto m_row = [&](const float *Tt, int r, float (&Mr)[6]) {
-            if (r < 3) {
-                Mr[0] = Tt[4 * r]; Mr[1] = Tt[4 * r + 1]; Mr[2] = Tt[4 * r + 2]; Mr[3] = 0.f; Mr[4] = 0.f; Mr[5] = 0.f;
-            } else {
+        // M of every frame once (36 N entries, one lane each), parked in the vector region that is not written before
+        // phase B2: the per-pair loop below then reads rows of M instead of rebuilding them with divergent branches
+        float *Mf = vb;                                   // 6 ld >= 36 N floats
+        for (int e = tid; e < 36 * N; e += nthr) {
+            const int k = e / 36, r = (e % 36) / 6, c = e % 6;
+            const float *Tt = vT + 16 * k;
+            float v;
+            if (r < 3) v = (c < 3) ? Tt[4 * r + c] : 0.0f;
+            else {
                 const int q = r - 3, qa = (q + 1) % 3, qb = (q + 2) % 3;     // ([t]x R)[q][c] = t[qa] R[qb][c] - t[qb] R[qa][c]
-                const float ta = Tt[4 * qa + 3], tb = Tt[4 * qb + 3];
-#pragma unroll
-                for (int c = 0; c < 3; c++) { Mr[c] = ta * Tt[4 * qb + c] - tb * Tt[4 * qa + c]; Mr[3 + c] = Tt[4 * q + c]; }
+                v = (c < 3) ? Tt[4 * qa + 3] * Tt[4 * qb + c] - Tt[4 * qb + 3] * Tt[4 * qa + c] : Tt[4 * q + (c - 3)];
             }
-        };
+            Mf[e] = v;
+        }
+        __syncthreads();
         for (int e = tid; e < D.n_dense_pairs * 27; e += nthr) {
             const int p = e / 27, idx = e % 27;
-            const float *Tt = vT + 16 * dense_pairs_lds[2 * p];
+            const float *Mt = Mf + 36 * dense_pairs_lds[2 * p];
             const float *Sp = pdr + (size_t)p * kDenseVals;
             float *So = pd + (size_t)p * kDenseVals;
             if (idx < 21) {
@@ -888,7 +893,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
 #pragma unroll
                 for (int k2 = 0; k2 < 21; k2++) S[k2] = Sp[k2];
                 float Mr[6], Mc[6];
-                m_row(Tt, r, Mr); m_row(Tt, c, Mc);
+#pragma unroll
+                for (int l = 0; l < 6; l++) { Mr[l] = Mt[6 * r + l]; Mc[l] = Mt[6 * c + l]; }
                 float acc = 0.0f;
 #pragma unroll
                 for (int k2 = 0; k2 < 6; k2++) {
@@ -900,11 +906,9 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
                 So[idx] = acc;
             } else {
                 const int r = idx - 21;
-                float Mr[6];
-                m_row(Tt, r, Mr);
                 float acc = 0.0f;
 #pragma unroll
-                for (int k2 = 0; k2 < 6; k2++) acc += Mr[k2] * Sp[21 + k2];
+                for (int k2 = 0; k2 < 6; k2++) acc += Mt[6 * r + k2] * Sp[21 + k2];
                 So[21 + r] = acc;
                 if (r == 0) So[27] = Sp[27];
             }
