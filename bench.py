@@ -58,6 +58,16 @@ def generate_instances(cfg, ids, masked=False):
     return [_gen(j) for j in jobs]
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, inst, budget_s=20.0):
     """The CPU oracle (a port: the reference has no CPU path) timed on this box's host cores on a bounded
     sample of the same workload: whole solves of ONE instance, single-thread and all-threads."""
@@ -80,7 +90,7 @@ def cpu_baseline(cfg, inst, budget_s=20.0):
     return {"value": round(best[0], 3), "unit": "GN iterations/s", "cores": best[3], "kind": "port",
             "sample": f"{best[1]} full solves (7 GN x 5 PCG) of one {cfg['desc']} instance in {best[2]:.1f} s; "
                       f"1 thread: {out['1t'][0]:.2f} it/s, {nmt} threads: {out['all'][0]:.2f} it/s (gcc -O3 AVX2 + OpenMP, oracle/btba_oracle.c)",
-            "host_cpus": ncpu}
+            "host_cpus": ncpu, "host_cpu_model": _cpu_model()}
 
 
 def measured_copy_bandwidth(torch, dev, nbytes=1 << 30, reps=10):
