@@ -240,11 +240,13 @@ def main():
                 copy_bw = measured_copy_bandwidth(torch, dev)
                 res["roofline"]["peak_measured_copy"] = round(copy_bw, 1)
                 res["roofline"]["frac_of_measured_copy"] = round(achieved / copy_bw, 4)
+            sweeps_ms = (st["ms_dense_sweep"] + st["ms_sparse_sweep"]) / args.steps
             res["kernels_ms_per_step"] = {
-                "dense_sweep": round(st["ms_dense_sweep"] / args.steps, 4), "sparse_sweep": round(st["ms_sparse_sweep"] / args.steps, 4),
+                "sweeps": round(sweeps_ms, 4), "fused_sweeps": fused,            # fused: ONE launch per iteration carries both sweeps
+                "dense_sweep": None if fused else round(st["ms_dense_sweep"] / args.steps, 4),
+                "sparse_sweep": None if fused else round(st["ms_sparse_sweep"] / args.steps, 4),
                 "system_solve": round(st["ms_system_solve"] / args.steps, 4), "solve_region": round(st["ms_solve"] / args.steps, 4),
-                "sparse_alg_GBps": (round(32 * n_corr / max(st["ms_sparse_sweep"] / max(st["n_sparse_launches"], 1), 1e-9) / 1e6, 1) if st["n_sparse_launches"] else None),
-                "fused_sweeps": bool(st.get("fused_sweeps", 0))}
+                "sparse_alg_GBps": (round(32 * n_corr / max(st["ms_sparse_sweep"] / max(st["n_sparse_launches"], 1), 1e-9) / 1e6, 1) if st["n_sparse_launches"] else None)}
         elif cfg["w_dense"] == 0.0 and not args.no_kernel_timing and st["n_sparse_launches"] > 0:
             avg_ms = st["ms_sparse_sweep"] / st["n_sparse_launches"]
             achieved = 32 * n_corr / (avg_ms * 1e-3) / 1e9
