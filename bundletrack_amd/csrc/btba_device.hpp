@@ -41,17 +41,21 @@ __device__ __forceinline__ float minor3(const float *m, int r0, int r1, int r2, 
 }
 
 // generic 4x4 inverse by cofactors (the reference does NOT use the rigid shortcut)
+// float4x4::getInverse (cuda_SimpleMatrixUtil.h:978-1104): adjugate entry (R, C) = cofactor of element (C, R), six signed
+// triple products summed left to right in the reference's order (see oracle/btba_oracle.c m4_inverse), scaled by 1/det.
 __device__ __forceinline__ Mat4 mat_inverse(const Mat4 &a)
 {
     Mat4 adj;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int R = 0; R < 4; R++) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int r0 = (r == 0) ? 1 : 0, r1 = (r <= 1) ? 2 : 1, r2 = (r <= 2) ? 3 : 2;
-            const int c0 = (c == 0) ? 1 : 0, c1 = (c <= 1) ? 2 : 1, c2 = (c <= 2) ? 3 : 2;
-            float mn = minor3(a.m, r0, r1, r2, c0, c1, c2);
-            adj.m[4 * c + r] = ((r + c) & 1) ? -mn : mn;
+        for (int Cc = 0; Cc < 4; Cc++) {
+            const int r0 = (Cc == 0) ? 1 : 0, r1 = (Cc <= 1) ? 2 : 1, r2 = (Cc <= 2) ? 3 : 2;
+            const int c0 = (R == 0) ? 1 : 0, c1 = (R <= 1) ? 2 : 1, c2 = (R <= 2) ? 3 : 2;
+            const float t1 = a.m[4 * r0 + c0] * a.m[4 * r1 + c1] * a.m[4 * r2 + c2], t2 = a.m[4 * r0 + c0] * a.m[4 * r1 + c2] * a.m[4 * r2 + c1];
+            const float t3 = a.m[4 * r1 + c0] * a.m[4 * r0 + c1] * a.m[4 * r2 + c2], t4 = a.m[4 * r1 + c0] * a.m[4 * r0 + c2] * a.m[4 * r2 + c1];
+            const float t5 = a.m[4 * r2 + c0] * a.m[4 * r0 + c1] * a.m[4 * r1 + c2], t6 = a.m[4 * r2 + c0] * a.m[4 * r0 + c2] * a.m[4 * r1 + c1];
+            adj.m[4 * R + Cc] = ((R + Cc) & 1) ? (((((-t1) + t2) + t3) - t4) - t5) + t6 : ((((t1 - t2) - t3) + t4) + t5) - t6;
         }
     }
     float det = a.m[0] * adj.m[0] + a.m[1] * adj.m[4] + a.m[2] * adj.m[8] + a.m[3] * adj.m[12];

@@ -1,7 +1,8 @@
 /* btba_oracle_ransac.c -- CPU restatement of the reference's correspondence RANSAC.
  *
  * TEST INFRASTRUCTURE ONLY (same rules as btba_oracle.c): imported by tests/, never by the product path.
- * PARITY UNPINNED, twice over:
+ * PARITY: procrustesKernel and evalPoseKernel of the reference are compiled for the CPU (oracle/Makefile target `ref`,
+ * _ref/libbtba_ref_ransac.so) and compared with this file in tests/test_oracle_vs_reference.py.  Beyond that, unpinned:
  *   - the reference holds no golden vectors for this step either;
  *   - two ingredients live in third-party code that is absent from /root/reference and cannot be rebuilt here:
  *     cuRAND's XORWOW generator (curand_init(0, idx, 0) + curand_uniform, cuda_ransac.cu:1156-1163; CUDA toolkit,

@@ -1,0 +1,158 @@
+"""ctypes binding of oracle/_ref/libbtba_ref.so: the REFERENCE'S OWN device functions compiled for the CPU
+(oracle/ref_driver.cpp + oracle/ref_shim/, built by `make -C oracle ref` where /root/reference exists).
+Test infrastructure: used only by tests/ to pin oracle/btba_oracle.c against the reference itself."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(_HERE, "_ref", "libbtba_ref.so")
+REFERENCE = os.environ.get("BTBA_REFERENCE", "/root/reference")
+_lib = None
+
+
+def available() -> bool:
+    """True when the library exists or can be built (the reference checkout is present)."""
+    return os.path.exists(SO) or os.path.isdir(os.path.join(REFERENCE, "src", "cuda", "Solver"))
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, "ref_driver.cpp"), os.path.join(_HERE, "ref_shim", "cuda_runtime.h")]
+    stale = not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(s) for s in srcs)
+    if (force or stale) and os.path.isdir(os.path.join(REFERENCE, "src", "cuda", "Solver")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref", "REFERENCE=" + REFERENCE] + (["-B"] if force else []))
+    return SO
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(SO)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f(*vals):
+    return [np.ascontiguousarray(v, np.float32) for v in vals]
+
+
+def pose_to_matrix(rot, trans):
+    r, t = _f(rot, trans); M = np.zeros(16, np.float32)
+    lib().ref_pose_to_matrix(_p(r), _p(t), _p(M))
+    return M.reshape(4, 4)
+
+
+def matrix_to_pose(M):
+    (M,) = _f(np.reshape(M, 16)); r, t = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    lib().ref_matrix_to_pose(_p(M), _p(r), _p(t))
+    return r, t
+
+
+def mat4_inverse(M):
+    (M,) = _f(np.reshape(M, 16)); o = np.zeros(16, np.float32)
+    lib().ref_mat4_inverse(_p(M), _p(o))
+    return o.reshape(4, 4)
+
+
+def lie_update(dW, dT, cW, cT):
+    a = _f(dW, dT, cW, cT); nW, nT = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    lib().ref_lie_update(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(nW), _p(nT))
+    return nW, nT
+
+
+def lie_deriv(which, A, D, p):
+    A, D, p = _f(np.reshape(A, 16), np.reshape(D, 16), p); jac = np.zeros(18, np.float32)
+    lib().ref_lie_deriv(1 if which == "J" else 0, _p(A), _p(D), _p(p), _p(jac))
+    return jac.reshape(3, 6)
+
+
+def bilinear4(x, y, img):
+    (img,) = _f(img); H, W = img.shape[:2]; out = np.zeros(4, np.float32)
+    f = lib().ref_bilinear4; f.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    f(float(x), float(y), _p(img), W, H, _p(out))
+    return out
+
+
+def huber(e, delta):
+    rho = np.zeros(3, np.float32)
+    f = lib().ref_huber; f.argtypes = [C.c_float, C.c_float, C.c_void_p]
+    f(float(e), float(delta), _p(rho))
+    return rho
+
+
+def sparse_rhs(corr, T, robust_delta=0.005, weight_sparse=1.0):
+    T = np.ascontiguousarray(T, np.float32); N = T.shape[0]
+    corr = np.ascontiguousarray(corr)
+    rhs, prec = np.zeros((N, 6), np.float32), np.zeros((N, 6), np.float32)
+    f = lib().ref_sparse_rhs; f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    f(N, _p(corr), len(corr), _p(T), robust_delta, weight_sparse, _p(rhs), _p(prec))
+    return rhs, prec
+
+
+def sparse_apply(corr, T, p, weight_sparse=1.0):
+    T = np.ascontiguousarray(T, np.float32); N = T.shape[0]
+    corr = np.ascontiguousarray(corr); p = np.ascontiguousarray(p, np.float32).reshape(N, 6)
+    out = np.zeros((N, 6), np.float32)
+    f = lib().ref_sparse_apply; f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    f(N, _p(corr), len(corr), _p(T), weight_sparse, _p(p), _p(out))
+    return out
+
+
+def dense_system(campos, normals, intr, T, Tinv, pairs, dist_thresh=0.02, normal_thresh=float(np.cos(np.pi / 4)), depth_min=0.1, depth_max=9999.0,
+                 robust_delta=0.005, weight_dense=1.0):
+    campos, normals, T, Tinv = _f(campos, normals, T, Tinv)
+    N, Hd, Wd = campos.shape[:3]
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    (intr,) = _f(intr)
+    JtJ, Jtr, cnt = np.zeros((6 * N, 6 * N), np.float32), np.zeros(6 * N, np.float32), np.zeros(len(pairs), np.int32)
+    f = lib().ref_dense_system
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 6 + [C.c_void_p] * 3
+    f(N, Wd, Hd, _p(intr), _p(campos), _p(normals), _p(T), _p(Tinv), _p(pairs), len(pairs), dist_thresh, normal_thresh, depth_min, depth_max, robust_delta, weight_dense,
+      _p(JtJ), _p(Jtr), _p(cnt))
+    return JtJ, Jtr, cnt
+
+
+# ---- the reference's procrustesKernel / evalPoseKernel (oracle/_ref/libbtba_ref_ransac.so) -------------------
+SO_RANSAC = os.path.join(_HERE, "_ref", "libbtba_ref_ransac.so")
+_lib_r = None
+
+
+def lib_ransac() -> C.CDLL:
+    global _lib_r
+    if _lib_r is None:
+        if not os.path.exists(SO_RANSAC):
+            build(force=True)
+        _lib_r = C.CDLL(SO_RANSAC)
+    return _lib_r
+
+
+def _pts4(p):
+    p = np.asarray(p, np.float32)
+    if p.shape[1] == 3:
+        p = np.concatenate([p, np.ones((p.shape[0], 1), np.float32)], 1)
+    return np.ascontiguousarray(p, np.float32)
+
+
+def procrustes(src, dst):
+    """procrustesKernel (cuda_ransac.cu:999-1102, with the reference's approximate 3x3 SVD): (ok, pose [4,4])."""
+    s, d = _pts4(src), _pts4(dst); pose = np.zeros(16, np.float32)
+    f = lib_ransac().ref_procrustes; f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    ok = f(_p(s), _p(d), s.shape[0], _p(pose))
+    return bool(ok), pose.reshape(4, 4)
+
+
+def eval_pose(ptsA, ptsB, pose, dist_thres):
+    """evalPoseKernel (cuda_ransac.cu:978-997): ascending ids of the points with |ptB - pose ptA| <= dist_thres."""
+    a, b = _pts4(ptsA), _pts4(ptsB); ids = np.zeros(max(len(a), 1), np.int32)
+    (P,) = _f(np.reshape(pose, 16))
+    f = lib_ransac().ref_eval_pose; f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
+    n = f(_p(a), _p(b), len(a), _p(P), dist_thres, _p(ids))
+    return ids[:n].copy()

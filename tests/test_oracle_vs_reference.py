@@ -1,0 +1,150 @@
+"""The oracle against THE REFERENCE ITSELF: wenbowen123/BundleTrack's header-only device functions (SE(3) helpers,
+4x4 inverse, bilinear taps, Huber, the sparse residual / Jacobian-transpose / matrix-free operator, the dense
+projective association and point-to-plane rows) compiled for the CPU where they lie under /root/reference
+(oracle/ref_driver.cpp, oracle/ref_shim/, `make -C oracle ref` -> oracle/_ref/libbtba_ref.so) and called on the same
+inputs as oracle/btba_oracle.c.  Skipped where neither the built library nor the reference checkout exists."""
+import numpy as np
+import pytest
+
+from bundletrack_amd import synthetic as S
+from oracle import reference as R
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref/libbtba_ref.so not built and /root/reference absent")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def first_iterate_transforms(oracle, poses):
+    """What the solver linearises about in its first iteration: T = Exp(Log(pose)) (SBA.cpp:106,115 -> SolverBundling.cu:890-897)."""
+    return np.stack([oracle.pose_to_matrix(*oracle.matrix_to_pose(P)) for P in np.asarray(poses, np.float32)])
+
+
+def test_se3_helpers_bit_exact(oracle):
+    rng = np.random.default_rng(0)
+    cases = [np.zeros(3), [1e-5, 0, 0], [9e-5, 3e-5, 0], [1e-3, -1e-3, 2e-4], [0.03, 0.01, -0.02], [0.7, -0.4, 0.2], [2.0, 1.5, -1.0],
+             [3.1, 0.2, 0.1], [0, 3.14159, 0], [1e-4, 1e-4, 1e-4]] + list(rng.uniform(-np.pi, np.pi, size=(300, 3))) + list(rng.normal(scale=1e-3, size=(100, 3)))
+    for w in cases:
+        t = rng.uniform(-1, 1, 3)
+        Mo, Mr = oracle.pose_to_matrix(w, t), R.pose_to_matrix(w, t)
+        assert np.array_equal(bits(Mo), bits(Mr)), w                         # every Exp branch: theta^2 < 1e-8, < 1e-6, general
+        ro, to = oracle.matrix_to_pose(Mr); rr, tr = R.matrix_to_pose(Mr)
+        assert np.array_equal(bits(ro), bits(rr)) and np.array_equal(bits(to), bits(tr)), w      # every Log branch incl. near pi
+        io, ir = oracle.mat4_inverse(Mr), R.mat4_inverse(Mr)
+        assert np.array_equal(io, ir)                                         # value-equal (the two differ in the sign of exact zeros)
+        dW, dT = rng.normal(scale=0.01, size=3), rng.normal(scale=0.01, size=3)
+        uo, ur = oracle.lie_update(dW, dT, w, t), R.lie_update(dW, dT, w, t)
+        assert np.array_equal(bits(uo[0]), bits(ur[0])) and np.array_equal(bits(uo[1]), bits(ur[1]))
+    for _ in range(50):                                                       # a general (non-rigid) 4x4 through the cofactor inverse
+        M = rng.normal(size=(4, 4)).astype(np.float32)
+        assert np.array_equal(oracle.mat4_inverse(M), R.mat4_inverse(M))
+
+
+def test_jacobians_bilinear_huber_bit_exact(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        A = oracle.pose_to_matrix(rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3)); D = oracle.pose_to_matrix(rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3))
+        p = rng.uniform(-1, 1, 3)
+        for which in ("I", "J"):
+            assert np.array_equal(bits(oracle.lie_deriv(which, A, D, p)), bits(R.lie_deriv(which, A, D, p)))
+    img = rng.uniform(0.2, 2.0, size=(9, 11, 4)).astype(np.float32)
+    img[2, 3] = 0; img[5, 5] = 0                                              # zero (invalid) taps are blended in, ICPUtil.h:83-110
+    MINF = np.float32(-np.inf)
+    for x, y in [(0, 0), (10, 8), (3.3, 2.2), (2.5, 1.5), (4.7, 4.9), (-0.4, 3), (10.4, 8.3), (-1.2, 2), (3, 8.9), (11.2, 3), (9.99, 7.99), (0.0, 8.0)] + \
+            [tuple(v) for v in rng.uniform(-1.5, 11.5, size=(300, 2))]:
+        ok, vo = oracle.bilinear4(x, y, img)
+        vr = R.bilinear4(x, y, img)
+        if ok:
+            assert np.array_equal(bits(vo), bits(vr)), (x, y)
+        else:
+            assert vr[0] == MINF, (x, y)                                      # the reference's "no tap in the image" marker
+    for e in [0.0, 1e-9, 2.4e-5, 2.5e-5, 2.6e-5, 1e-4, 0.3, 7.0] + list(rng.uniform(0, 1e-3, 100)):
+        assert np.float32(oracle.huber_weight(e, 0.005)) == R.huber(e, 0.005)[1]
+
+
+@pytest.mark.parametrize("K,m,seed", [(4, 150, 3), (6, 300, 31), (10, 1000, 32)])
+def test_sparse_term_matches_reference(oracle, K, m, seed):
+    """-J^T W r, the Jacobi diagonal and the matrix-free J^T J p: the reference's evalMinusJTFDevice / applyJDevice /
+    applyJTDevice against the oracle.  The reference adds several hundred terms per frame sequentially in fp32 (table
+    order), the canonical oracle carries the same fp32 terms in a double: agreement to the fp32 sum's own round-off."""
+    pb = S.make_problem(K, m, seed, background=True, full_res=False)
+    T = first_iterate_transforms(oracle, pb.poses_init)
+    tr = oracle.solve(*S.analytic_cache(pb)[:3], pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=0.0, n_gn_iters=1))
+    rhs_r, prec_r = R.sparse_rhs(pb.corr, T)
+    scale = np.abs(rhs_r).max()
+    assert np.abs(tr.rhs[0].reshape(K, 6) - rhs_r).max() <= 1e-5 * scale
+    po, pr = tr.precond[0].reshape(K, 6)[1:], prec_r[1:]
+    assert np.abs(po - pr).max() <= 1e-5 * np.abs(pr).max()
+    rng = np.random.default_rng(seed)
+    p = rng.normal(size=(K, 6)).astype(np.float32); p[0] = 0
+    ao, ar = oracle.sparse_apply(pb.corr, T, p), R.sparse_apply(pb.corr, T, p)
+    assert np.abs(ao - ar).max() <= 1e-5 * np.abs(ar).max()
+    # invalid entries are skipped by both
+    corr = pb.corr.copy(); corr["imgIdx_i"][::7] = 0xFFFFFFFF
+    tr2 = oracle.solve(*S.analytic_cache(pb)[:3], corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=0.0, n_gn_iters=1))
+    rhs_r2, _ = R.sparse_rhs(corr, T)
+    assert np.abs(tr2.rhs[0].reshape(K, 6) - rhs_r2).max() <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("K,seed,bg", [(3, 41, True), (4, 42, False), (5, 43, True)])
+def test_dense_term_matches_reference(oracle, K, seed, bg):
+    """findDenseCorr + Huber + computeJacobianBlockRow_i/j + addToLocalSystemBrute run by the reference's own code over
+    every pixel of every (target < source) pair, against the oracle's dense system of the first Gauss-Newton iterate:
+    the same accepted pixels, the same matrix and right-hand side up to fp32 summation order."""
+    pb = S.make_problem(K, 10, seed, background=bg, full_res=False)
+    campos, normals, intr = S.analytic_cache(pb)
+    tr = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(weight_sparse=0.0, n_gn_iters=1))
+    T = first_iterate_transforms(oracle, pb.poses_init)
+    Tinv = np.stack([oracle.mat4_inverse(T[k]) for k in range(K)])
+    pairs = oracle.target_lower_pairs(K)
+    JtJ, Jtr, cnt = R.dense_system(campos, normals, intr, T, Tinv, pairs)
+    assert np.array_equal(cnt, tr.dense_count[0][:len(pairs)]) and cnt.sum() > 500
+    lower = np.tril(JtJ)                                                      # FlipJtJ (SolverBundling.cu:49-59): upper <- lower
+    flipped = lower + np.tril(lower, -1).T
+    n = 6 * K
+    Jo = tr.dense_JtJ[0].reshape(n, n)
+    assert np.abs(Jo - flipped).max() <= 2e-5 * np.abs(flipped).max()
+    # J^T r adds tens of thousands of signed terms sequentially in fp32 on the reference side (atomicAdd order = pixel order here)
+    assert np.abs(tr.dense_Jtr[0] - Jtr).max() <= 1e-4 * np.abs(Jtr).max()
+
+
+def test_ransac_hypothesis_and_vote_match_reference(oracle):
+    """The reference's procrustesKernel (with its pasted approximate 3x3 SVD: 4 Jacobi sweeps, rsqrt-based Givens angles)
+    and evalPoseKernel, compiled for the CPU, against oracle/btba_oracle_ransac.c (exact Kabsch).  Same conventions --
+    the typical difference is 1e-6 -- and wherever the two differ more, the oracle's fit has the smaller residual: the
+    reference's SVD is the inaccurate side (heavy tail on 3-point samples, whose correlation matrix has rank 2).
+    For a given pose the two inlier lists are identical (same distance formula, same `dist > thres => reject` rule)."""
+    from test_oracle_ransac import planted
+    rng = np.random.default_rng(8)
+
+    def fit_residual(pose, P, Q):
+        return float((((P.astype(np.float64) @ pose[:3, :3].astype(np.float64).T + pose[:3, 3]) - Q) ** 2).sum())
+
+    for n, med_bound, max_bound in ((3, 1e-5, None), (5, 1e-5, None), (40, 1e-6, 2e-3), (400, 1e-6, 5e-4)):
+        diffs = []
+        for _ in range(120):
+            P, Q, T, _ = planted(rng, n, 0.0, noise=0.001)
+            ok_r, pose_r = R.procrustes(P, Q)
+            ok_o, pose_o, gap = oracle.procrustes(P, Q)
+            assert ok_o
+            if not ok_r:                       # "R is not valid": the reference's SVD gave up
+                continue
+            diffs.append(np.abs(pose_r - pose_o).max())
+            ro, rr = fit_residual(pose_o, P, Q), fit_residual(pose_r, P, Q)
+            assert ro <= rr * (1 + 1e-3) + 1e-9                                    # the oracle is never the worse fit ...
+            if diffs[-1] > 1e-3:
+                assert ro < rr                                                     # ... and where the two really differ, it is the better one
+        diffs = np.array(diffs)
+        print(f"procrustes n={n}: reference vs oracle pose entries: median {np.median(diffs):.1e}, 95 % {np.percentile(diffs, 95):.1e}, max {diffs.max():.1e}")
+        assert np.median(diffs) < med_bound and (max_bound is None or diffs.max() < max_bound)
+    for n, frac in ((60, 0.3), (500, 0.5)):
+        P, Q, T, mask = planted(rng, n, frac)
+        res = oracle.ransac_pair(P, Q, 200, 0.01, seed=4)
+        ids_ref = R.eval_pose(P, Q, res["best_pose"], 0.01)
+        assert np.array_equal(ids_ref, res["inlier_ids"]) and np.array_equal(ids_ref, np.nonzero(mask)[0])
+        for t in (0, 7, 63):                   # arbitrary (bad) hypotheses too: same list, point for point
+            pose = np.eye(4, dtype=np.float32); pose[:3] = res["poses"][t][:3]
+            want = [i for i in range(n) if not (np.float32(np.sqrt(np.float32(((Q[i].astype(np.float32) - (pose[:3, :3] @ P[i] + pose[:3, 3]).astype(np.float32)) ** 2).sum()))) > np.float32(0.01))]
+            got = R.eval_pose(P, Q, pose, 0.01)
+            assert abs(len(got) - len(want)) <= 1
