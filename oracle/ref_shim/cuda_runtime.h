@@ -33,7 +33,7 @@ struct uint2 { unsigned x, y; };
 struct uint3 { unsigned x, y, z; };
 struct uint4 { unsigned x, y, z, w; };
 struct uchar4 { unsigned char x, y, z, w; };
-struct dim3 { unsigned x, y, z; };
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 
 static inline float2 make_float2(float x, float y) { float2 v = { x, y }; return v; }
 static inline float3 make_float3(float x, float y, float z) { float3 v = { x, y, z }; return v; }
@@ -53,14 +53,14 @@ static inline float __saturatef(float x) { return x < 0.f ? 0.f : (x > 1.f ? 1.f
 using std::max;
 using std::min;
 
-/* thread geometry: a single "thread" */
-static const uint3 threadIdx = { 0, 0, 0 }, blockIdx = { 0, 0, 0 };
-static const dim3 blockDim = { 1, 1, 1 }, gridDim = { 1, 1, 1 };
+/* thread geometry: ONE thread runs at a time; btba_emulate() below walks a launch's blocks and threads sequentially */
+static uint3 threadIdx = { 0, 0, 0 }, blockIdx = { 0, 0, 0 };
+static dim3 blockDim(1, 1, 1), gridDim(1, 1, 1);
 static inline void __syncthreads() {}
 /* one lane at a time: the other lanes of the "warp" contribute nothing, so the reference's warpReduce(v) returns v and the
  * caller (oracle/ref_driver.cpp) adds up the lanes itself */
 template <class T> static inline T __shfl_down_sync(unsigned, T, int, int = 32) { return T(0); }
-template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p += v; return o; }
+template <class T, class U> static inline T atomicAdd(T *p, U v) { T o = *p; *p += (T)v; return o; }
 
 /* "device" memory is host memory here; the runtime calls the headers' helper structs make become libc calls */
 typedef int cudaError_t;
@@ -84,4 +84,27 @@ static inline cudaError_t cudaEventSynchronize(cudaEvent_t) { return 0; }
 static inline cudaError_t cudaEventElapsedTime(float *ms, cudaEvent_t, cudaEvent_t) { *ms = 0.f; return 0; }
 #define cutilSafeCall(x) (x)
 #define cutilCheckMsg(x)
+
+/* ---- kernel launches ------------------------------------------------------------------------------------------
+ * oracle/Makefile rewrites `kernel<<<grid, block>>>(args);` in the streamed .cu into BTBA_LAUNCH("kernel", (kernel(args)),
+ * grid, block); the kernel (a plain function here, __global__ is empty) is then called once per (block, thread), in order.
+ * That is a faithful execution for kernels whose threads only meet through atomics -- every kernel of the solve path once
+ * WARP_SIZE is 1 in the .cu (each thread is lane 0 of its own warp, so the `lane == 0 -> atomicAdd(warpReduce(v))`
+ * pattern adds every thread's value).  The two dense-sweep kernels also reduce through __shared__ memory between
+ * __syncthreads(); they index pixels as threadIdx.x * gridDim.y + blockIdx.y, so they are run with one thread per block
+ * and gridDim.y enlarged by the block size: the same set of pixels, and the block-wide reduction degenerates to the
+ * thread's own value.  Sums are therefore formed sequentially in launch order (the GPU's order is arbitrary). */
+#include <string.h>
+template <class F>
+static void btba_emulate(const char *name, F body, dim3 grid, dim3 block, size_t = 0, void * = 0)
+{
+    if (strstr(name, "BuildDenseSystem_Kernel") || strstr(name, "FindDenseCorrespondences_Kernel")) { grid = dim3(grid.x, grid.y * block.x, 1); block = dim3(1, 1, 1); }
+    gridDim = grid; blockDim = block;
+    for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned bx = 0; bx < grid.x; bx++) for (unsigned by = 0; by < grid.y; by++)
+        for (unsigned tz = 0; tz < block.z; tz++) for (unsigned ty = 0; ty < block.y; ty++) for (unsigned tx = 0; tx < block.x; tx++) {
+            blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz; threadIdx.x = tx; threadIdx.y = ty; threadIdx.z = tz;
+            body();
+        }
+}
+#define BTBA_LAUNCH(name, call, ...) btba_emulate(name, [&]() { call; }, __VA_ARGS__)
 #endif

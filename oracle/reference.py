@@ -156,3 +156,34 @@ def eval_pose(ptsA, ptsB, pose, dist_thres):
     f = lib_ransac().ref_eval_pose; f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
     n = f(_p(a), _p(b), len(a), _p(P), dist_thres, _p(ids))
     return ids[:n].copy()
+
+
+# ---- the reference's WHOLE solver, emulated sequentially (oracle/_ref/libbtba_ref_solver.so) -----------------
+SO_SOLVER = os.path.join(_HERE, "_ref", "libbtba_ref_solver.so")
+_lib_s = None
+
+
+def lib_solver() -> C.CDLL:
+    global _lib_s
+    if _lib_s is None:
+        if not os.path.exists(SO_SOLVER):
+            build(force=True)
+        _lib_s = C.CDLL(SO_SOLVER)
+    return _lib_s
+
+
+def solve(campos, normals, intr, corr, poses, n_gn=7, n_pcg=5, weight_sparse=1.0, weight_dense=1.0, robust_delta=0.005,
+          dist_thresh=0.02, normal_thresh=float(np.cos(np.pi / 4)), depth_min=0.1, depth_max=9999.0):
+    """solveBundlingStub (SolverBundling.cu:931-1003) and everything under it, run by the reference's own code.
+    Returns (poses [N,4,4] after n_gn Gauss-Newton iterations, x [N,6] = (rot, trans))."""
+    campos, normals = _f(campos, normals)
+    N, Hd, Wd = campos.shape[:3]
+    (intr,) = _f(intr)
+    corr = np.ascontiguousarray(corr)
+    P = np.ascontiguousarray(poses, np.float32).reshape(N, 16).copy()
+    x = np.zeros((N, 6), np.float32)
+    f = lib_solver().ref_solve
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 7 + [C.c_void_p]
+    f(N, Wd, Hd, _p(intr), _p(campos), _p(normals), _p(corr), len(corr), _p(P), n_gn, n_pcg, weight_sparse, weight_dense, robust_delta,
+      dist_thresh, normal_thresh, depth_min, depth_max, _p(x))
+    return P.reshape(N, 4, 4), x

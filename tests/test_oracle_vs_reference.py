@@ -148,3 +148,40 @@ def test_ransac_hypothesis_and_vote_match_reference(oracle):
             want = [i for i in range(n) if not (np.float32(np.sqrt(np.float32(((Q[i].astype(np.float32) - (pose[:3, :3] @ P[i] + pose[:3, 3]).astype(np.float32)) ** 2).sum()))) > np.float32(0.01))]
             got = R.eval_pose(P, Q, pose, 0.01)
             assert abs(len(got) - len(want)) <= 1
+
+
+# ---- the reference's WHOLE solver ------------------------------------------------------------------------------
+# solveBundlingStub and every kernel under it (BuildDenseSystem incl. addToLocalSystem, FlipJtJ, PCGInit, the five PCG
+# kernels, the dense mat-vec, computeLieUpdate, convertLiePosesToMatricesCU, the frame->correspondence table), compiled
+# for the CPU and executed thread by thread (oracle/ref_shim/cuda_runtime.h btba_emulate, oracle/ref_solver_wrap.h).
+
+@pytest.mark.parametrize("case", [
+    dict(K=4, m=150, seed=7, bg=False, wd=1.0, tol=1e-5),       # object mask, feature + dense
+    dict(K=5, m=200, seed=8, bg=False, wd=1.0, tol=1e-5),
+    dict(K=3, m=0, seed=9, bg=False, wd=1.0, tol=2e-3),         # dense term alone: no Jacobi diagonal (it comes from the feature term), weakly conditioned
+    dict(K=6, m=300, seed=9, bg=False, wd=0.0, tol=1e-5),       # feature term alone
+    dict(K=4, m=150, seed=7, bg=True, wd=1.0, tol=1e-3),        # 100 %-valid K=4: weakly conditioned
+], ids=lambda c: f"K{c['K']}_m{c['m']}_{'bg' if c['bg'] else 'mask'}_wd{c['wd']:g}")
+def test_reference_solver_matches_oracle_per_iterate(oracle, case):
+    pb = S.make_problem(case["K"], case["m"], case["seed"], background=case["bg"], full_res=False)
+    campos, normals, intr = S.analytic_cache(pb)
+    tr = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=case["wd"]))
+    worst = 0.0
+    for n in range(1, 8):                                        # the stub has no per-iterate output: run it for 1, 2, ... 7 iterations
+        P, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, n_gn=n, weight_dense=case["wd"])
+        worst = max(worst, max(max(S.pose_error(P[k], tr.T_after[n - 1][k])) for k in range(case["K"])))
+        assert np.array_equal(P[0], tr.T_after[n - 1][0])        # frame 0 is never moved, by either
+    print(f"{case}: reference vs oracle, worst over the 7 iterates {worst:.2e}")
+    assert worst < case["tol"], worst
+
+
+@pytest.mark.parametrize("name,K,m,wd,config", [("c2", 10, 1000, 0.0, 2), ("c3", 15, 2000, 1.0, 3)])
+def test_reference_solver_matches_oracle_at_baseline_sizes(oracle, name, K, m, wd, config):
+    """BASELINE.json configs[1] and configs[2] (the headline), same seeds as the GPU full-size tests."""
+    pb = S.make_problem(K, m, S.config_seed(config), background=True, full_res=False)
+    campos, normals, intr = S.analytic_cache(pb)
+    tr = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=wd, n_threads=4))
+    P, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, weight_dense=wd)
+    worst = max(max(S.pose_error(P[k], tr.poses[k])) for k in range(K))
+    print(f"{name}: reference vs oracle after 7 GN x 5 PCG: {worst:.2e}")
+    assert worst < 1e-4, worst
