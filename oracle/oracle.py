@@ -1,10 +1,10 @@
 """ctypes binding of the CPU oracle (oracle/btba_oracle.c).
 
 TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and the
-cpu_baseline leg of bench.py -- never from bundletrack_amd/.  Parity: pinned at function
-level against the reference's own __device__ math compiled for the CPU (oracle/reference.py,
-tests/test_oracle_vs_reference.py), unpinned at kernel level (the reference has no golden vectors
-for this path); see the header of btba_oracle.c.
+cpu_baseline leg of bench.py -- never from bundletrack_amd/.  Parity: pinned against the
+reference's own solver compiled and executed on the CPU (oracle/reference.py, oracle/_ref,
+tests/test_oracle_vs_reference.py); the reference has no golden vectors for this path
+(SURVEY.md section 8c); see the header of btba_oracle.c.
 """
 from __future__ import annotations
 
