@@ -1,5 +1,6 @@
 """Self-derived known-answer tests that pin the CPU oracle (the reference has no
-golden vectors for this path -- PARITY UNPINNED -- so these replace them): SE(3) exp/log, the cofactor
+golden vectors for this path; the reference-executed pins live in test_oracle_vs_reference.py, these are the
+self-derived checks that came first): SE(3) exp/log, the cofactor
 inverse, Huber, the bilinear gather's zero-blending quirk and finite-difference Jacobian checks."""
 import numpy as np
 import pytest
