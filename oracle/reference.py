@@ -187,3 +187,47 @@ def solve(campos, normals, intr, corr, poses, n_gn=7, n_pcg=5, weight_sparse=1.0
     f(N, Wd, Hd, _p(intr), _p(campos), _p(normals), _p(corr), len(corr), _p(P), n_gn, n_pcg, weight_sparse, weight_dense, robust_delta,
       dist_thresh, normal_thresh, depth_min, depth_max, _p(x))
     return P.reshape(N, 4, 4), x
+
+
+# ---- the reference's image kernels (oracle/_ref/libbtba_ref_image.so) ----------------------------------------
+SO_IMAGE = os.path.join(_HERE, "_ref", "libbtba_ref_image.so")
+_lib_i = None
+
+
+def lib_image() -> C.CDLL:
+    global _lib_i
+    if _lib_i is None:
+        if not os.path.exists(SO_IMAGE):
+            build(force=True)
+        _lib_i = C.CDLL(SO_IMAGE)
+    return _lib_i
+
+
+def store_frame(depth, normals, Kinv4, downscale=4.0):
+    """CUDACache::storeFrame (CUDACache.cpp:76-88) by the reference's kernels: (campos, normals, depth, n_valid) at cache size."""
+    depth, normals, Kinv4 = _f(depth, normals, np.reshape(Kinv4, 16))
+    H, W = depth.shape
+    Wd, Hd = int(W / downscale), int(H / downscale)
+    cam, nrm, dd = np.zeros((Hd, Wd, 4), np.float32), np.zeros((Hd, Wd, 4), np.float32), np.zeros((Hd, Wd), np.float32)
+    nv = C.c_int(0)
+    f = lib_image().ref_store_frame
+    f.argtypes = [C.c_int] * 4 + [C.c_void_p] * 6 + [C.POINTER(C.c_int)]
+    f(W, H, Wd, Hd, _p(Kinv4), _p(depth), _p(normals), _p(cam), _p(nrm), _p(dd), C.byref(nv))
+    return cam, nrm, dd, int(nv.value)
+
+
+def process_depth(depth, erode_radius=1, erode_diff=0.001, erode_ratio=0.8, bf_radius=2, sigma_d=2.0, sigma_r=100000.0):
+    (depth,) = _f(depth); H, W = depth.shape; out = np.zeros_like(depth)
+    f = lib_image().ref_process_depth
+    f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
+    f(W, H, _p(depth), _p(out), int(erode_radius), erode_diff, erode_ratio, int(bf_radius), sigma_d, sigma_r)
+    return out
+
+
+def depth_to_normals(depth, Kinv4):
+    depth, Kinv4 = _f(depth, np.reshape(Kinv4, 16)); H, W = depth.shape
+    nrm, xyz = np.zeros((H, W, 4), np.float32), np.zeros((H, W, 4), np.float32)
+    f = lib_image().ref_depth_to_normals
+    f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f(W, H, _p(Kinv4), _p(depth), _p(nrm), _p(xyz))
+    return nrm, xyz

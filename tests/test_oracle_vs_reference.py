@@ -185,3 +185,44 @@ def test_reference_solver_matches_oracle_at_baseline_sizes(oracle, name, K, m, w
     worst = max(max(S.pose_error(P[k], tr.poses[k])) for k in range(K))
     print(f"{name}: reference vs oracle after 7 GN x 5 PCG: {worst:.2e}")
     assert worst < 1e-4, worst
+
+
+# ---- the reference's image kernels (CUDAImageUtil.cu), emulated the same way ------------------------------------
+
+def _kinv4(oracle, K):
+    K4 = np.eye(4, dtype=np.float32); K4[:3, :3] = np.asarray(K, np.float32)
+    return oracle.mat4_inverse(K4)
+
+
+def test_frame_cache_matches_reference_kernels(oracle):
+    """CUDACache::storeFrame = convertDepthFloatToCameraSpaceFloat4 + resampleFloat4 x2 + resampleFloat + countNumValidDepth
+    (CUDACache.cpp:76-88), run by the reference's kernels, against orc_build_cache: bit for bit, masked and full frames,
+    an odd frame size and a non-integer downscale."""
+    for pb, ds in ((S.make_problem(2, 10, seed=51, background=False), 4.0), (S.make_problem(2, 10, seed=52, background=True), 4.0),
+                   (S.make_problem(2, 10, seed=53, background=True, H=37, W=53, K=S.NOCS_K * np.array([[53 / 640], [37 / 480], [1.0]])), 4.0),
+                   (S.make_problem(2, 10, seed=54, background=False), 3.0)):
+        for k in range(2):
+            depth = pb.depth[k].copy(); depth[5:9, 7:30] = 0.05; depth[20, 20] = np.nan            # below the 0.1 m validity gate, and a NaN
+            cam, nrm, dd, nv = R.store_frame(depth, pb.normals[k], _kinv4(oracle, pb.K), ds)
+            o = oracle.build_cache(depth, pb.normals[k], pb.K, ds)
+            assert np.array_equal(bits(o["campos"]), bits(cam)) and np.array_equal(bits(o["normals"]), bits(nrm))
+            assert np.array_equal(bits(o["depth"]), bits(dd)) and o["n_valid"] == nv
+
+
+def test_depth_preprocessing_matches_reference_kernels(oracle):
+    """Frame::processDepth (erodeDepthMapDevice, gaussFilterDepthMapDevice x2) and Frame::depthToCloudAndNormals
+    (convertDepthFloatToCameraSpaceFloat4 + computeNormals_Kernel) by the reference's kernels against the oracle."""
+    rng = np.random.default_rng(3)
+    for shape, bg in (((96, 128), True), ((61, 67), False), ((120, 160), False)):
+        Ks = S.NOCS_K.copy(); Ks[0] *= shape[1] / 640; Ks[1] *= shape[0] / 480
+        pb = S.make_problem(2, 10, seed=60 + shape[0], background=bg, H=shape[0], W=shape[1], K=Ks)
+        depth = (pb.depth[0] + (pb.depth[0] > 0) * rng.normal(scale=0.002, size=shape)).astype(np.float32)
+        depth[rng.random(shape) < 0.02] = 0                                                      # holes
+        for params in (dict(), dict(erode_radius=2, erode_diff=0.01, erode_ratio=0.5, bf_radius=1, sigma_d=1.0, sigma_r=0.02)):
+            a, b = oracle.process_depth(depth, **params), R.process_depth(depth, **params)
+            assert np.array_equal(bits(a), bits(b)), (shape, params)
+        filt = oracle.process_depth(depth)
+        no, xo = oracle.depth_to_normals(filt, pb.K)
+        nr, xr = R.depth_to_normals(filt, _kinv4(oracle, pb.K))
+        assert np.array_equal(bits(xo), bits(xr))
+        assert np.array_equal(bits(no), bits(nr))
