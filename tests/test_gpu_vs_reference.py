@@ -41,3 +41,46 @@ def test_hip_matches_the_reference_solver(name, K, m, wd, seed, bg):
     worst = max(max(S.pose_error(got[k], ref[k])) for k in range(K))
     print(f"{name}: HIP vs the reference's own solver after 7 GN x 5 PCG: worst pose difference {worst:.2e}")
     assert worst < 1e-4, worst
+
+
+@pytest.mark.skipif(not os.path.exists(R.SO_IMAGE), reason="oracle/_ref/libbtba_ref_image.so not built")
+def test_hip_frame_cache_and_preprocessing_match_the_reference_kernels():
+    """btba_build_cache / btba_process_depth / btba_depth_to_normals against the reference's own CUDAImageUtil kernels
+    (run on the CPU): the frame cache bit for bit, the filtered depth and the normals to fp32 round-off."""
+    import torch
+    from bundletrack_amd.optimizer import Workspace, build_cache, process_depth, depth_to_normals
+    dev = torch.device("cuda:0")
+    ws = Workspace()
+    pb = S.make_problem(3, 10, seed=77, background=False)
+    K4 = np.eye(4, dtype=np.float32); K4[:3, :3] = pb.K
+    from oracle import oracle as O            # only for the reference-ordered 4x4 inverse of K
+    Kinv = O.mat4_inverse(K4)
+    d = [torch.from_numpy(pb.depth[k]).to(dev) for k in range(3)]
+    n = [torch.from_numpy(pb.normals[k]).to(dev) for k in range(3)]
+    campos, nrm, nvalid, intr = build_cache(ws, d, n, pb.H, pb.W, pb.K)
+    ws.sync()
+    for k in range(3):
+        cam_r, nrm_r, _, nv_r = R.store_frame(pb.depth[k], pb.normals[k], Kinv)
+        assert np.array_equal(campos[k].cpu().numpy().view(np.uint32), cam_r.view(np.uint32))
+        assert np.array_equal(nrm[k].cpu().numpy().view(np.uint32), nrm_r.view(np.uint32))
+        assert int(nvalid[k]) == nv_r
+    rng = np.random.default_rng(1)
+    Ks = S.NOCS_K.copy(); Ks[0] *= 160 / 640; Ks[1] *= 120 / 480
+    small = S.make_problem(2, 10, seed=78, background=True, H=120, W=160, K=Ks)
+    depth = (small.depth[0] + rng.normal(scale=0.002, size=small.depth[0].shape)).astype(np.float32)
+    filt = process_depth(ws, torch.from_numpy(depth).to(dev))
+    ws.sync()
+    ref_filt = R.process_depth(depth)
+    fg = filt.cpu().numpy()
+    # the filter weights go through expf: the device's and glibc's differ in the last ulp, so the filtered depth agrees to
+    # round-off (like tests/test_depth_processing.py against the oracle), with the same validity pattern
+    mism = (fg == 0) != (ref_filt == 0)                                  # a pixel within an ulp of the 0.01 m mean gate may flip
+    diff = np.abs(fg - ref_filt)[~mism]
+    # ... and so may a neighbour's membership in a pixel's window (|c - mean| < 0.01): a handful of outputs move by a tap's weight
+    assert mism.sum() <= 4 and (diff > 2e-6).sum() <= 4 and diff.max() < 2e-3, (int(mism.sum()), int((diff > 2e-6).sum()), float(diff.max()))
+    K4s = np.eye(4, dtype=np.float32); K4s[:3, :3] = small.K
+    nr, _ = R.depth_to_normals(fg, O.mat4_inverse(K4s))                 # same input on both sides
+    ng = depth_to_normals(ws, filt, small.K)
+    ws.sync()
+    ng = ng.cpu().numpy()
+    assert np.array_equal(ng == 0, nr == 0) and np.abs(ng - nr).max() <= 2e-6
