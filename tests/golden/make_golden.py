@@ -1,10 +1,8 @@
 """Generates tests/golden/*.npz.
 
-SELF-DERIVED fixtures: the reference repository contains no golden vectors, recorded solver I/O or
-tests for this path and cannot be executed here, so these files are outputs of THIS
-repo's CPU oracle (oracle/btba_oracle.c, accum_mode=1) on seeded synthetic problems.  They pin the
-oracle against regressions and give the GPU tests a fixed target; they do NOT pin parity with the
-reference -- parity stays "unpinned" (DESIGN.md section 3).
+SELF-DERIVED regression fixtures: outputs of THIS repo's CPU oracle (oracle/btba_oracle.c, accum_mode=1) on seeded
+synthetic problems; they pin the oracle against regressions and give the GPU tests a fixed target.  The golden vectors
+produced by the REFERENCE itself are the ref_*.npz files next to these (make_reference_golden.py).
 
     python tests/golden/make_golden.py
 """
