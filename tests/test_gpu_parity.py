@@ -13,7 +13,7 @@ from bundletrack_amd import _lib, synthetic as S
 
 pytestmark = pytest.mark.gpu
 TOL_R, TOL_T = 1e-4, 1e-4
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith("ref_"))
 
 
 @pytest.fixture(scope="module")
