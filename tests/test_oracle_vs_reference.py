@@ -175,10 +175,13 @@ def test_reference_solver_matches_oracle_per_iterate(oracle, case):
     assert worst < case["tol"], worst
 
 
-@pytest.mark.parametrize("name,K,m,wd,config", [("c2", 10, 1000, 0.0, 2), ("c3", 15, 2000, 1.0, 3)])
+@pytest.mark.parametrize("name,K,m,wd,config", [("c2", 10, 1000, 0.0, 2), ("c3", 15, 2000, 1.0, 3), ("c4", 30, 4000, 1.0, 4)])
 def test_reference_solver_matches_oracle_at_baseline_sizes(oracle, name, K, m, wd, config):
-    """BASELINE.json configs[1] and configs[2] (the headline), same seeds as the GPU full-size tests."""
-    pb = S.make_problem(K, m, S.config_seed(config), background=True, full_res=False)
+    """BASELINE.json configs[1], configs[2] (the headline) and configs[3] (K=30, 4k corr/pair, 60-keyframe pool pruned to 30),
+    same seeds as the GPU full-size tests.  c4 takes the emulated reference ~40 s (435 pairs x 19 200 pixels x 7 iterations)."""
+    seed = S.config_seed(config)
+    angles = S.pruned_pool_angles(60, 30, seed) if name == "c4" else None
+    pb = S.make_problem(K, m, seed, background=True, full_res=False, angles=angles)
     campos, normals, intr = S.analytic_cache(pb)
     tr = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=wd, n_threads=4))
     P, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, weight_dense=wd)
