@@ -87,7 +87,17 @@ def cpu_baseline(cfg, inst, budget_s=20.0):
         dt = time.perf_counter() - t0
         out[label] = (7.0 * n / dt, n, dt, nt)
     best = max(out.values(), key=lambda v: v[0])
-    return {"value": round(best[0], 3), "unit": "GN iterations/s", "cores": best[3], "kind": "port",
+    ref_note = None
+    try:        # the reference's own solver, compiled for the CPU and run through the sequential launch emulator (oracle/_ref):
+        from oracle import reference as R           # one thread by construction, every sum through emulated atomics -- context, not the baseline
+        if os.path.exists(R.SO_SOLVER) and cfg["K"] <= 15:
+            t0 = time.perf_counter()
+            R.solve(inst["campos"], inst["normals"], inst["intr"], inst["corr"], inst["poses"], weight_dense=cfg["w_dense"])
+            ref_note = {"gn_iters_per_s": round(7.0 / (time.perf_counter() - t0), 3), "cores": 1,
+                        "what": "wenbowen123/BundleTrack solveBundlingStub + all kernels, emulated thread by thread on the host (oracle/_ref/libbtba_ref_solver.so)"}
+    except Exception:
+        ref_note = None
+    return {"value": round(best[0], 3), "unit": "GN iterations/s", "cores": best[3], "kind": "port", "reference_emulated": ref_note,
             "sample": f"{best[1]} full solves (7 GN x 5 PCG) of one {cfg['desc']} instance in {best[2]:.1f} s; "
                       f"1 thread: {out['1t'][0]:.2f} it/s, {nmt} threads: {out['all'][0]:.2f} it/s (gcc -O3 AVX2 + OpenMP, oracle/btba_oracle.c)",
             "host_cpus": ncpu, "host_cpu_model": _cpu_model()}
