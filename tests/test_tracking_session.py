@@ -96,7 +96,7 @@ def test_c1_sliding_window_hip_vs_oracle(oracle, tmp_path):
     d = np.array(par.diffs)
     # A converged window sits on the reference's PCG guard (r.z <= 1e-6 => no step, SolverBundling.cu:728-818): r.z
     # hovers at 0.9-1.1e-6 and last-bit rounding decides whether one more ~1e-4 step is taken in an iteration.  The
-    # oracle's own two summation orders disagree on those calls (scripts/dbg_session.py); one or two flipped steps move a
+    # oracle's own two summation orders disagree on those calls (tests/tools/dbg_session.py); one or two flipped steps move a
     # pose by 1-2.5e-4, so those calls are held to 5e-4.
     print("BA calls: %d, median diff %.2e, over 1e-4: %s" % (len(d), np.median(d), np.round(d[d >= 1e-4], 6).tolist()))
     assert np.median(d) < 1e-5 and (d < 1e-4).mean() >= 0.9 and d.max() < 5e-4, d

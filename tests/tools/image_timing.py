@@ -1,7 +1,7 @@
 """Per-frame pre-processing timing at 640x480: btba_process_depth (erode + 2 bilateral passes,
 one launch) and btba_depth_to_normals (one launch), against the CPU oracle.  GPU box only."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(_TESTS)); sys.path.insert(0, _TESTS)
 import numpy as np, torch
 from bundletrack_amd import synthetic as S
 from bundletrack_amd.optimizer import Workspace, process_depth, depth_to_normals, DEPTH_PROCESSING_DEFAULTS

@@ -1,7 +1,7 @@
 """Correspondence RANSAC timing: all 105 frame pairs of a K=15 window, 2 000 matches per pair, 2 000 trials (the
 reference's ransac.max_iter) in ONE call, against the CPU oracle on a sample of pairs.  GPU box only."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(_TESTS)); sys.path.insert(0, _TESTS)
 import numpy as np, torch
 from bundletrack_amd.optimizer import Workspace
 from bundletrack_amd.ransac import pack_points, ransac_packed
