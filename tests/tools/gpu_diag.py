@@ -1,5 +1,5 @@
 """GPU diagnostic: HIP path vs CPU oracle, quantity by quantity, plus a first timing.
-Run on the GPU box:  python scripts/gpu_diag.py [K] [m]"""
+Run on the GPU box:  python tests/tools/gpu_diag.py [K] [m]"""
 import os
 import sys
 import time
