@@ -84,3 +84,45 @@ def test_hip_frame_cache_and_preprocessing_match_the_reference_kernels():
     ws.sync()
     ng = ng.cpu().numpy()
     assert np.array_equal(ng == 0, nr == 0) and np.abs(ng - nr).max() <= 2e-6
+
+
+def test_random_windows_match_the_reference_solver():
+    """Forty seeded windows of random shape (2-9 frames, 0-400 matches per pair, masked or 100 %-valid frames, feature and
+    dense weights on or off, perturbations up to 3 deg / 8 mm) through the HIP path and through the reference's own solver.
+    Well-conditioned windows (>= 150 matches per pair on an object mask, or features alone) are held to the 1e-4 bar.
+    The others -- 100 %-valid frames, the dense term alone, or only 40 matches per pair next to it -- are the windows the
+    reference itself determines only to ~1e-3: the dense term's accept tests (<= 2 cm, >= cos 45 deg, in-image) are
+    discontinuous, one pixel flipping on a last-bit difference moves such a window by ~1e-4 and the next iterations
+    amplify it (tests/tools/dbg_window.py 9 shows it iterate by iterate).  They are held to 5e-3
+    (the worst, a dense-only K=3 window on 100 %-valid frames, sits at 2e-3)."""
+    rng = np.random.default_rng(2024)
+    worst_strict = worst_loose = 0.0
+    n_strict = 0
+    above = []
+    n_windows = 40
+    for trial in range(n_windows):
+        K = int(rng.integers(2, 10))
+        m = int(rng.choice([0, 40, 150, 400]))
+        bg = bool(rng.integers(0, 2))
+        wd = float(rng.choice([0.0, 1.0, 1.0]))
+        if m == 0 and wd == 0.0:
+            wd = 1.0
+        pb = S.make_problem(K, m, 5000 + trial, background=bg, full_res=False, perturb_deg=float(rng.uniform(0.5, 3.0)), perturb_m=float(rng.uniform(0.001, 0.008)))
+        campos, normals, intr = S.analytic_cache(pb)
+        ref, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, weight_dense=wd)
+        got = hip_solve(pb, wd)
+        assert np.isfinite(got).all()
+        err = max(max(S.pose_error(got[k], ref[k])) for k in range(K))
+        strict = (m >= 150) and (wd == 0.0 or not bg) and K >= 3
+        if strict:
+            worst_strict = max(worst_strict, err); n_strict += 1
+            assert err < 1e-4, (trial, K, m, bg, wd, err)
+        else:
+            worst_loose = max(worst_loose, err)
+            assert err < 5e-3, (trial, K, m, bg, wd, err)
+            if err >= 1e-4:
+                above.append((trial, K, m, 'full' if bg else 'mask', wd, float(f'{err:.1e}')))
+    print(f"random windows: {n_strict} well-conditioned, worst {worst_strict:.2e}; {n_windows - n_strict} weakly conditioned, worst {worst_loose:.2e}, "
+          f"{len(above)} of them above 1e-4 (trial, K, m, frames, w_dense, err): {above}")
+    assert len(above) <= n_windows // 4                  # even in the weak class most windows agree to 1e-4
+    assert n_strict >= 6
