@@ -13,7 +13,9 @@ export TMPDIR=/tmp
 cd /tmp
 export BTBA_BENCH_NPROC=1
 ARGS="--steps 3 --warmup 1 --distinct 4 --no-cpu-baseline $*"
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$REPO/bench.py" $ARGS > "$OUT/stats.log" 2>&1
+# the stats pass runs bench.py's DEFAULT step counts (20 timed + 3 warm-up), so that the kernel durations are taken at the
+# same clocks as the bench line they are compared with; only the CPU baseline is left out (it spawns worker processes)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$REPO/bench.py" --no-cpu-baseline $* > "$OUT/stats.log" 2>&1
 echo "stats rc=$?" >> "$OUT/stats.log"
 timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o bench -- python "$REPO/bench.py" $ARGS --no-kernel-timing > "$OUT/fetch.log" 2>&1
 echo "fetch rc=$?" >> "$OUT/fetch.log"
