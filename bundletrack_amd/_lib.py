@@ -29,6 +29,7 @@ ENTRYJ_DTYPE = np.dtype(
 EXPORTED_SYMBOLS = [
     "btba_params_default", "btba_strerror", "btba_last_hip_error", "btba_version",
     "btba_workspace_create", "btba_workspace_create_on_stream", "btba_workspace_destroy", "btba_workspace_sync",
+    "btba_workspace_wait_stream", "btba_workspace_signal_stream",
     "btba_optimize_frames", "btba_optimize_frames_keyed", "btba_frame_cache_clear", "btba_ransac_pairs", "btba_build_cache", "btba_solve_batch", "btba_collect_stats",
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
@@ -135,6 +136,8 @@ def lib() -> C.CDLL:
         L.btba_workspace_destroy.argtypes = [C.c_void_p]
         L.btba_workspace_destroy.restype = None
         L.btba_workspace_sync.argtypes = [C.c_void_p]
+        L.btba_workspace_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.btba_workspace_signal_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.btba_collect_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.btba_optimize_frames.argtypes = [
             C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_void_p,

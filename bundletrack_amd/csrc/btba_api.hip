@@ -59,7 +59,7 @@ struct btba_workspace {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int device = 0;
-    DevBuf x, T, Tinv, sparse_part, dense_part, pairsum, dense_pairs, ptrs;
+    DevBuf x, T, Tinv, sparse_part, dense_part, pairsum, dense_pairs, ptrs, big_A;
     DevBuf corr, offsets, poses, campos, normals, nvalid;   // optimize_frames staging
     DevBuf valid_lists, valid_counts;                       // per-frame lists of pixels with a depth (compact cache)
     std::vector<int32_t> dense_pairs_host;                  // what dense_pairs currently holds
@@ -70,7 +70,7 @@ struct btba_workspace {
     bool lds_attr_set = false;
     bool always_time_region = false;   // optimize_frames: ms_solve is part of its stats contract
     hipStream_t aux_stream = nullptr;  // second half of a batch runs here (software pipelining across instances)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_order = nullptr;
 
     // persistent frame cache (btba_optimize_frames_keyed): compact (z, n) frames, their valid-pixel lists and counts
     // live in pool slots that survive across calls; a keyframe is cached once, not once per BA call.
@@ -160,13 +160,14 @@ void btba_workspace_destroy(btba_workspace *ws)
     (void)hipStreamSynchronize(ws->stream);
     for (auto &ep : ws->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
-    DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs,
+    DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts,
                        &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->ransac };
     for (auto b : bufs) b->release();
     if (ws->aux_stream) (void)hipStreamDestroy(ws->aux_stream);
     if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
     if (ws->ev_join) (void)hipEventDestroy(ws->ev_join);
+    if (ws->ev_order) (void)hipEventDestroy(ws->ev_order);
     if (ws->owns_stream) (void)hipStreamDestroy(ws->stream);
     delete ws;
 }
@@ -176,6 +177,27 @@ int btba_workspace_sync(btba_workspace *ws)
     if (!ws) return BTBA_EINVAL;
     HIP_TRY(hipStreamSynchronize(ws->stream));
     return BTBA_OK;
+}
+
+static int order_streams(btba_workspace *ws, hipStream_t from, hipStream_t to)
+{
+    if (from == to) return BTBA_OK;
+    if (!ws->ev_order) HIP_TRY(hipEventCreateWithFlags(&ws->ev_order, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ws->ev_order, from));
+    HIP_TRY(hipStreamWaitEvent(to, ws->ev_order, 0));
+    return BTBA_OK;
+}
+
+int btba_workspace_wait_stream(btba_workspace *ws, void *stream)
+{
+    if (!ws) return BTBA_EINVAL;
+    return order_streams(ws, static_cast<hipStream_t>(stream), ws->stream);
+}
+
+int btba_workspace_signal_stream(btba_workspace *ws, void *stream)
+{
+    if (!ws) return BTBA_EINVAL;
+    return order_streams(ws, ws->stream, static_cast<hipStream_t>(stream));
 }
 
 void btba_trace_layout_get(int n_frames, int n_dense_pairs, int n_pcg_iters, btba_trace_layout *L)
@@ -304,7 +326,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
 {
     if (!ws || !prm || B < 1 || N < 2 || Hd < 2 || Wd < 2 || !intr || !poses) return BTBA_EINVAL;
     if (prm->n_gn_iters < 1 || prm->n_pcg_iters < 0) return BTBA_EINVAL;   // MLIB_ASSERT, CUDASolverBundling.cpp:194
-    if (N > BTBA_MAX_FRAMES) return BTBA_EINVAL;                            // the 6N x 6N system must fit one CU's 160 KB of LDS
+    if (N > BTBA_MAX_FRAMES) return BTBA_EINVAL;                            // MAX_NUM_IMAGES of the reference (GlobalDefines.h:8) is 85 as well
     const int P = N * (N - 1) / 2;
     const bool use_sparse = prm->weight_sparse > 0.0f && corr && pair_offsets && max_corr_per_pair > 0;
     // dense pair list
@@ -383,17 +405,24 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.tr_pcg = L.off_pcg; D.tr_delta = L.off_delta; D.tr_dpair = L.off_dense_pair; D.tr_A = L.off_A; D.tr_clk = L.off_clk;
 
     const size_t n = 6 * (size_t)N, ld = 4 * (((n + 3) / 4) | 1);
-    const size_t lds_core = (n * ld + 6 * ld + 16 + 16 * (size_t)N + 4 * (size_t)D.n_dense_pairs + (size_t)N + 1 + (size_t)P + 288) * sizeof(float);
-    const size_t lds_pairs = ((size_t)P * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals) * sizeof(float);
+    // the 6N x 6N matrix lives in the CU's LDS when it fits (N <= BTBA_MAX_FRAMES_LDS with the default pair list); larger
+    // windows (up to the reference's 85 frames) keep it in an L2-resident global scratch and run the multi-wave PCG
+    const size_t lds_rest = (6 * ld + 16 + 16 * (size_t)N + 4 * (size_t)D.n_dense_pairs + (size_t)N + 1 + (size_t)P + 288) * sizeof(float);
     const size_t lds_limit = 160 * 1024;
+    const bool a_global = n * ld * sizeof(float) + lds_rest > lds_limit;
+    const size_t lds_core = (a_global ? 0 : n * ld * sizeof(float)) + lds_rest;
+    const size_t lds_pairs = ((size_t)P * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals) * sizeof(float);
     D.pairsum_in_lds = (lds_core + lds_pairs <= 64 * 1024) ? 1 : 0;   // keep two workgroups per CU when it fits
     if (!D.pairsum_in_lds && lds_core + lds_pairs <= lds_limit && B <= 256) D.pairsum_in_lds = 1;
     const size_t lds_bytes = lds_core + (D.pairsum_in_lds ? lds_pairs : 0);
     if (lds_bytes > lds_limit) return BTBA_EINVAL;
     if (!D.pairsum_in_lds) { if ((rc = ws->pairsum.ensure((size_t)B * lds_pairs + 16))) return rc; }
+    if (a_global) { if ((rc = ws->big_A.ensure((size_t)B * n * ld * sizeof(float)))) return rc; }
     if (lds_bytes > 64 * 1024 || !ws->lds_attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         ws->lds_attr_set = true;
     }
 
@@ -504,8 +533,11 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                 }
             }
             if ((rc = time_begin(ws, timing, 2, &slot, H.st))) return rc;
-            if (D.pairsum_in_lds) k_system_solve<true><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h);
-            else k_system_solve<false><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h);
+            float *A_h = a_global ? ws->big_A.as<float>() + b0 * n * ld : nullptr;
+#define BTBA_SOLVE(LP, AG) k_system_solve<LP, AG><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h, A_h)
+            if (a_global) { if (D.pairsum_in_lds) BTBA_SOLVE(true, true); else BTBA_SOLVE(false, true); }
+            else { if (D.pairsum_in_lds) BTBA_SOLVE(true, false); else BTBA_SOLVE(false, false); }
+#undef BTBA_SOLVE
             if ((rc = time_end(ws, slot, H.st))) return rc;
         }
     }

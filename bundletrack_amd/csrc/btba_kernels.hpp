@@ -790,18 +790,20 @@ __device__ __forceinline__ float strided_sum(const float *__restrict__ q, int co
 
 // grid (B); dynamic LDS: A[n*ld] + 7 vectors[n] + scratch + (optionally) reduced pair sums.
 // cross_ok[p] (dense) = 1 when the dense cross block survives FlipJtJ (target < source).
-template <bool LDS_PAIRS>
+template <bool LDS_PAIRS, bool A_GLOBAL = false>
 __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int iter,
                                                         const float *__restrict__ sparse_partials, const float *__restrict__ dense_partials,
                                                         const int2 *__restrict__ dense_pairs, const int *__restrict__ adj_off, const int *__restrict__ adj,
                                                         float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv,
-                                                        float *__restrict__ pairsum_global, float *__restrict__ trace)
+                                                        float *__restrict__ pairsum_global, float *__restrict__ trace, float *__restrict__ A_scratch = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int N = D.n_frames, n = 6 * N, ld = 4 * (((n + 3) / 4) | 1);   // odd multiple of 4: 16-B rows, conflict-free ds_read_b128
-    float *A = lds;
-    float *vb = A + (size_t)n * ld;       // rhs / residual r   (A's pad columns n..ld-1 stay 0)
+    // windows of more than BTBA_MAX_FRAMES_LDS frames: the matrix does not fit the CU's LDS and lives in an L2-resident
+    // global scratch (A_GLOBAL); everything else keeps its place
+    float *A = A_GLOBAL ? A_scratch + (size_t)blockIdx.x * n * ld : lds;
+    float *vb = A_GLOBAL ? lds : A + (size_t)n * ld;       // rhs / residual r   (A's pad columns n..ld-1 stay 0)
     float *vM = vb + ld, *vz = vM + ld, *vp = vz + ld, *vAp = vp + ld, *vd = vAp + ld;     // vector stride ld (16-B aligned, zero padded)
     float *scratch = vd + ld;             // 16 floats
     float *vT = scratch + 16;             // this iterate's T[N][16]
@@ -1035,8 +1037,44 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     // ONE wave runs it: <= 186 unknowns = <= 3 rows per lane (4 provisioned), vectors live in registers, the two dot products per
     // step are DPP wave sums, only p travels through LDS.  No workgroup barrier inside the iteration (the
     // 16-wave version spent ~6 k cycles per step in barriers; this one ~1 k).
-    if (tid < 64) {
-        constexpr int kMaxRows = 4;                     // n = 6N <= 186 (N <= BTBA_MAX_FRAMES = 31 is enforced by the host)
+    if (A_GLOBAL) {
+        // large windows (n up to 510): all 16 waves, one row per thread.  A is symmetric, so thread `row` walks COLUMN `row`
+        // (A[k ld + row]: neighbouring threads read neighbouring addresses), p and the other vectors stay in LDS, the two dot
+        // products per step are workgroup sums.  Same recurrences and epsilon guards as the single-wave version below.
+        const int row = tid;
+        const bool live = row < n;
+        float r_ = live ? vb[row] : 0.0f, m_ = live ? vM[row] : 0.0f, d_ = 0.0f;
+        float p_ = m_ * r_;
+        if (live) vp[row] = p_;
+        float rz = block_sum(r_ * p_, scratch);          // (contains the barrier that publishes vp)
+        for (int li = 0; li < D.n_pcg; li++) {
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            if (live) {
+                int k = 0;
+                for (; k + 4 <= n; k += 4) {
+                    a0 += A[(size_t)k * ld + row] * vp[k]; a1 += A[(size_t)(k + 1) * ld + row] * vp[k + 1];
+                    a2 += A[(size_t)(k + 2) * ld + row] * vp[k + 2]; a3 += A[(size_t)(k + 3) * ld + row] * vp[k + 3];
+                }
+                for (; k < n; k++) a0 += A[(size_t)k * ld + row] * vp[k];
+            }
+            const float ap = (a0 + a1) + (a2 + a3);
+            const float pAp = block_sum(live ? p_ * ap : 0.0f, scratch);
+            const float alpha = (pAp > kEps) ? rz / pAp : 0.0f;
+            d_ = d_ + alpha * p_;
+            r_ = r_ - alpha * (live ? ap : 0.0f);
+            const float z_ = m_ * r_;
+            const float rz_new = block_sum(z_ * r_, scratch);
+            const float beta = (rz > kEps) ? rz_new / rz : 0.0f;
+            if (tr && tid == 0) { float *sc = tr + D.tr_pcg + 4 * li; sc[0] = pAp; sc[1] = alpha; sc[2] = rz_new; sc[3] = beta; }
+            rz = rz_new;
+            p_ = z_ + beta * p_;
+            __syncthreads();                             // every thread has finished reading the old p
+            if (live) vp[row] = p_;
+            __syncthreads();
+        }
+        if (live) vd[row] = d_;
+    } else if (tid < 64) {
+        constexpr int kMaxRows = 4;                     // n = 6N <= 186 (N <= BTBA_MAX_FRAMES_LDS = 31 on this path)
         const int lane = tid;
         float r_[kMaxRows], m_[kMaxRows], p_[kMaxRows], d_[kMaxRows];
         float part = 0.0f;

@@ -45,6 +45,15 @@ class Workspace:
     def sync(self):
         check(lib().btba_workspace_sync(self._h), "btba_workspace_sync")
 
+    def wait_stream(self, stream: int | None):
+        """Work enqueued on the workspace after this call waits (on the device) for what `stream` (a raw HIP stream handle,
+        None = the default stream) holds now: inputs produced on another stream."""
+        check(lib().btba_workspace_wait_stream(self._h, C.c_void_p(stream) if stream else None), "btba_workspace_wait_stream")
+
+    def signal_stream(self, stream: int | None):
+        """`stream` waits (on the device) for what the workspace has enqueued so far: results consumed on another stream."""
+        check(lib().btba_workspace_signal_stream(self._h, C.c_void_p(stream) if stream else None), "btba_workspace_signal_stream")
+
     def collect_stats(self) -> dict:
         s = Stats()
         check(lib().btba_collect_stats(self._h, C.byref(s)), "btba_collect_stats")
@@ -62,10 +71,24 @@ class Workspace:
             pass
 
 
-def _ptr_array(tensors):
+def _dev_ptr(t, what: str = "tensor"):
+    """Raw device address of a tensor handed across the C ABI, which sees plain pointers: the tensor must be a dense
+    row-major CUDA tensor of 4-byte (or byte) elements -- a strided view would be read as garbage without any error."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError(f"{what}: expected a CUDA tensor, got device {t.device}")
+    if not t.is_contiguous():
+        raise ValueError(f"{what}: expected a contiguous (row-major) tensor, got shape {tuple(t.shape)} with strides {tuple(t.stride())}; call .contiguous()")
+    if t.element_size() not in (1, 4):
+        raise ValueError(f"{what}: expected float32 / int32 / uint8 data, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _ptr_array(tensors, what: str = "frame map"):
     arr = (C.c_void_p * len(tensors))()
     for k, t in enumerate(tensors):
-        arr[k] = t.data_ptr()
+        arr[k] = _dev_ptr(t, f"{what} {k}")
     return arr
 
 
@@ -154,7 +177,7 @@ def build_cache(ws: Workspace, depths_gpu, normals_gpu, H, W, K, image_downscale
     Kf = np.ascontiguousarray(K, np.float32).reshape(9)
     dptr, nptr = _ptr_array(depths_gpu), _ptr_array(normals_gpu)
     check(lib().btba_build_cache(ws.handle, N, H, W, Kf.ctypes.data, float(image_downscale), C.cast(dptr, C.c_void_p), C.cast(nptr, C.c_void_p),
-                                 campos.data_ptr(), normals.data_ptr(), nvalid.data_ptr(), intr.ctypes.data), "btba_build_cache")
+                                 _dev_ptr(campos, "campos"), _dev_ptr(normals, "normals"), _dev_ptr(nvalid, "nvalid"), intr.ctypes.data), "btba_build_cache")
     return campos, normals, nvalid, intr
 
 
@@ -170,7 +193,7 @@ def build_cache_zn(ws: Workspace, depths_gpu, normals_gpu, H, W, K, image_downsc
     Kf = np.ascontiguousarray(K, np.float32).reshape(9)
     dptr, nptr = _ptr_array(depths_gpu), _ptr_array(normals_gpu)
     check(lib().btba_build_cache_zn(ws.handle, N, H, W, Kf.ctypes.data, float(image_downscale), C.cast(dptr, C.c_void_p), C.cast(nptr, C.c_void_p),
-                                    zn.data_ptr(), nvalid.data_ptr(), intr.ctypes.data), "btba_build_cache_zn")
+                                    _dev_ptr(zn, "zn"), _dev_ptr(nvalid, "nvalid"), intr.ctypes.data), "btba_build_cache_zn")
     return zn, nvalid, intr
 
 
@@ -178,7 +201,7 @@ def pack_zn(ws: Workspace, campos, normals):
     """Reference-layout float4 caches -> compact cache (camPos.xy are re-derived from z by the solver)."""
     torch = _torch()
     zn = torch.empty_like(campos)
-    check(lib().btba_pack_zn(ws.handle, campos.numel() // 4, campos.data_ptr(), normals.data_ptr(), zn.data_ptr()), "btba_pack_zn")
+    check(lib().btba_pack_zn(ws.handle, campos.numel() // 4, _dev_ptr(campos, "campos"), _dev_ptr(normals, "normals"), _dev_ptr(zn, "zn")), "btba_pack_zn")
     return zn
 
 
@@ -264,11 +287,11 @@ class BatchSolver:
             self.params.flags &= ~_lib.FLAG_TRACE
         rc = lib().btba_solve_batch(
             self.ws.handle, C.byref(self.params), B, N, Hd, Wd, intr.ctypes.data,
-            campos.data_ptr(), normals.data_ptr(),
-            corr_dev.data_ptr() if corr_dev is not None else None, stride,
-            pair_offsets_dev.data_ptr() if pair_offsets_dev is not None else None, int(max_corr_per_pair),
+            _dev_ptr(campos, "campos"), _dev_ptr(normals, "normals"),
+            _dev_ptr(corr_dev, "corr_dev"), stride,
+            _dev_ptr(pair_offsets_dev, "pair_offsets_dev"), int(max_corr_per_pair),
             dp.ctypes.data if dp is not None else None, dp.shape[0] if dp is not None else 0,
-            poses_dev.data_ptr(), tr.data_ptr() if tr is not None else None)
+            _dev_ptr(poses_dev, "poses_dev"), _dev_ptr(tr, "tr"))
         check(rc, "btba_solve_batch")
         self._last_layout = (L, N, npd if self.params.weight_dense_depth > 0 else 0)
         return tr
@@ -294,11 +317,11 @@ class BatchSolver:
         else:
             self.params.flags &= ~_lib.FLAG_TRACE
         rc = lib().btba_solve_batch_zn(
-            self.ws.handle, C.byref(self.params), B, N, int(H), int(W), Kf.ctypes.data, zn.data_ptr(),
-            corr_dev.data_ptr() if corr_dev is not None else None, stride,
-            pair_offsets_dev.data_ptr() if pair_offsets_dev is not None else None, int(max_corr_per_pair),
+            self.ws.handle, C.byref(self.params), B, N, int(H), int(W), Kf.ctypes.data, _dev_ptr(zn, "zn"),
+            _dev_ptr(corr_dev, "corr_dev"), stride,
+            _dev_ptr(pair_offsets_dev, "pair_offsets_dev"), int(max_corr_per_pair),
             dp.ctypes.data if dp is not None else None, dp.shape[0] if dp is not None else 0,
-            poses_dev.data_ptr(), tr.data_ptr() if tr is not None else None)
+            _dev_ptr(poses_dev, "poses_dev"), _dev_ptr(tr, "tr"))
         check(rc, "btba_solve_batch_zn")
         self._last_layout = (L, N, npd if self.params.weight_dense_depth > 0 else 0)
         return tr
@@ -319,7 +342,7 @@ def process_depth(ws: Workspace, depth_gpu, **kw):
     p = dict(DEPTH_PROCESSING_DEFAULTS); p.update(kw)
     H, W = depth_gpu.shape
     out = torch.empty_like(depth_gpu)
-    check(lib().btba_process_depth(ws.handle, H, W, depth_gpu.data_ptr(), out.data_ptr(), int(p["erode_radius"]), float(p["erode_diff"]), float(p["erode_ratio"]),
+    check(lib().btba_process_depth(ws.handle, H, W, _dev_ptr(depth_gpu, "depth_gpu"), _dev_ptr(out, "out"), int(p["erode_radius"]), float(p["erode_diff"]), float(p["erode_ratio"]),
                                    int(p["bf_radius"]), float(p["sigma_d"]), float(p["sigma_r"])), "btba_process_depth")
     return out
 
@@ -331,5 +354,5 @@ def depth_to_normals(ws: Workspace, depth_gpu, K, want_xyz=False):
     normals = torch.empty((H, W, 4), dtype=torch.float32, device=depth_gpu.device)
     xyz = torch.empty((H, W, 4), dtype=torch.float32, device=depth_gpu.device) if want_xyz else None
     Kf = np.ascontiguousarray(K, np.float32).reshape(9)
-    check(lib().btba_depth_to_normals(ws.handle, H, W, Kf.ctypes.data, depth_gpu.data_ptr(), normals.data_ptr(), xyz.data_ptr() if xyz is not None else None), "btba_depth_to_normals")
+    check(lib().btba_depth_to_normals(ws.handle, H, W, Kf.ctypes.data, _dev_ptr(depth_gpu, "depth_gpu"), _dev_ptr(normals, "normals"), _dev_ptr(xyz, "xyz")), "btba_depth_to_normals")
     return (normals, xyz) if want_xyz else normals

@@ -98,10 +98,13 @@ typedef struct btba_params {
 
 /* Timing / diagnostics filled by the solve entry points (all times in milliseconds, measured
  * with hipEvents on the workspace stream; per-kernel fields need BTBA_FLAG_TIME_KERNELS). */
-/* Largest window: the 6N x 6N normal matrix of an instance lives in one CU's 160 KB of LDS (186 x 188 floats at N = 31).
- * The reference ships max_BA_frames = 15 (config_ycbineoat.yml:27) and spins forever above 85 frames
- * (SolverBundling.cu:621-625); here a larger window is BTBA_EINVAL. */
-#define BTBA_MAX_FRAMES 31
+/* Largest window: 85 frames, the reference's MAX_NUM_IMAGES (GlobalDefines.h:8; its solver spins forever above it,
+ * SolverBundling.cu:621-625; it ships max_BA_frames = 15, config_ycbineoat.yml:27).  Up to BTBA_MAX_FRAMES_LDS frames the
+ * 6N x 6N normal matrix of an instance lives in one CU's 160 KB of LDS (186 x 188 floats at N = 31) and a single wave runs
+ * the PCG; larger windows keep the matrix in an L2-resident device scratch and run a 16-wave PCG (slower per iterate, same
+ * arithmetic).  A window of more than BTBA_MAX_FRAMES frames is BTBA_EINVAL. */
+#define BTBA_MAX_FRAMES 85
+#define BTBA_MAX_FRAMES_LDS 31
 
 typedef struct btba_stats {
     int32_t n_instances, n_frames, n_pairs, n_dense_pairs;
@@ -154,6 +157,13 @@ BTBA_API int btba_workspace_create(btba_workspace **out, void *stream);
 BTBA_API int btba_workspace_create_on_stream(btba_workspace **out, void *stream);
 BTBA_API void btba_workspace_destroy(btba_workspace *ws);
 BTBA_API int btba_workspace_sync(btba_workspace *ws);
+/* Stream ordering without a host wait, for callers whose producers / consumers run on another HIP stream (PyTorch's
+ * current stream, a camera driver's copy stream): _wait_stream makes everything enqueued on the workspace stream AFTER the
+ * call wait for what `stream` holds at the time of the call (inputs uploaded or rendered there); _signal_stream makes
+ * `stream` wait for what the workspace stream holds (poses / caches / filtered maps produced by the asynchronous entry
+ * points).  `stream` = NULL is the legacy default stream.  No-ops when `stream` is the workspace's own stream. */
+BTBA_API int btba_workspace_wait_stream(btba_workspace *ws, void *stream);
+BTBA_API int btba_workspace_signal_stream(btba_workspace *ws, void *stream);
 
 /* Drop-in for OptimizerGpu::optimizeFrames (LossGPU.cu:53-139).
  *   corres_host       : n_corres EntryJ on the host (any order; pair-major order as produced by

@@ -130,3 +130,13 @@ def test_marshal_window_layout_and_gate():
     assert w.n_edges_newframe == 5 and w.run_ba                      # new frame id 2 touches pairs (0,2),(1,2)
     w2 = bundler.marshal_window(frames, m, newframe=frames[0], min_fm_edges_newframe=5)
     assert not w2.run_ba and frames[0].status == "NO_BA"             # `<=` gate, Bundler.cpp:343-347
+
+
+def test_tensor_handover_is_validated():
+    """The C ABI sees plain pointers: the Python host layer refuses anything but dense row-major CUDA tensors (a strided
+    view -- e.g. torch.from_numpy of a fancy-indexed numpy array -- would otherwise be read as garbage without an error)."""
+    import torch
+    from bundletrack_amd.optimizer import _dev_ptr
+    assert _dev_ptr(None) is None
+    with pytest.raises(ValueError, match="CUDA"):
+        _dev_ptr(torch.zeros(4), "zn")

@@ -542,14 +542,22 @@ def test_edge_shapes_through_the_boundary(gpu, oracle):
         assert np.isfinite(poses).all()
         return worst, poses, d, n
 
-    # N = 31 (BTBA_MAX_FRAMES) on small frames (128 x 96 -> 32 x 24 cache; intrinsics scaled with the image)
+    # N = 31 (BTBA_MAX_FRAMES_LDS: the largest window whose matrix lives in LDS) on small frames (128 x 96 -> 32 x 24 cache;
+    # intrinsics scaled with the image)
     Ks = S.NOCS_K.copy(); Ks[:2] *= 0.2
     big = S.make_problem(31, 12, seed=91, background=False, H=96, W=128, K=Ks, rot_step_deg=(5.0, 6.0))
     worst, _, dN, nN = run(big)
     print(f"N=31: worst pose diff {worst:.2e}")
     assert worst < 5e-4, worst                           # 465 pairs of 12 matches each: dense-dominated, measured 8e-7 ... 4e-5
-    with pytest.raises(_lib.BtbaError) as e:             # N = 32 does not fit; a status, not `while(1);` (SolverBundling.cu:621-625)
-        opt.optimizeFrames(big.corr[:0], None, 32, big.H, big.W, dN + dN[:1], None, nN + nN[:1], np.tile(np.eye(4, dtype=np.float32), (32, 1, 1)), big.K)
+    # N = 32, 40 and 85 (= BTBA_MAX_FRAMES = the reference's MAX_NUM_IMAGES): the matrix moves to the global scratch and the
+    # PCG to 16 waves; same arithmetic, same bar
+    for N_big, seed in ((32, 93), (40, 94), (85, 95)):
+        pbN = S.make_problem(N_big, 12, seed=seed, background=False, H=96, W=128, K=Ks, rot_step_deg=(5.0, 6.0))
+        worst, _, dB, nB = run(pbN)
+        print(f"N={N_big}: worst pose diff {worst:.2e}")
+        assert worst < 5e-4, (N_big, worst)
+    with pytest.raises(_lib.BtbaError) as e:             # N = 86 is refused with a status, not `while(1);` (SolverBundling.cu:621-625)
+        opt.optimizeFrames(pbN.corr[:0], None, 86, pbN.H, pbN.W, dB + dB[:1], None, nB + nB[:1], np.tile(np.eye(4, dtype=np.float32), (86, 1, 1)), pbN.K)
     assert e.value.status == _lib.BTBA_EINVAL
     # 53 x 37 frames: int(W / 4) = 13, int(H / 4) = 9 (LossGPU.cu:56-57), nearest-neighbour resample with fractional scales
     Ko = S.NOCS_K.copy(); Ko[0] *= 53 / 640; Ko[1] *= 37 / 480
@@ -577,3 +585,41 @@ def test_edge_shapes_through_the_boundary(gpu, oracle):
     n = [gpu.torch.from_numpy(pb.normals[k]).to(gpu.dev) for k in range(pb.n_frames)]
     sparse_only.optimizeFrames(pb.corr, None, pb.n_frames, pb.H, pb.W, d, None, n, p2, pb.K)
     assert max(max(S.pose_error(poses_nodepth[k], p2[k])) for k in range(pb.n_frames)) < 2e-6
+
+
+def test_strided_tensors_are_refused(gpu):
+    from bundletrack_amd.optimizer import _dev_ptr
+    t = gpu.torch.zeros((4, 6, 8, 4), device=gpu.dev)
+    assert _dev_ptr(t, "zn") == t.data_ptr()
+    with pytest.raises(ValueError, match="contiguous"):
+        _dev_ptr(t.permute(0, 2, 1, 3), "zn")
+    with pytest.raises(ValueError, match="float32"):
+        _dev_ptr(t.double(), "zn")
+
+
+def test_workspace_on_its_own_stream_orders_with_torch(gpu, small_problem_masked):
+    """A workspace on a private non-blocking stream (btba_workspace_create) next to torch's stream: wait_stream orders the
+    solve after the uploads, signal_stream orders torch's read-back after the solve -- no host synchronisation in between.
+    Same poses as the default workspace (which runs on torch's stream), bit for bit."""
+    from bundletrack_amd.optimizer import Workspace, build_cache_zn
+    pb = small_problem_masked
+    torch = gpu.torch
+    d, n = upload_frames(gpu, pb)
+    zn, _, _ = build_cache_zn(gpu.ws, d, n, pb.H, pb.W, pb.K, 4.0)
+    gpu.ws.sync()
+    outs = []
+    for own in (False, True):
+        ws = Workspace(use_torch_stream=False) if own else gpu.ws
+        bs = gpu.BatchSolver(ws)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):                      # producer and consumer live on a third stream
+            corr_d, offs_d, mx, poses_d = batch_inputs(gpu, bs, zn.cpu().numpy()[None], None, [pb.corr], [pb.poses_init])
+            zn_b = zn[None].clone()
+            ws.wait_stream(side.cuda_stream)
+            bs.solve_zn(zn_b, pb.H, pb.W, pb.K, corr_d, offs_d, mx, poses_d)
+            ws.signal_stream(side.cuda_stream)
+            out = poses_d.to("cpu", non_blocking=False)
+        outs.append(out.numpy()[0].copy())
+        torch.cuda.synchronize()
+    assert np.isfinite(outs[0]).all() and not np.array_equal(outs[0], pb.poses_init)
+    assert np.array_equal(outs[0], outs[1])

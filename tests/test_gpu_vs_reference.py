@@ -18,12 +18,13 @@ def hip_solve(pb, wd):
     dev = torch.device("cuda:0")
     bs = BatchSolver(Workspace(), weight_dense_depth=wd)
     corr, offs, mx = bs.pack_correspondences([pb.corr], pb.n_frames)
-    zn = np.concatenate([pb.cache_depth[..., None], pb.cache_normals[..., :3]], -1).astype(np.float32)
+    zn = np.ascontiguousarray(np.concatenate([pb.cache_depth[..., None], pb.cache_normals[..., :3]], -1), np.float32)   # astype() alone keeps a strided layout
     zn_d = torch.from_numpy(zn[None]).to(dev)
     corr_d = torch.from_numpy(corr.view(np.uint8).reshape(1, -1, 32)).to(dev)
     offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
     poses_d = torch.from_numpy(pb.poses_init[None].copy()).to(dev)
     bs.solve_zn(zn_d, pb.H, pb.W, pb.K, corr_d, offs_d, mx, poses_d)
+    bs.ws.sync()
     return poses_d.cpu().numpy()[0]
 
 
@@ -40,6 +41,19 @@ def test_hip_matches_the_reference_solver(name, K, m, wd, seed, bg):
     got = hip_solve(pb, wd)
     worst = max(max(S.pose_error(got[k], ref[k])) for k in range(K))
     print(f"{name}: HIP vs the reference's own solver after 7 GN x 5 PCG: worst pose difference {worst:.2e}")
+    assert worst < 1e-4, worst
+
+
+def test_large_window_matches_the_reference_solver():
+    """40 frames (above BTBA_MAX_FRAMES_LDS = 31: matrix in the global scratch, 16-wave PCG) on 32 x 24 caches against the
+    reference's own solver, whose limit is MAX_NUM_IMAGES = 85."""
+    Ks = S.NOCS_K.copy(); Ks[:2] *= 0.2
+    pb = S.make_problem(40, 30, seed=96, background=False, H=96, W=128, K=Ks, rot_step_deg=(5.0, 6.0))
+    campos, normals, intr = S.analytic_cache(pb)
+    ref, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, weight_dense=1.0)
+    got = hip_solve(pb, 1.0)
+    worst = max(max(S.pose_error(got[k], ref[k])) for k in range(pb.n_frames))
+    print(f"N=40: HIP vs the reference's own solver: worst pose difference {worst:.2e}")
     assert worst < 1e-4, worst
 
 

@@ -190,6 +190,20 @@ def test_reference_solver_matches_oracle_at_baseline_sizes(oracle, name, K, m, w
     assert worst < 1e-4, worst
 
 
+@pytest.mark.parametrize("N,m,seed", [(40, 30, 96), (85, 12, 95)])
+def test_reference_solver_matches_oracle_on_large_windows(oracle, N, m, seed):
+    """Windows above the 31 frames the HIP path keeps in LDS, up to the reference's MAX_NUM_IMAGES = 85 (GlobalDefines.h:8),
+    on 32 x 24 caches: same problems as the GPU large-window tests."""
+    Ks = S.NOCS_K.copy(); Ks[:2] *= 0.2
+    pb = S.make_problem(N, m, seed=seed, background=False, H=96, W=128, K=Ks, rot_step_deg=(5.0, 6.0))
+    campos, normals, intr = S.analytic_cache(pb)
+    tr = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(n_threads=4))
+    P, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, weight_dense=1.0)
+    worst = max(max(S.pose_error(P[k], tr.poses[k])) for k in range(N))
+    print(f"N={N}: reference vs oracle after 7 GN x 5 PCG: {worst:.2e}")
+    assert worst < 1e-4, worst
+
+
 # ---- the reference's image kernels (CUDAImageUtil.cu), emulated the same way ------------------------------------
 
 def _kinv4(oracle, K):
