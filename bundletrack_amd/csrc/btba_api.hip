@@ -534,7 +534,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             }
             if ((rc = time_begin(ws, timing, 2, &slot, H.st))) return rc;
             float *A_h = a_global ? ws->big_A.as<float>() + b0 * n * ld : nullptr;
-#define BTBA_SOLVE(LP, AG) k_system_solve<LP, AG><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h, A_h)
+            float *out_h = (it == prm->n_gn_iters - 1) ? poses + 16 * b0 * N : nullptr;     // the last iterate's matrices go straight to the caller's buffer
+#define BTBA_SOLVE(LP, AG) k_system_solve<LP, AG><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h, A_h, out_h)
             if (a_global) { if (D.pairsum_in_lds) BTBA_SOLVE(true, true); else BTBA_SOLVE(false, true); }
             else { if (D.pairsum_in_lds) BTBA_SOLVE(true, false); else BTBA_SOLVE(false, false); }
 #undef BTBA_SOLVE
@@ -545,8 +546,6 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         HIP_TRY(hipEventRecord(ws->ev_join, ws->aux_stream));
         HIP_TRY(hipStreamWaitEvent(ws->stream, ws->ev_join, 0));
     }
-    // convertPosesToMatricesCU: T already holds Exp(x) of the final iterate
-    HIP_TRY(hipMemcpyAsync(poses, ws->T.p, sizeof(float) * 16 * (size_t)B * N, hipMemcpyDeviceToDevice, ws->stream));
     if ((rc = time_end(ws, reg))) return rc;
     HIP_TRY(hipGetLastError());
     return BTBA_OK;

