@@ -322,7 +322,7 @@ struct ZnSpec {      // compact cache + the full-res geometry it encodes
 static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int N, int Hd, int Wd, const float *intr,
                          const float *campos, const float *normals, const ZnSpec &Z, const btba_entryj *corr, int64_t corr_stride,
                          const uint32_t *pair_offsets, uint32_t max_corr_per_pair,
-                         const int32_t *dense_pairs, int Pd_in, float *poses, float *trace)
+                         const int32_t *dense_pairs, int Pd_in, float *poses, float *trace, int *order_flag = nullptr)
 {
     if (!ws || !prm || B < 1 || N < 2 || Hd < 2 || Wd < 2 || !intr || !poses) return BTBA_EINVAL;
     if (prm->n_gn_iters < 1 || prm->n_pcg_iters < 0) return BTBA_EINVAL;   // MLIB_ASSERT, CUDASolverBundling.cpp:194
@@ -384,6 +384,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.depth_min = prm->depth_min; D.depth_max = prm->depth_max;
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;
+    D.order_flag = order_flag;
     D.n_gn = prm->n_gn_iters;
     int zn_layout = 0;
     if (use_zn) {
@@ -681,34 +682,63 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     if (Wd < 2 || Hd < 2) return finish(BTBA_EINVAL);
     const int npix = Wd * Hd;
 
-    // A0/A6: bucket by frame pair (a pair-major input, the only order Bundler::optimizeGPU produces, passes through)
+    // A0/A6: correspondences by frame pair.  Bundler::optimizeGPU hands the array over pair-major with the segment lengths
+    // in n_match_per_pair (Bundler.cpp:298-323): when the lengths add up, the array is uploaded as it is and the sparse
+    // sweep itself checks every entry against the pair of its segment (a device flag read back with the poses); only
+    // if that check fails -- or without n_match_per_pair -- the host buckets the array (a pass over all of it).
     std::vector<uint32_t> offsets(P + 1, 0);
-    bool bucketed = false;
-    if ((rc = count_correspondences(corres_host, n_corres, N, offsets.data(), &bucketed))) return finish(rc);
-    const uint32_t kept = offsets[P];
     std::unique_ptr<btba_entryj[]> scattered;                 // only when the caller's order is not pair-major already
     const btba_entryj *upload = corres_host;
-    if (!bucketed && kept) {
-        scattered.reset(new btba_entryj[kept]);
-        scatter_correspondences(corres_host, n_corres, N, offsets.data(), scattered.get());
-        upload = scattered.get();
+    uint32_t kept = 0, max_per_pair = 0;
+    bool trust = false;
+    if (n_match_per_pair && n_corres) {
+        uint64_t tot = 0;
+        bool ok = true;
+        for (int p = 0; p < P && ok; p++) {
+            ok = n_match_per_pair[p] >= 0;
+            tot += (uint64_t)(ok ? n_match_per_pair[p] : 0);
+            offsets[p + 1] = (uint32_t)tot;
+        }
+        trust = ok && tot == n_corres;
     }
-    uint32_t max_per_pair = 0;
-    for (int p = 0; p < P; p++) max_per_pair = std::max(max_per_pair, offsets[p + 1] - offsets[p]);
+    auto bucket_on_host = [&]() -> int {
+        bool bucketed = false;
+        std::fill(offsets.begin(), offsets.end(), 0u);
+        if (int r = count_correspondences(corres_host, n_corres, N, offsets.data(), &bucketed)) return r;
+        kept = offsets[P];
+        upload = corres_host;
+        if (!bucketed && kept) {
+            scattered.reset(new btba_entryj[kept]);
+            scatter_correspondences(corres_host, n_corres, N, offsets.data(), scattered.get());
+            upload = scattered.get();
+        }
+        return BTBA_OK;
+    };
+    if (trust) kept = n_corres;
+    else if ((rc = bucket_on_host())) return finish(rc);
+    auto longest_segment = [&]() { uint32_t m = 0; for (int p = 0; p < P; p++) m = std::max(m, offsets[p + 1] - offsets[p]); return m; };
+    max_per_pair = longest_segment();
 
     const auto tu0 = std::chrono::steady_clock::now();
     if ((rc = ws->corr.ensure(sizeof(btba_entryj) * (size_t)(kept ? kept : 1)))) return finish(rc);
     if ((rc = ws->offsets.ensure(sizeof(uint32_t) * (P + 1)))) return finish(rc);
-    if ((rc = ws->poses.ensure(sizeof(float) * 16 * (size_t)N))) return finish(rc);
+    if ((rc = ws->poses.ensure(sizeof(float) * (16 * (size_t)N + 1)))) return finish(rc);      // + the order flag
     if ((rc = ws->campos.ensure(sizeof(float) * 4 * (size_t)N * npix))) return finish(rc);
     if ((rc = ws->normals.ensure(sizeof(float) * 4 * (size_t)N * npix))) return finish(rc);
     if ((rc = ws->nvalid.ensure(sizeof(int32_t) * N))) return finish(rc);
     auto hip_fail = [&](hipError_t e) { g_last_hip_error = (int)e; return finish(BTBA_EHIP); };
     hipError_t e;
-    if (kept && (e = hipMemcpyAsync(ws->corr.p, upload, sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
-    if ((e = hipMemcpyAsync(ws->offsets.p, offsets.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
-    if ((e = hipMemcpyAsync(ws->poses.p, poses, sizeof(float) * 16 * N, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
-    // the sources (caller's arrays, `offsets`, `scattered`) outlive the synchronising end of this call; the sync only serves the upload timer
+    std::vector<float> stage(16 * (size_t)N + 1);             // poses + one word for the device's "not pair-major" flag (0)
+    auto upload_inputs = [&]() -> hipError_t {
+        hipError_t r;
+        if (kept && (r = hipMemcpyAsync(ws->corr.p, upload, sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+        if ((r = hipMemcpyAsync(ws->offsets.p, offsets.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+        std::memcpy(stage.data(), poses, sizeof(float) * 16 * N);
+        stage[16 * (size_t)N] = 0.0f;
+        return hipMemcpyAsync(ws->poses.p, stage.data(), sizeof(float) * stage.size(), hipMemcpyHostToDevice, ws->stream);
+    };
+    if ((e = upload_inputs()) != hipSuccess) return hip_fail(e);
+    // the sources (caller's arrays, `offsets`, `scattered`, `stage`) outlive the synchronising end of this call; the sync only serves the upload timer
     if ((prm.flags & BTBA_FLAG_TIME_KERNELS) && (e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
     const auto tu1 = std::chrono::steady_clock::now();
 
@@ -769,16 +799,35 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
             if (tot * 10 < (long)N * npix * 6) prm.flags |= BTBA_FLAG_COMPACTION;
         }
     }
-    rc = solve_enqueue(ws, &prm, 1, N, Hd, Wd, intr, compact ? nullptr : ws->campos.as<float>(), compact ? nullptr : ws->normals.as<float>(), Z, ws->corr.as<btba_entryj>(), (int64_t)(kept ? kept : 1),
-                       ws->offsets.as<uint32_t>(), max_per_pair, pairs_ptr, n_pairs_dense, ws->poses.as<float>(), nullptr);
+    std::vector<float> out(16 * (size_t)N + 1);
+    btba_stats S;
+    int *order_flag = reinterpret_cast<int *>(ws->poses.as<float>() + 16 * (size_t)N);
+    auto solve_and_read = [&]() -> int {
+        int r = solve_enqueue(ws, &prm, 1, N, Hd, Wd, intr, compact ? nullptr : ws->campos.as<float>(), compact ? nullptr : ws->normals.as<float>(), Z, ws->corr.as<btba_entryj>(), (int64_t)(kept ? kept : 1),
+                              ws->offsets.as<uint32_t>(), max_per_pair, pairs_ptr, n_pairs_dense, ws->poses.as<float>(), nullptr, trust ? order_flag : nullptr);
+        if (r) return r;
+        hipError_t he;
+        if ((he = hipMemcpyAsync(out.data(), ws->poses.p, sizeof(float) * out.size(), hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) { g_last_hip_error = (int)he; return BTBA_EHIP; }
+        return btba_collect_stats(ws, &S);       // synchronises
+    };
+    rc = solve_and_read();
+    if (!rc && trust) {
+        uint32_t flag;
+        std::memcpy(&flag, &out[16 * (size_t)N], sizeof flag);
+        if (flag) {
+            // the array was not pair-major after all: bucket it on the host and solve again from the caller's poses
+            trust = false;
+            if ((rc = bucket_on_host())) { ws->always_time_region = false; return finish(rc); }
+            max_per_pair = longest_segment();
+            if ((rc = ws->corr.ensure(sizeof(btba_entryj) * (size_t)(kept ? kept : 1)))) { ws->always_time_region = false; return finish(rc); }
+            if ((e = upload_inputs()) != hipSuccess) { ws->always_time_region = false; return hip_fail(e); }
+            rc = solve_and_read();
+        }
+    }
     ws->always_time_region = false;
     if (rc) return finish(rc);
-    std::vector<float> out(16 * (size_t)N);
-    if ((e = hipMemcpyAsync(out.data(), ws->poses.p, sizeof(float) * 16 * N, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) return hip_fail(e);
-    btba_stats S;
-    if ((rc = btba_collect_stats(ws, &S))) return finish(rc);       // synchronises
-    for (float v : out) if (!std::isfinite(v)) return finish(BTBA_ENUMERIC);
-    std::memcpy(poses, out.data(), sizeof(float) * out.size());
+    for (size_t k = 0; k < 16 * (size_t)N; k++) if (!std::isfinite(out[k])) return finish(BTBA_ENUMERIC);
+    std::memcpy(poses, out.data(), sizeof(float) * 16 * (size_t)N);
     if (stats) {
         S.n_corr = kept;
         S.cache_frames_built = n_built;

@@ -61,6 +61,7 @@ struct SolveDims {
     int64_t tr_x, tr_T, tr_rhs, tr_prec, tr_pcg, tr_delta, tr_dpair, tr_A, tr_clk;
     int n_gn;
     int pairsum_in_lds;  // 1: stage reduced pair sums in LDS, 0: in global scratch
+    int *order_flag;     // non-null: the sparse sweep ORs 1 into it when an entry does not belong to the pair of its segment
     // compact (z, nx, ny, nz) frame cache: how a cached pixel maps back to camera space -- the arithmetic of k_build_cache
     float zn_ki[16];     // full-resolution intrinsicsInv (4x4 embedding, generic cofactor inverse)
     float zn_scale_w, zn_scale_h;   // (W-1)/(Wd-1), (H-1)/(Hd-1) of the nearest-neighbour resample
@@ -257,9 +258,11 @@ __device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *_
     for (int k = 0; k < kSparseVals; k++) acc[k] = 0.0f;
 
     const float delta2 = D.robust_delta * D.robust_delta;
+    bool misplaced = false;                       // an entry whose (imgIdx_i, imgIdx_j) is not this segment's pair
     auto accumulate = [&](const float4 &q0, const float4 &q1, bool live) {
         // q0 = (imgIdx_i, imgIdx_j, pos_i.x, pos_i.y)  q1 = (pos_i.z, pos_j.x, pos_j.y, pos_j.z)
         const float m = (live && __float_as_uint(q0.x) != 0xFFFFFFFFu) ? 1.0f : 0.0f;      // EntryJ::isValid
+        misplaced |= (m != 0.0f) & ((__float_as_uint(q0.x) != (uint32_t)fi) | (__float_as_uint(q0.y) != (uint32_t)fj));
         float wix, wiy, wiz, wjx, wjy, wjz;
         xform_point(Ti, q0.z, q0.w, q1.x, wix, wiy, wiz);
         xform_point(Tj, q1.y, q1.z, q1.w, wjx, wjy, wjz);
@@ -293,6 +296,7 @@ __device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *_
         accumulate(a0, a1, true);
         accumulate(b0, b1, live2);
     }
+    if (D.order_flag && misplaced) atomicOr(D.order_flag, 1);
     float *out = partials + (((size_t)b * D.n_pairs + p) * D.sparse_chunks + chunk) * kSparseVals;
     block_reduce_store<kSparseVals, 4>(acc, red, out);
 }

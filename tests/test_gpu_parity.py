@@ -623,3 +623,41 @@ def test_workspace_on_its_own_stream_orders_with_torch(gpu, small_problem_masked
         torch.cuda.synchronize()
     assert np.isfinite(outs[0]).all() and not np.array_equal(outs[0], pb.poses_init)
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_trusted_pair_major_upload_and_its_fallback(gpu, small_problem_masked):
+    """optimizeFrames with n_match_per_pair (what Bundler::optimizeGPU passes, Bundler.cpp:298-323): the array goes to the
+    device unchecked by the host and the sparse sweep verifies every entry against the pair of its segment.  Same bits as
+    the host-bucketed path; a shuffled array, wrong lengths, invalid entries and out-of-range indices all end where the
+    host path ends."""
+    pb = small_problem_masked
+    N = pb.n_frames
+    d, n = upload_frames(gpu, pb)
+    opt = gpu.OptimizerGpu(workspace=gpu.ws)
+
+    def run(corr, nm):
+        poses = pb.poses_init.copy()
+        opt.optimizeFrames(corr, nm, N, pb.H, pb.W, d, None, n, poses, pb.K)
+        return poses
+
+    base = run(pb.corr, None)                                   # host pass over the array (no lengths given)
+    assert np.array_equal(run(pb.corr, pb.n_match_per_pair), base)          # trusted: same offsets, same order, same bits
+    rng = np.random.default_rng(5)
+    shuffled = pb.corr[rng.permutation(len(pb.corr))]
+    by_host = run(shuffled, None)
+    assert np.array_equal(run(shuffled, pb.n_match_per_pair), by_host)      # lengths add up, order does not: device flag -> host bucketing
+    wrong = pb.n_match_per_pair.copy(); wrong[0] += 1
+    assert np.array_equal(run(pb.corr, wrong), base)                       # lengths do not add up: never trusted
+    shifted = pb.n_match_per_pair.copy(); shifted[0] -= 1; shifted[1] += 1  # sum right, one boundary off by one
+    assert np.array_equal(run(pb.corr, shifted), base)
+    holes = pb.corr.copy()
+    holes["imgIdx_i"][::7] = 0xFFFFFFFF                                    # invalid entries stay where they are on the trusted path
+    r_host, r_trust = run(holes, None), run(holes, pb.n_match_per_pair)
+    for k in range(N):
+        rr, tt = S.pose_error(r_host[k], r_trust[k])
+        assert rr < 2e-5 and tt < 2e-5                                     # same entries per pair in the same order, other lane / chunk assignment: fp32 round-off (measured 1.6e-6)
+    bad = pb.corr.copy(); bad["imgIdx_j"][3] = N + 2
+    for nm in (None, pb.n_match_per_pair):
+        with pytest.raises(_lib.BtbaError) as e:
+            run(bad, nm)
+        assert e.value.status == _lib.BTBA_EINVAL
