@@ -168,7 +168,11 @@ BTBA_API int btba_workspace_signal_stream(btba_workspace *ws, void *stream);
 /* Drop-in for OptimizerGpu::optimizeFrames (LossGPU.cu:53-139).
  *   corres_host       : n_corres EntryJ on the host (any order; pair-major order as produced by
  *                       Bundler::optimizeGPU is used as is, anything else is bucketed by frame pair).
- *   n_match_per_pair  : may be NULL (the reference stores it and never reads it, SBA.cpp:85).
+ *   n_match_per_pair  : may be NULL (the reference stores it and never reads it, SBA.cpp:85).  When given -- P = n(n-1)/2
+ *                       segment lengths in pair order (0,1) (0,2) ... as Bundler::optimizeGPU builds them -- and adding
+ *                       up to n_corres, the array is taken as pair-major and uploaded without a host pass; the device
+ *                       verifies every entry against its segment's pair and the call falls back to host bucketing if
+ *                       that check fails, so a wrong or inconsistent array costs time, never correctness.
  *   depth_dev[k]      : device float[H*W], metres, 0 = invalid          (Frame.h:73)
  *   normal_dev[k]     : device float4[H*W], xyz unit, w = 0, zeros = invalid (Frame.h:75)
  *   poses_rowmajor    : host float[n_frames*16], camera->model, in/out  (LossGPU.cu:88-97,121-130)
