@@ -59,11 +59,12 @@ struct btba_workspace {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int device = 0;
-    DevBuf x, T, Tinv, sparse_part, dense_part, pairsum, dense_pairs, ptrs, big_A;
+    DevBuf x, T, Tinv, sparse_part, dense_part, pairsum, dense_pairs, ptrs, big_A, solve_tab;
     DevBuf corr, offsets, poses, campos, normals, nvalid;   // optimize_frames staging
     DevBuf valid_lists, valid_counts;                       // per-frame lists of pixels with a depth (compact cache)
     std::vector<int32_t> dense_pairs_host;                  // what dense_pairs currently holds
     int dense_pairs_frames = -1;
+    int solve_tab_frames = -1;                              // window size solve_tab was built for
     std::vector<EventPair> events;                          // pending timed regions
     std::vector<hipEvent_t> event_pool;
     btba_stats stats{};
@@ -160,7 +161,7 @@ void btba_workspace_destroy(btba_workspace *ws)
     (void)hipStreamSynchronize(ws->stream);
     for (auto &ep : ws->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
-    DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A,
+    DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A, &ws->solve_tab,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts,
                        &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->ransac };
     for (auto b : bufs) b->release();
@@ -371,6 +372,18 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         ws->dense_pairs_host = pairs;
         ws->dense_pairs_frames = N;
     }
+    // tables of k_system_solve that depend on the window size only: canonical pair p -> (i << 8 | j), then the 72
+    // descriptors of the sparse 6x6 block entries (btba_kernels.hpp: sparse_entry_descriptor)
+    if (ws->solve_tab_frames != N) {
+        std::vector<int32_t> tab((size_t)P + 288);
+        int q = 0;
+        for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) tab[q++] = (i << 8) | j;
+        for (int t = 0; t < 72; t++) sparse_entry_descriptor(t >= 36, (t % 36) / 6, t % 6, &tab[(size_t)P + 4 * t]);
+        if ((rc = ws->solve_tab.ensure(sizeof(int32_t) * tab.size()))) return rc;
+        HIP_TRY(hipMemcpyAsync(ws->solve_tab.p, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice, ws->stream));
+        HIP_TRY(hipStreamSynchronize(ws->stream));         // `tab` is a local
+        ws->solve_tab_frames = N;
+    }
     const int32_t *d_adj_off = ws->dense_pairs.as<int32_t>() + 2 * (size_t)Pd;
     const int32_t *d_adj = d_adj_off + (N + 1);
 
@@ -408,7 +421,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     const size_t n = 6 * (size_t)N, ld = 4 * (((n + 3) / 4) | 1);
     // the 6N x 6N matrix lives in the CU's LDS when it fits (N <= BTBA_MAX_FRAMES_LDS with the default pair list); larger
     // windows (up to the reference's 85 frames) keep it in an L2-resident global scratch and run the multi-wave PCG
-    const size_t lds_rest = (6 * ld + 16 + 16 * (size_t)N + 4 * (size_t)D.n_dense_pairs + (size_t)N + 1 + (size_t)P + 288) * sizeof(float);
+    const size_t lds_rest = (6 * ld + 16 + 16 * (size_t)N + 4 * (size_t)D.n_dense_pairs + (size_t)N + 1 + (size_t)P + 288 + ((6 * (size_t)N + 3) & ~(size_t)3)) * sizeof(float);
     const size_t lds_limit = 160 * 1024;
     const bool a_global = n * ld * sizeof(float) + lds_rest > lds_limit;
     const size_t lds_core = (a_global ? 0 : n * ld * sizeof(float)) + lds_rest;
@@ -536,7 +549,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             if ((rc = time_begin(ws, timing, 2, &slot, H.st))) return rc;
             float *A_h = a_global ? ws->big_A.as<float>() + b0 * n * ld : nullptr;
             float *out_h = (it == prm->n_gn_iters - 1) ? poses + 16 * b0 * N : nullptr;     // the last iterate's matrices go straight to the caller's buffer
-#define BTBA_SOLVE(LP, AG) k_system_solve<LP, AG><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h, A_h, out_h)
+#define BTBA_SOLVE(LP, AG) k_system_solve<LP, AG><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h, A_h, out_h, ws->solve_tab.as<int>())
             if (a_global) { if (D.pairsum_in_lds) BTBA_SOLVE(true, true); else BTBA_SOLVE(false, true); }
             else { if (D.pairsum_in_lds) BTBA_SOLVE(true, false); else BTBA_SOLVE(false, false); }
 #undef BTBA_SOLVE

@@ -746,25 +746,28 @@ __device__ __forceinline__ float sparse_cross_entry(const float *rec, int r, int
 
 // Linear form of sparse_diag_entry / sparse_cross_entry: value = c1 rec[i1 + e es] + c2 rec[i2 + e es].
 // Returned as int4 (i1 | es << 8, i2, bits(c1), bits(c2)); es = record offset per endpoint (0 for n and cross blocks).
-__device__ __forceinline__ int4 sparse_entry_descriptor(bool cross, int r, int c)
+// (c1, c2 are 0 or +-1; the table is built once per window size on the host, btba_api.hip: solve_tables)
+__host__ __device__ inline void sparse_entry_descriptor(bool cross, int r, int c, int out[4])
 {
     const int br = r / 3, bc = c / 3, rr = r % 3, cc = c % 3;
     int i1 = 0, i2 = 0, es = 0;
-    float c1 = 0.0f, c2 = 0.0f;
+    int c1 = 0, c2 = 0;                                                // signs
     const int k = 3 - rr - cc;
-    const float sgn = ((cc - rr + 3) % 3 == 1) ? -1.0f : 1.0f;        // skew(v, rr, cc) = sgn v[k] for rr != cc
-    if (br == 0 && bc == 0) { if (rr == cc) { i1 = 0; c1 = 1.0f; } }
+    const int sgn = ((cc - rr + 3) % 3 == 1) ? -1 : 1;                 // skew(v, rr, cc) = sgn v[k] for rr != cc
+    if (br == 0 && bc == 0) { if (rr == cc) { i1 = 0; c1 = 1; } }
     else if (br == 0 && bc == 1) { if (rr != cc) { i1 = (cross ? 4 : 1) + k; c1 = -sgn; es = cross ? 0 : 3; } }
     else if (br == 1 && bc == 0) { if (rr != cc) { i1 = 1 + k; c1 = sgn; es = cross ? 0 : 3; } }
     else if (rr == cc) {                                               // tr(M) - M_rr = the other two diagonal entries
         const int a = (rr + 1) % 3, b = (rr + 2) % 3;
         const int dg[3] = { 0, 3, 5 };
-        i1 = cross ? 19 + 4 * a : 7 + dg[a]; i2 = cross ? 19 + 4 * b : 7 + dg[b]; c1 = 1.0f; c2 = 1.0f; es = cross ? 0 : 6;
+        i1 = cross ? 19 + 4 * a : 7 + dg[a]; i2 = cross ? 19 + 4 * b : 7 + dg[b]; c1 = 1; c2 = 1; es = cross ? 0 : 6;
     } else {
         const int lo = rr < cc ? rr : cc, hi = rr < cc ? cc : rr;
-        i1 = cross ? 19 + cc * 3 + rr : 7 + lo * 3 - lo * (lo - 1) / 2 + (hi - lo); c1 = -1.0f; es = cross ? 0 : 6;
+        i1 = cross ? 19 + cc * 3 + rr : 7 + lo * 3 - lo * (lo - 1) / 2 + (hi - lo); c1 = -1; es = cross ? 0 : 6;
     }
-    return make_int4(i1 | (es << 8), i2, __float_as_int(c1), __float_as_int(c2));
+    const int one = 0x3F800000, minus_one = (int)0xBF800000u;          // fp32 bit patterns of +-1
+    out[0] = i1 | (es << 8); out[1] = i2;
+    out[2] = c1 > 0 ? one : c1 < 0 ? minus_one : 0; out[3] = c2 > 0 ? one : c2 < 0 ? minus_one : 0;
 }
 
 __device__ __forceinline__ float block_sum(float v, float *scratch)
@@ -801,7 +804,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
                                                         const int2 *__restrict__ dense_pairs, const int *__restrict__ adj_off, const int *__restrict__ adj,
                                                         float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv,
                                                         float *__restrict__ pairsum_global, float *__restrict__ trace, float *__restrict__ A_scratch = nullptr,
-                                                        float *__restrict__ poses_out = nullptr)
+                                                        float *__restrict__ poses_out = nullptr, const int *__restrict__ solve_tab = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -822,7 +825,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     // reduced pair sums: in LDS when they fit (address space known at compile time -> ds_* instructions, not flat_*),
     // otherwise in an L2-resident global scratch (K = 30)
     float *ps;
-    if (LDS_PAIRS) ps = reinterpret_cast<float *>(entry_lut + 288);
+    float *x_l = reinterpret_cast<float *>(entry_lut + 288);       // this iterate's x (6 N floats, padded to 16 bytes): phase D would otherwise start with a fabric-latency load
+    if (LDS_PAIRS) ps = x_l + ((6 * N + 3) & ~3);
     else ps = pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals);
     float *pd = ps + (size_t)D.n_pairs * kSparseVals;          // model-frame dense pair sums (S, g, count)
     float *pdr = pd + (size_t)D.n_dense_pairs * kDenseVals;     // camera-frame sums as the sweep produced them
@@ -830,25 +834,29 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
 
     const long long clk0 = tr ? (long long)clock64() : 0;
 #define BTBA_STAMP(slot) do { if (tr && tid == 0) tr[D.tr_clk + (slot)] = (float)((long long)clock64() - clk0); } while (0)
-    for (int e = tid; e < 16 * N; e += nthr) vT[e] = T[16 * (size_t)b * N + e];
-    for (int e = tid; e < D.n_dense_pairs; e += nthr) { const int2 ij = dense_pairs[e]; dense_pairs_lds[2 * e] = ij.x; dense_pairs_lds[2 * e + 1] = ij.y; }
-    for (int e = tid; e < D.n_pairs; e += nthr) { int i, j; pair_from_index(e, N, i, j); pair_ij_l[e] = (i << 8) | j; }
-    if (tid < 72) { const int4 d = sparse_entry_descriptor(tid >= 36, (tid % 36) / 6, tid % 6); entry_lut[4 * tid] = d.x; entry_lut[4 * tid + 1] = d.y; entry_lut[4 * tid + 2] = d.z; entry_lut[4 * tid + 3] = d.w; }
-    if (D.use_dense) {
-        for (int e = tid; e < N + 1; e += nthr) adj_off_l[e] = adj_off[e];
-        for (int e = tid; e < 2 * D.n_dense_pairs; e += nthr) adj_l[e] = adj[e];
-    }
-    // Phase A: fixed-order reduction of the sweep partials (4 independent loads in flight per lane)
-    // (two items per lane per trip, all their loads issued before the first add: the partials come from other
-    //  CUs' write-through stores, i.e. every load is an L2 miss of ~1-2 k cycles, so memory-level parallelism is
-    //  what this phase is made of)
-    // four items per lane per trip, up to eight partials of each in flight (32 loads issued before the first add): the
+    // Staging of this iterate's T and of the pair tables into LDS.  Every one of these global loads is a fabric-latency
+    // miss (~2 k cycles; written by the previous launch / the host), and a load -> LDS-store loop per array serialises
+    // them behind s_waitcnt (measured: 7.7 k cycles for four tiny arrays).  So: the first trip of all four arrays is
+    // loaded into registers here, the partial sums' loads are issued behind them, and the LDS stores happen after
+    // the reduction -- the staging latency hides behind the first round of partial loads.
+    const int n_dp = D.n_dense_pairs, n_adj = D.use_dense ? 2 * D.n_dense_pairs : 0, n_ao = D.use_dense ? N + 1 : 0;
+    const float st_T = tid < 16 * N ? T[16 * (size_t)b * N + tid] : 0.0f;
+    const float st_x = tid < 6 * N ? x[6 * (size_t)b * N + tid] : 0.0f;
+    const int2 st_dp = tid < n_dp ? dense_pairs[tid] : make_int2(0, 0);
+    const int st_ao = tid < n_ao ? adj_off[tid] : 0;
+    const int st_adj = tid < n_adj ? adj[tid] : 0;
+    // canonical pair -> (i << 8 | j) and the 72 entry descriptors: constant per window size, tabulated by the host
+    const int st_pij = tid < D.n_pairs ? solve_tab[tid] : 0;
+    const int st_lut = tid < 288 ? solve_tab[D.n_pairs + tid] : 0;
+    // Phase A: fixed-order reduction of the sweep partials
+    BTBA_STAMP(6);
+    // several items per lane per trip, up to eight partials of each in flight (24-40 loads issued before the first add): the
     // partials were written by other XCDs' workgroups, every load comes from the fabric side of this XCD's L2 at ~1-2 k
     // cycles, so the phase costs (number of dependent load rounds) x (that latency) -- 6 rounds at B = 1 (10 tiles,
     // 5 chunks) instead of the 14 of a 2-item x 4-partial scheme.  Sums in partial order (fixed), whatever the grouping.
-    auto reduce_partials = [&](auto vals_c, const float *src, float *dst, int n_items_pairs, int parts) {
+    auto reduce_partials = [&](auto vals_c, auto items_c, const float *src, float *dst, int n_items_pairs, int parts) {
         constexpr int vals = decltype(vals_c)::value;
-        constexpr int kItems = 4;
+        constexpr int kItems = decltype(items_c)::value;
         const int total = n_items_pairs * vals;
         for (int e0 = tid; e0 < total; e0 += kItems * nthr) {
             const float *q[kItems];
@@ -882,9 +890,23 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             for (int i = 0; i < kItems; i++) { const int e = e0 + i * nthr; if (e < total) dst[e] = sum[i]; }
         }
     };
-    if (D.use_sparse) reduce_partials(std::integral_constant<int, kSparseVals>{}, sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals, ps, D.n_pairs, D.sparse_chunks);
+    // items per lane per trip: one trip covers the c3 window (105 pairs: 4 620 sparse / 2 940 dense sums over 1 024 lanes)
+    if (D.use_sparse) reduce_partials(std::integral_constant<int, kSparseVals>{}, std::integral_constant<int, 5>{}, sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals, ps, D.n_pairs, D.sparse_chunks);
     else for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) ps[e] = 0.0f;
-    if (D.use_dense) reduce_partials(std::integral_constant<int, kDenseVals>{}, dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals, pdr, D.n_dense_pairs, D.dense_tiles);
+    if (D.use_dense) reduce_partials(std::integral_constant<int, kDenseVals>{}, std::integral_constant<int, 3>{}, dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals, pdr, D.n_dense_pairs, D.dense_tiles);
+    BTBA_STAMP(7);
+    // the staged values: first trip from the registers loaded above, the rest (windows beyond 64 frames / 1 024 pairs) by loops
+    if (tid < 16 * N) vT[tid] = st_T;
+    if (tid < 6 * N) x_l[tid] = st_x;                    // 6 N <= 510 < 1 024: one trip
+    if (tid < D.n_pairs) pair_ij_l[tid] = st_pij;
+    if (tid < 288) entry_lut[tid] = st_lut;
+    for (int e = tid + nthr; e < D.n_pairs; e += nthr) pair_ij_l[e] = solve_tab[e];
+    if (tid < n_dp) { dense_pairs_lds[2 * tid] = st_dp.x; dense_pairs_lds[2 * tid + 1] = st_dp.y; }
+    if (tid < n_ao) adj_off_l[tid] = st_ao;
+    if (tid < n_adj) adj_l[tid] = st_adj;
+    for (int e = tid + nthr; e < 16 * N; e += nthr) vT[e] = T[16 * (size_t)b * N + e];
+    for (int e = tid + nthr; e < n_dp; e += nthr) { const int2 ij = dense_pairs[e]; dense_pairs_lds[2 * e] = ij.x; dense_pairs_lds[2 * e + 1] = ij.y; }
+    for (int e = tid + nthr; e < n_adj; e += nthr) adj_l[e] = adj[e];
     for (int e = tid; e < n * ld; e += nthr) A[e] = 0.0f;
     __syncthreads();
     BTBA_STAMP(0);
@@ -1177,7 +1199,8 @@ _Pragma("unroll 4")
     // Phase D: x_k <- Log(Exp(delta_k) Exp(x_k)); next iterate's T, T^-1  (SolverBundling.cu:805-815, 890-897)
     for (int k = tid; k < N; k += nthr) {
         float *xk = x + 6 * ((size_t)b * N + k);
-        float rot[3] = { xk[0], xk[1], xk[2] }, trans[3] = { xk[3], xk[4], xk[5] };
+        const float *xl = x_l + 6 * k;
+        float rot[3] = { xl[0], xl[1], xl[2] }, trans[3] = { xl[3], xl[4], xl[5] };
         if (k > 0) {
             const float dW[3] = { vd[6 * k + 3], vd[6 * k + 4], vd[6 * k + 5] }, dT[3] = { vd[6 * k], vd[6 * k + 1], vd[6 * k + 2] };
             const Mat4 U = pose_to_matrix(dW, dT);

@@ -22,7 +22,7 @@ def main():
         tv = bs.trace_view(bs.solve(cam_d, nrm_d, pick[0]["intr"], corr_d, offs_d, mx, poses_d, trace=True))
         clk = tv.clk[0]          # [n_gn, 8]
         c = clk.mean(0)
-        print(f"B={B}: k_system_solve phase shader-clock cycles (mean over GN iterations): reduce {c[0]:.0f}  congruence {c[1]-c[0]:.0f}  assemble {c[2]-c[1]:.0f}  [trace dump {c[5]-c[2]:.0f}]  PCG {c[3]-c[5]:.0f}  update {c[4]-c[3]:.0f}  total w/o dump {c[4]-(c[5]-c[2]):.0f}")
+        print(f"B={B}: k_system_solve phase shader-clock cycles (mean over GN iterations): [wave 0: staging {c[6]:.0f}, partial sums {c[7]-c[6]:.0f}, zero-fill + barrier {c[0]-c[7]:.0f}] reduce {c[0]:.0f}  congruence {c[1]-c[0]:.0f}  assemble {c[2]-c[1]:.0f}  [trace dump {c[5]-c[2]:.0f}]  PCG {c[3]-c[5]:.0f}  update {c[4]-c[3]:.0f}  total w/o dump {c[4]-(c[5]-c[2]):.0f}")
 
 
 if __name__ == "__main__":
