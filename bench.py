@@ -246,6 +246,12 @@ def main():
                                        "boundary (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"}
             if traffic:
                 res["roofline"]["hbm_traffic_GBps"] = round(traffic / (avg_ms * 1e-3) / 1e9, 1)
+            # what actually limits the kernel (VALU issue, 66 % busy): the same launch against the fp32 vector
+            # peak, from SURVEY.md 8(d)'s algorithmic flops (200 per pixel pair, 120 per correspondence) -- context, not `frac`
+            flops_alg = 200.0 * P * npix * B + (120.0 * n_corr if fused else 0.0)
+            res["roofline"]["valu_context"] = {"algorithmic_flops_per_launch": flops_alg, "achieved_TFLOPs": round(flops_alg / (avg_ms * 1e-3) / 1e12, 2),
+                                               "peak_TFLOPs_f32_vector": 157.3, "peak_TFLOPs_f32_vector_unpacked": 78.6,
+                                               "note": "157.3 TF is the packed (v_pk_fma_f32) figure of MI355X_MICROARCH.md; the sweep's scalar fp32 code can reach half of it"}
             if world == 1:
                 copy_bw = measured_copy_bandwidth(torch, dev)
                 res["roofline"]["peak_measured_copy"] = round(copy_bw, 1)
