@@ -19,7 +19,7 @@ HEADER = os.path.join(_ROOT, "include", "btba.h")
 
 BTBA_OK, BTBA_EINVAL, BTBA_EHIP, BTBA_ENUMERIC, BTBA_ENOMEM = 0, 1, 2, 3, 4
 PAIRS_TARGET_LOWER, PAIRS_TARGET_MORE_VALID, PAIRS_EXPLICIT = 0, 1, 2
-FLAG_TRACE, FLAG_TIME_KERNELS = 1, 2
+FLAG_TRACE, FLAG_TIME_KERNELS, FLAG_PAIR_MAJOR = 1, 2, 4
 FLAG_DENSE_2PIX, FLAG_DENSE_4WAVE, FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_FUSE, FLAG_FLOAT4_CACHE, FLAG_NO_COMPACTION, FLAG_COMPACTION = 8, 16, 32, 64, 128, 256, 512, 1024
 
 ENTRYJ_DTYPE = np.dtype(

@@ -301,10 +301,13 @@ static int pick_tiles(const btba_params *prm, int B, int Pd, int npix)
 {
     if (prm->dense_tiles > 0) return prm->dense_tiles;
     if (Pd == 0) return 1;
-    // measured with the fused sweep launch at c3 (scripts/ab_dense.py): B=32 2.27 / 2.40 / 2.39 ms per step for 4 / 5 / 6
-    // tiles, B=8 0.871 / 0.886 / 0.874 / 0.900 for 4 / 5 / 6 / 8; a single instance wants 10-15 (0.486 ms) to fill the chip
+    // measured with the fused sweep launch (bench.py, BTBA_BENCH_TILES; fused-sweep time per launch):
+    //   c3 x 32 (3 360 pair-instances): 437 / 279 / 320 / 287 / 304 / 325 us for 1 / 2 / 3 / 4 / 6 / 8 tiles; c4 x 32: 1.66 / 1.12 / 1.23 / 1.17 ms
+    //   for 1 / 2 / 3 / 4; c3 x 32 on masked frames 0.78 vs 0.93 ms per step for 2 vs 4 -- every workgroup pays its set-up (LUT,
+    //   relative pose, block reduction), so a big batch wants few, large tiles; B=8 0.871 / 0.886 / 0.874 / 0.900 ms per step for
+    //   4 / 5 / 6 / 8; a single instance wants 10-15 (0.486 ms) to fill the chip
     const long blocks = (long)B * Pd;
-    int want = blocks >= 512 ? 4 : (int)((2048 + blocks - 1) / blocks);
+    int want = blocks >= 2048 ? 2 : blocks >= 512 ? 4 : (int)((2048 + blocks - 1) / blocks);
     const int cap = (npix + kBlock - 1) / kBlock;
     if (want > cap) want = cap;
     if (want < 2) want = 2;
@@ -398,6 +401,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;
     D.order_flag = order_flag;
+    D.tile_major = (prm->flags & BTBA_FLAG_PAIR_MAJOR) ? 0 : 1;
     D.n_gn = prm->n_gn_iters;
     int zn_layout = 0;
     if (use_zn) {

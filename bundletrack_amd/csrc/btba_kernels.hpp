@@ -61,6 +61,7 @@ struct SolveDims {
     int64_t tr_x, tr_T, tr_rhs, tr_prec, tr_pcg, tr_delta, tr_dpair, tr_A, tr_clk;
     int n_gn;
     int pairsum_in_lds;  // 1: stage reduced pair sums in LDS, 0: in global scratch
+    int tile_major;      // dense work order inside an instance: 1 = (tile, pair) -- all pairs' band t of the images together -- 0 = (pair, tile)
     int *order_flag;     // non-null: the sparse sweep ORs 1 into it when an entry does not belong to the pair of its segment
     // compact (z, nx, ny, nz) frame cache: how a cached pixel maps back to camera space -- the arithmetic of k_build_cache
     float zn_ki[16];     // full-resolution intrinsicsInv (4x4 embedding, generic cofactor inverse)
@@ -693,9 +694,10 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused_sweeps(SolveDims D, unsigne
         const unsigned before = nsx ? min(nsx, (slot + Rx - 1u) / Rx) : 0u;     // sparse slots of this XCD before `slot`
         const unsigned dl = slot - before;                                      // dense item local to the XCD
         const unsigned L = (xcd < rd ? xcd * (qd + 1u) : rd * (qd + 1u) + (xcd - rd) * qd) + dl;
-        const int tile = (int)(L % (unsigned)D.dense_tiles);
-        const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
         const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
+        const unsigned Lb = L - (unsigned)b * (unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs;
+        const int tile = D.tile_major ? (int)(Lb / (unsigned)D.n_dense_pairs) : (int)(Lb % (unsigned)D.dense_tiles);
+        const int p = D.tile_major ? (int)(Lb % (unsigned)D.n_dense_pairs) : (int)(Lb / (unsigned)D.dense_tiles);
         if (LAYOUT == 0) dense_block<1>(D, campos, normals, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
         else if (LAYOUT == 1) dense_block_zn<true, false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);     // `campos` carries the compact cache
         else if (LAYOUT == 2) dense_block_zn<false, false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);

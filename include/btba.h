@@ -62,7 +62,7 @@ enum {
 enum {
     BTBA_FLAG_TRACE         = 1,    /* record per-GN-iterate trace (btba_trace_layout)                            */
     BTBA_FLAG_TIME_KERNELS  = 2,    /* bracket every sweep / solve launch with hipEvents (btba_stats)             */
-    BTBA_FLAG_RESERVED_4    = 4,    /* unused                                                                     */
+    BTBA_FLAG_PAIR_MAJOR    = 4,    /* tuning / A-B: fused dense work ordered (pair, tile) inside an instance; default (tile, pair) */
     BTBA_FLAG_DENSE_2PIX    = 8,    /* tuning, reference-layout cache only: dense sweep with two pixels per lane per trip */
     BTBA_FLAG_DENSE_4WAVE   = 16,   /* tuning, reference-layout cache only: registers capped for 4 waves per SIMD */
     BTBA_FLAG_OVERLAP       = 32,   /* split a batch over two streams (main + low-priority) so one half's k_system_solve
