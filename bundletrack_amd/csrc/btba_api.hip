@@ -796,8 +796,6 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
         return finish(BTBA_EINVAL);
     }
 
-    // keep cache-build timing event, then enqueue the solve
-    ws->always_time_region = true;
     ZnSpec Z;
     if (compact) {
         Z.zn = keyed ? ws->pool_zn.as<float>() : ws->campos.as<float>(); Z.H = H; Z.W = W; Z.K = K;
@@ -827,6 +825,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
         if ((he = hipMemcpyAsync(out.data(), ws->poses.p, sizeof(float) * out.size(), hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) { g_last_hip_error = (int)he; return BTBA_EHIP; }
         return btba_collect_stats(ws, &S);       // synchronises
     };
+    ws->always_time_region = true;               // ms_solve is reported by this entry point whatever the flags
     rc = solve_and_read();
     if (!rc && trust) {
         uint32_t flag;
