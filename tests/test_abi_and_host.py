@@ -140,3 +140,22 @@ def test_tensor_handover_is_validated():
     assert _dev_ptr(None) is None
     with pytest.raises(ValueError, match="CUDA"):
         _dev_ptr(torch.zeros(4), "zn")
+
+
+def test_python_constants_match_the_header():
+    """Status codes, pair policies, tuning flags and the window limits of include/btba.h against the Python mirror
+    (bundletrack_amd/_lib.py): the two are maintained by hand, so a drift must fail here."""
+    import os, re
+    from bundletrack_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "btba.h")).read()
+    enums = {k: int(v) for k, v in re.findall(r"\b(BTBA_[A-Z0-9_]+)\s*=\s*(\d+)", hdr)}
+    defines = {k: int(v) for k, v in re.findall(r"#define\s+(BTBA_[A-Z0-9_]+)\s+(\d+)\b", hdr)}
+    for name in ("BTBA_OK", "BTBA_EINVAL", "BTBA_EHIP", "BTBA_ENUMERIC", "BTBA_ENOMEM"):
+        assert enums[name] == getattr(_lib, name), name
+    for name in ("TARGET_LOWER", "TARGET_MORE_VALID", "EXPLICIT"):
+        assert enums["BTBA_PAIRS_" + name] == getattr(_lib, "PAIRS_" + name), name
+    flags = {k[len("BTBA_FLAG_"):]: v for k, v in enums.items() if k.startswith("BTBA_FLAG_")}
+    assert len(set(flags.values())) == len(flags) and all(v & (v - 1) == 0 for v in flags.values())     # distinct single bits
+    for name, v in flags.items():
+        assert getattr(_lib, "FLAG_" + name) == v, name
+    assert defines["BTBA_MAX_FRAMES"] == 85 and defines["BTBA_MAX_FRAMES_LDS"] == 31     # the reference's MAX_NUM_IMAGES; the LDS-resident limit
