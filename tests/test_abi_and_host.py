@@ -159,3 +159,17 @@ def test_python_constants_match_the_header():
     for name, v in flags.items():
         assert getattr(_lib, "FLAG_" + name) == v, name
     assert defines["BTBA_MAX_FRAMES"] == 85 and defines["BTBA_MAX_FRAMES_LDS"] == 31     # the reference's MAX_NUM_IMAGES; the LDS-resident limit
+
+
+def test_traffic_file_matches_the_committed_pmc_summary():
+    """profiles/dense_sweep_traffic.json (what bench.py reports as roofline.traffic) must be the number in the PMC summary
+    it names -- both are written by scripts/summarize_profiles.py, and a hand edit of one would leave the bench line with a
+    byte count no committed profile backs."""
+    import csv, json, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tj = json.load(open(os.path.join(root, "profiles", "dense_sweep_traffic.json")))
+    src = re.match(r"(profiles/r01/\S+\.csv)", tj["source"]).group(1)
+    rows = [r for r in csv.DictReader(open(os.path.join(root, src))) if r["kernel"] == tj["kernel"]]
+    assert len(rows) == 1 and int(rows[0]["hbm_bytes_per_launch_corrected"]) == tj["hbm_bytes_per_launch"]
+    fetch_kib, write_kib = float(rows[0]["FETCH_SIZE_KiB_mean"]), float(rows[0]["WRITE_SIZE_KiB_mean"])
+    assert abs(int(fetch_kib * 1024 * 2 + write_kib * 1024) - tj["hbm_bytes_per_launch"]) <= 2048      # the guide's gfx950 correction
