@@ -2,6 +2,8 @@
 #include "btba_host.hpp"
 
 #include <algorithm>
+#include <cstring>
+#include <fstream>
 #include <cmath>
 #include <limits>
 
@@ -124,6 +126,65 @@ std::vector<std::shared_ptr<Frame>> KeyframeMemory::selectKeyFramesForBA(const s
     }
     std::sort(frames.begin(), frames.end(), by_id);
     return frames;
+}
+
+// ---- problem dumps (bundletrack_amd/problem_io.py documents the layout) ---------------------------------------
+namespace {
+const char kProblemMagic[8] = { 'B', 'T', 'B', 'A', 'P', 'R', 'B', '1' };
+struct ProblemHeader { char magic[8]; int32_t n_frames, H, W; uint32_t n_corr; int32_t flags; float image_downscale; };
+static_assert(sizeof(ProblemHeader) == 32, "problem dump header");
+template <class T> void read_array(std::ifstream &f, std::vector<T> &v, size_t n, const std::string &path)
+{
+    v.resize(n);
+    f.read(reinterpret_cast<char *>(v.data()), (std::streamsize)(sizeof(T) * n));
+    if (!f) throw Error(BTBA_EINVAL, path + ": truncated problem dump");
+}
+template <class T> void write_array(std::ofstream &f, const std::vector<T> &v) { f.write(reinterpret_cast<const char *>(v.data()), (std::streamsize)(sizeof(T) * v.size())); }
+}  // namespace
+
+ProblemDump loadProblem(const std::string &path)
+{
+    std::ifstream f(path, std::ios::binary);
+    ProblemHeader h{};
+    f.read(reinterpret_cast<char *>(&h), sizeof h);
+    if (!f || std::memcmp(h.magic, kProblemMagic, 8) != 0) throw Error(BTBA_EINVAL, path + ": not a BTBAPRB1 problem dump");
+    if (h.n_frames < 1 || h.H < 1 || h.W < 1) throw Error(BTBA_EINVAL, path + ": corrupt problem dump header");
+    ProblemDump pb;
+    pb.n_frames = h.n_frames; pb.H = h.H; pb.W = h.W; pb.image_downscale = h.image_downscale;
+    f.read(reinterpret_cast<char *>(pb.K), sizeof pb.K);
+    const size_t N = (size_t)h.n_frames, P = N * (N - 1) / 2, npix = (size_t)h.H * h.W;
+    read_array(f, pb.corr, h.n_corr, path);
+    std::vector<int32_t> nm;
+    read_array(f, nm, P, path);
+    pb.n_match_per_pair.assign(nm.begin(), nm.end());
+    read_array(f, pb.poses_init, 16 * N, path);
+    if (h.flags & 1) read_array(f, pb.poses_gt, 16 * N, path);
+    read_array(f, pb.depth, N * npix, path);
+    read_array(f, pb.normals, 4 * N * npix, path);
+    if (f.peek() != std::ifstream::traits_type::eof()) throw Error(BTBA_EINVAL, path + ": trailing bytes after the problem dump");
+    return pb;
+}
+
+void saveProblem(const std::string &path, const ProblemDump &pb)
+{
+    const size_t N = (size_t)pb.n_frames, P = N * (N - 1) / 2, npix = (size_t)pb.H * pb.W;
+    if (pb.n_frames < 1 || pb.n_match_per_pair.size() != P || pb.poses_init.size() != 16 * N || (!pb.poses_gt.empty() && pb.poses_gt.size() != 16 * N) ||
+        pb.depth.size() != N * npix || pb.normals.size() != 4 * N * npix)
+        throw Error(BTBA_EINVAL, "saveProblem: array sizes do not match n_frames / H / W");
+    ProblemHeader h{};
+    std::memcpy(h.magic, kProblemMagic, 8);
+    h.n_frames = pb.n_frames; h.H = pb.H; h.W = pb.W; h.n_corr = (uint32_t)pb.corr.size(); h.flags = pb.poses_gt.empty() ? 0 : 1;
+    h.image_downscale = pb.image_downscale;
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char *>(&h), sizeof h);
+    f.write(reinterpret_cast<const char *>(pb.K), sizeof pb.K);
+    write_array(f, pb.corr);
+    write_array(f, std::vector<int32_t>(pb.n_match_per_pair.begin(), pb.n_match_per_pair.end()));
+    write_array(f, pb.poses_init);
+    write_array(f, pb.poses_gt);
+    write_array(f, pb.depth);
+    write_array(f, pb.normals);
+    if (!f) throw Error(BTBA_EINVAL, path + ": write failed");
 }
 
 }  // namespace btba

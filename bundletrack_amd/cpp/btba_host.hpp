@@ -116,4 +116,21 @@ private:
     std::shared_ptr<Config> yml;
 };
 
+// One bundle-adjustment call as a file (the layout is documented in bundletrack_amd/problem_io.py, which writes and reads
+// the same bytes): what Bundler::optimizeGPU hands to OptimizerGpu::optimizeFrames, with the frames on the HOST -- the
+// caller uploads them (hipMalloc + hipMemcpy, as Frame's constructor does, src/Frame.cpp:68-70,107-149).
+struct ProblemDump {
+    int n_frames = 0, H = 0, W = 0;
+    float image_downscale = 4.0f;
+    float K[9] = {};                                  // row-major
+    std::vector<EntryJ> corr;                         // pair-major
+    std::vector<int> n_match_per_pair;                // P = n (n - 1) / 2 segment lengths
+    std::vector<float> poses_init;                    // n x 16, row-major, camera -> model
+    std::vector<double> poses_gt;                     // n x 16 or empty
+    std::vector<float> depth;                         // n x H x W
+    std::vector<float> normals;                       // n x H x W x 4
+};
+ProblemDump loadProblem(const std::string &path);                    // throws btba::Error(BTBA_EINVAL) on a malformed file
+void saveProblem(const std::string &path, const ProblemDump &pb);
+
 }  // namespace btba

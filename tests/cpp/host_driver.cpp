@@ -2,6 +2,7 @@
 // OptimizerGpu, on a problem dumped by the Python tests.  Built by __graft_entry__.build().
 //   host_driver ba <problem.bin> <poses_out.bin>        window -> marshalWindow -> OptimizerGpu::optimizeFrames (GPU)
 //   host_driver keyframes <poses.bin> <ids_out.bin>     checkAndAddKeyframe over a pose sequence + selectKeyFramesForBA (CPU)
+//   host_driver problem <dump.btba> <copy_out.btba>     loadProblem -> saveProblem round trip + a one-line summary (CPU)
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -118,12 +119,26 @@ static int run_keyframes(const char *in, const char *out)
     return 0;
 }
 
+static int run_problem(const char *in, const char *out)
+{
+    const ProblemDump pb = loadProblem(in);
+    long valid = 0;
+    for (float d : pb.depth) valid += d >= 0.1f;
+    int longest = 0;
+    for (int m : pb.n_match_per_pair) longest = std::max(longest, m);
+    std::printf("problem: %d frames %dx%d, %zu correspondences (longest pair segment %d), %ld valid depth pixels, ground truth %s\n",
+                pb.n_frames, pb.W, pb.H, pb.corr.size(), longest, valid, pb.poses_gt.empty() ? "no" : "yes");
+    saveProblem(out, pb);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
         if (argc == 4 && !std::strcmp(argv[1], "ba")) return run_ba(argv[2], argv[3]);
         if (argc == 4 && !std::strcmp(argv[1], "keyframes")) return run_keyframes(argv[2], argv[3]);
+        if (argc == 4 && !std::strcmp(argv[1], "problem")) return run_problem(argv[2], argv[3]);
     } catch (const std::exception &e) { std::fprintf(stderr, "host_driver: %s\n", e.what()); return 2; }
-    std::fprintf(stderr, "usage: host_driver ba|keyframes <in> <out>\n");
+    std::fprintf(stderr, "usage: host_driver ba|keyframes|problem <in> <out>\n");
     return 1;
 }
