@@ -50,6 +50,84 @@ void OptimizerGpu::optimizeFrames(const std::vector<EntryJ> &global_corres, cons
     for (int i = 0; i < n_frames; i++) for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) poses[i](r, c) = P[16 * (size_t)i + 4 * r + c];      // :121-130
 }
 
+// Thin SVD of a 3x3 matrix S = U diag(sig) V^T by one-sided (Hestenes) Jacobi rotations on the columns, singular values
+// sorted descending like Eigen::JacobiSVD; a vanishing third singular value (coplanar points) gets the cross product of
+// the first two left vectors, so U stays orthonormal.
+static void svd3(const float S[9], float U[9], float sig[3], float V[9])
+{
+    double A[9], W[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    for (int k = 0; k < 9; k++) A[k] = S[k];
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                double al = 0, be = 0, ga = 0;
+                for (int k = 0; k < 3; k++) { al += A[3 * k + p] * A[3 * k + p]; be += A[3 * k + q] * A[3 * k + q]; ga += A[3 * k + p] * A[3 * k + q]; }
+                if (ga == 0.0 || std::fabs(ga) <= 1e-15 * std::sqrt(al * be)) continue;
+                off = std::max(off, std::fabs(ga) / std::sqrt(al * be));
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+                for (int k = 0; k < 3; k++) {
+                    const double ap = A[3 * k + p], aq = A[3 * k + q];
+                    A[3 * k + p] = c * ap - sn * aq; A[3 * k + q] = sn * ap + c * aq;
+                    const double wp = W[3 * k + p], wq = W[3 * k + q];
+                    W[3 * k + p] = c * wp - sn * wq; W[3 * k + q] = sn * wp + c * wq;
+                }
+            }
+        if (off < 1e-14) break;
+    }
+    double norm[3];
+    int order[3] = { 0, 1, 2 };
+    for (int j = 0; j < 3; j++) norm[j] = std::sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+    std::sort(order, order + 3, [&](int a, int b) { return norm[a] > norm[b]; });
+    double Ud[9];
+    for (int j = 0; j < 3; j++) {
+        const int o = order[j];
+        sig[j] = (float)norm[o];
+        for (int k = 0; k < 3; k++) { V[3 * k + j] = (float)W[3 * k + o]; Ud[3 * k + j] = norm[o] > 0 ? A[3 * k + o] / norm[o] : 0.0; }
+    }
+    if (norm[order[2]] <= 1e-12 * norm[order[0]]) {                   // rank 2: complete U with u0 x u1
+        Ud[2] = Ud[3] * Ud[7] - Ud[6] * Ud[4]; Ud[5] = Ud[6] * Ud[1] - Ud[0] * Ud[7]; Ud[8] = Ud[0] * Ud[4] - Ud[3] * Ud[1];
+    }
+    for (int k = 0; k < 9; k++) U[k] = (float)Ud[k];
+}
+
+void solveRigidTransformBetweenPoints(const std::vector<float> &points1, const std::vector<float> &points2, Matrix4f &pose)
+{
+    pose = Matrix4f::Identity();
+    const size_t n = points1.size() / 3;
+    if (n < 3 || points1.size() != points2.size() || points1.size() % 3) return;      // the reference asserts
+    float m1[3] = { 0, 0, 0 }, m2[3] = { 0, 0, 0 };
+    for (size_t i = 0; i < n; i++) for (int c = 0; c < 3; c++) { m1[c] += points1[3 * i + c]; m2[c] += points2[3 * i + c]; }
+    for (int c = 0; c < 3; c++) { m1[c] /= (float)n; m2[c] /= (float)n; }
+    float S[9] = {};                                                  // P^T Q, row-major
+    for (size_t i = 0; i < n; i++)
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) S[3 * r + c] += (points1[3 * i + r] - m1[r]) * (points2[3 * i + c] - m2[c]);
+    for (float v : S) if (!std::isfinite(v)) return;
+    float U[9], sig[3], V[9];
+    svd3(S, U, sig, V);
+    auto vut = [&](float R[9]) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { R[3 * r + c] = 0; for (int k = 0; k < 3; k++) R[3 * r + c] += V[3 * r + k] * U[3 * c + k]; } };
+    float R[9];
+    vut(R);
+    for (int r = 0; r < 3; r++)                                        // (R^T R).isApprox(I), float precision
+        for (int c = 0; c < 3; c++) {
+            float d = 0;
+            for (int k = 0; k < 3; k++) d += R[3 * k + r] * R[3 * k + c];
+            if (std::fabs(d - (r == c ? 1.0f : 0.0f)) > 1e-5f) return;
+        }
+    const float det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+    if (det < 0) { for (int k = 0; k < 3; k++) V[3 * k + 2] = -V[3 * k + 2]; vut(R); }
+    Matrix4f out = Matrix4f::Identity();
+    for (int r = 0; r < 3; r++) {
+        float t = m2[r];
+        for (int c = 0; c < 3; c++) { out(r, c) = R[3 * r + c]; t -= R[3 * r + c] * m1[c]; }
+        out(r, 3) = t;
+    }
+    for (float v : out.d) if (!std::isfinite(v)) return;
+    pose = out;
+}
+
 float rotationGeodesicDistance(const Matrix4f &A, const Matrix4f &B)
 {
     float tr = 0.0f;                                            // trace(R1 R2^T) = sum_ij R1_ij R2_ij

@@ -6,8 +6,8 @@
 //   Bundler::optimizeGPU's marshalling                  src/Bundler.cpp:286-347   (marshalWindow)
 //   Bundler::checkAndAddKeyframe / selectKeyFramesForBA src/Bundler.cpp:185-274   (KeyframeMemory)
 //   Utils::rotationGeodesicDistance                     src/Utils.cpp:42-47
-//   Utils::solveRigidTransformBetweenPoints             src/Utils.cpp:180-214     (only declared here: needs an SVD; the
-//                                                        Python mirror in bundletrack_amd/bundler.py carries it)
+//   Utils::solveRigidTransformBetweenPoints             src/Utils.cpp:180-214     (Kabsch; a 3x3 one-sided Jacobi SVD stands in
+//                                                        for Eigen::JacobiSVD)
 // The reference builds these on Eigen, yaml-cpp and PCL, none of which exist in this image, so the two value types
 // the interface needs are defined here with Eigen's conventions (column-major storage, (row, col) access): a
 // maintainer swaps `btba::Matrix4f` for `Eigen::Matrix4f` and `btba::Config` for the YAML node and nothing else
@@ -90,6 +90,10 @@ struct Frame {                                   // the fields of Frame (src/Fra
     float4 *_normal_gpu = nullptr;
     uchar4 *_color_gpu = nullptr;
 };
+
+// Utils::solveRigidTransformBetweenPoints (Utils.cpp:180-214): the rigid transform points1 -> points2 (n x 3 each, xyz
+// triples), identity when fewer than 3 points, a non-orthonormal V U^T or a non-finite result.
+void solveRigidTransformBetweenPoints(const std::vector<float> &points1, const std::vector<float> &points2, Matrix4f &pose);
 
 float rotationGeodesicDistance(const Matrix4f &A, const Matrix4f &B);           // rotation blocks only, radians (Utils.cpp:42-47)
 

@@ -3,6 +3,7 @@
 //   host_driver ba <problem.bin> <poses_out.bin>        window -> marshalWindow -> OptimizerGpu::optimizeFrames (GPU)
 //   host_driver keyframes <poses.bin> <ids_out.bin>     checkAndAddKeyframe over a pose sequence + selectKeyFramesForBA (CPU)
 //   host_driver problem <dump.btba> <copy_out.btba>     loadProblem -> saveProblem round trip + a one-line summary (CPU)
+//   host_driver kabsch <pairs.bin> <poses_out.bin>      solveRigidTransformBetweenPoints over a list of point-set pairs (CPU)
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -119,6 +120,26 @@ static int run_keyframes(const char *in, const char *out)
     return 0;
 }
 
+static int run_kabsch(const char *in, const char *out)
+{
+    std::ifstream f(in, std::ios::binary);
+    int32_t n_sets;
+    rd(f, &n_sets, 1);
+    std::vector<float> res;
+    for (int s = 0; s < n_sets; s++) {
+        int32_t n;
+        rd(f, &n, 1);
+        std::vector<float> a(3 * (size_t)n), b(3 * (size_t)n);
+        rd(f, a.data(), a.size()); rd(f, b.data(), b.size());
+        Matrix4f pose;
+        solveRigidTransformBetweenPoints(a, b, pose);
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) res.push_back(pose(r, c));
+    }
+    std::ofstream o(out, std::ios::binary);
+    o.write(reinterpret_cast<const char *>(res.data()), sizeof(float) * res.size());
+    return 0;
+}
+
 static int run_problem(const char *in, const char *out)
 {
     const ProblemDump pb = loadProblem(in);
@@ -138,7 +159,8 @@ int main(int argc, char **argv)
         if (argc == 4 && !std::strcmp(argv[1], "ba")) return run_ba(argv[2], argv[3]);
         if (argc == 4 && !std::strcmp(argv[1], "keyframes")) return run_keyframes(argv[2], argv[3]);
         if (argc == 4 && !std::strcmp(argv[1], "problem")) return run_problem(argv[2], argv[3]);
+        if (argc == 4 && !std::strcmp(argv[1], "kabsch")) return run_kabsch(argv[2], argv[3]);
     } catch (const std::exception &e) { std::fprintf(stderr, "host_driver: %s\n", e.what()); return 2; }
-    std::fprintf(stderr, "usage: host_driver ba|keyframes|problem <in> <out>\n");
+    std::fprintf(stderr, "usage: host_driver ba|keyframes|problem|kabsch <in> <out>\n");
     return 1;
 }

@@ -67,3 +67,52 @@ def test_cpp_optimizer_gpu_matches_python_and_oracle(oracle, tmp_path):
     caches = [oracle.build_cache(pb.depth[k], pb.normals[k], pb.K) for k in range(pb.n_frames)]
     ref = oracle.solve(np.stack([c["campos"] for c in caches]), np.stack([c["normals"] for c in caches]), caches[0]["intr"], pb.corr, pb.poses_init)
     assert max(max(S.pose_error(res[0][k], ref.poses[k])) for k in range(pb.n_frames)) < 1e-4
+
+
+def test_cpp_kabsch_matches_python(tmp_path):
+    """Utils::solveRigidTransformBetweenPoints (Utils.cpp:180-214) in the C++ host layer against the Python restatement:
+    noisy rigid motions, coplanar and minimal (3-point) sets, a mirrored set (the det < 0 branch), and the identity
+    fall-backs (fewer than 3 points, non-finite input)."""
+    from bundletrack_amd.bundler import solve_rigid_transform_between_points as kabsch_py
+    rng = np.random.default_rng(11)
+    sets = []
+    for trial in range(40):
+        n = int(rng.choice([3, 4, 10, 200]))
+        a = rng.normal(scale=0.1, size=(n, 3)).astype(np.float32) + np.float32([0.0, 0.0, 0.7])
+        if trial % 5 == 1:
+            a[:, 2] = 0.7 + 0.3 * a[:, 0]                       # coplanar: rank-2 covariance
+        T = S.se3_exp(rng.normal(scale=0.5, size=3), rng.normal(scale=0.1, size=3)) if hasattr(S, "se3_exp") else None
+        if T is None:
+            w = rng.normal(scale=0.5, size=3); th = np.linalg.norm(w); k = w / th
+            Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+            R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+            t = rng.normal(scale=0.1, size=3)
+        else:
+            R, t = T[:3, :3], T[:3, 3]
+        b = (a @ R.T + t + rng.normal(scale=0.0005, size=a.shape)).astype(np.float32)
+        if trial % 7 == 3:
+            b[:, 0] = -b[:, 0]                                  # mirrored target: V's last column is flipped
+        sets.append((a, b))
+    sets.append((sets[0][0][:2], sets[0][1][:2]))               # two points: identity
+    bad = sets[1][0].copy(); bad[0, 0] = np.nan
+    sets.append((bad, sets[1][1]))                              # non-finite: identity
+    inp, out = str(tmp_path / "kabsch_in.bin"), str(tmp_path / "kabsch_out.bin")
+    with open(inp, "wb") as f:
+        f.write(np.array([len(sets)], np.int32).tobytes())
+        for a, b in sets:
+            f.write(np.array([len(a)], np.int32).tobytes()); f.write(np.ascontiguousarray(a, np.float32).tobytes()); f.write(np.ascontiguousarray(b, np.float32).tobytes())
+    subprocess.run([driver(), "kabsch", inp, out], check=True, timeout=60)
+    got = np.fromfile(out, np.float32).reshape(len(sets), 4, 4)
+    worst = 0.0
+    for k, (a, b) in enumerate(sets):
+        ref = kabsch_py(a, b)
+        assert np.isfinite(got[k]).all() and abs(np.linalg.det(got[k][:3, :3].astype(np.float64)) - 1.0) < 1e-4
+        if len(a) > 3 or k >= len(sets) - 2:                    # 3 points are coplanar AND the fit is exact either way; compare the fit below
+            worst = max(worst, float(np.abs(got[k] - ref).max()))
+        if k >= len(sets) - 2:
+            continue                                            # the identity fall-backs: nothing was fitted
+        res_cpp = np.linalg.norm(a @ got[k][:3, :3].T + got[k][:3, 3] - b, axis=1).mean()
+        res_py = np.linalg.norm(a @ ref[:3, :3].T + ref[:3, 3] - b, axis=1).mean()
+        assert res_cpp <= res_py + 2e-6, (k, res_cpp, res_py)
+    assert np.array_equal(got[-1], np.eye(4, dtype=np.float32)) and np.array_equal(got[-2], np.eye(4, dtype=np.float32))
+    assert worst < 2e-5, worst
