@@ -2,6 +2,7 @@
 #include "btba_host.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <cmath>
@@ -126,6 +127,27 @@ void solveRigidTransformBetweenPoints(const std::vector<float> &points1, const s
     }
     for (float v : out.d) if (!std::isfinite(v)) return;
     pose = out;
+}
+
+std::string formatPoseTxt(const Matrix4f &M)
+{
+    char cell[16][32];
+    size_t width = 0;
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            std::snprintf(cell[4 * r + c], sizeof cell[0], "%.10g", (double)M(r, c));
+            width = std::max(width, std::strlen(cell[4 * r + c]));
+        }
+    std::string out;
+    for (int r = 0; r < 4; r++) {
+        for (int c = 0; c < 4; c++) {
+            if (c) out += ' ';
+            out.append(width - std::strlen(cell[4 * r + c]), ' ');
+            out += cell[4 * r + c];
+        }
+        out += '\n';
+    }
+    return out;
 }
 
 float rotationGeodesicDistance(const Matrix4f &A, const Matrix4f &B)

@@ -95,6 +95,10 @@ struct Frame {                                   // the fields of Frame (src/Fra
 // triples), identity when fewer than 3 points, a non-orthonormal V U^T or a non-finite result.
 void solveRigidTransformBetweenPoints(const std::vector<float> &points1, const std::vector<float> &points2, Matrix4f &pose);
 
+// `ff << std::setprecision(10) << ob_in_cam << std::endl` (Bundler.cpp:372-377) with Eigen's default IOFormat: %.10g
+// coefficients, right-aligned to the widest one, one space between columns, one row per line.
+std::string formatPoseTxt(const Matrix4f &ob_in_cam);
+
 float rotationGeodesicDistance(const Matrix4f &A, const Matrix4f &B);           // rotation blocks only, radians (Utils.cpp:42-47)
 
 struct Correspondences { std::vector<float> ptA_cam, ptB_cam; };                // xyz triples; A = the newer frame

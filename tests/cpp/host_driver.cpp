@@ -4,6 +4,7 @@
 //   host_driver keyframes <poses.bin> <ids_out.bin>     checkAndAddKeyframe over a pose sequence + selectKeyFramesForBA (CPU)
 //   host_driver problem <dump.btba> <copy_out.btba>     loadProblem -> saveProblem round trip + a one-line summary (CPU)
 //   host_driver kabsch <pairs.bin> <poses_out.bin>      solveRigidTransformBetweenPoints over a list of point-set pairs (CPU)
+//   host_driver posetxt <poses.bin> <out.txt>           formatPoseTxt of every 4x4 (row-major floats) in the file (CPU)
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -140,6 +141,18 @@ static int run_kabsch(const char *in, const char *out)
     return 0;
 }
 
+static int run_posetxt(const char *in, const char *out)
+{
+    std::ifstream f(in, std::ios::binary);
+    int32_t n;
+    rd(f, &n, 1);
+    std::vector<float> P(16 * (size_t)n);
+    rd(f, P.data(), P.size());
+    std::ofstream o(out);
+    for (int k = 0; k < n; k++) o << formatPoseTxt(from_rowmajor(&P[16 * (size_t)k]));
+    return 0;
+}
+
 static int run_problem(const char *in, const char *out)
 {
     const ProblemDump pb = loadProblem(in);
@@ -160,7 +173,8 @@ int main(int argc, char **argv)
         if (argc == 4 && !std::strcmp(argv[1], "keyframes")) return run_keyframes(argv[2], argv[3]);
         if (argc == 4 && !std::strcmp(argv[1], "problem")) return run_problem(argv[2], argv[3]);
         if (argc == 4 && !std::strcmp(argv[1], "kabsch")) return run_kabsch(argv[2], argv[3]);
+        if (argc == 4 && !std::strcmp(argv[1], "posetxt")) return run_posetxt(argv[2], argv[3]);
     } catch (const std::exception &e) { std::fprintf(stderr, "host_driver: %s\n", e.what()); return 2; }
-    std::fprintf(stderr, "usage: host_driver ba|keyframes|problem|kabsch <in> <out>\n");
+    std::fprintf(stderr, "usage: host_driver ba|keyframes|problem|kabsch|posetxt <in> <out>\n");
     return 1;
 }

@@ -116,3 +116,21 @@ def test_cpp_kabsch_matches_python(tmp_path):
         assert res_cpp <= res_py + 2e-6, (k, res_cpp, res_py)
     assert np.array_equal(got[-1], np.eye(4, dtype=np.float32)) and np.array_equal(got[-2], np.eye(4, dtype=np.float32))
     assert worst < 2e-5, worst
+
+
+def test_cpp_pose_txt_matches_python(tmp_path):
+    """The pose file body (Bundler.cpp:372-377: setprecision(10), Eigen's default IOFormat) from the C++ host layer and from
+    bundler.format_pose_txt, character for character."""
+    from bundletrack_amd.bundler import format_pose_txt
+    rng = np.random.default_rng(3)
+    poses = [np.eye(4, dtype=np.float32)]
+    for _ in range(20):
+        M = rng.normal(size=(4, 4)).astype(np.float32) * np.float32(10.0 ** rng.integers(-6, 4))
+        M[3] = [0, 0, 0, 1]
+        poses.append(M)
+    poses.append(np.linalg.inv(S.SyntheticSequence(n_frames=3, seed=1).poses_gt[2]).astype(np.float32))
+    inp, out = str(tmp_path / "poses.bin"), str(tmp_path / "poses.txt")
+    with open(inp, "wb") as f:
+        f.write(np.array([len(poses)], np.int32).tobytes()); f.write(np.stack(poses).astype(np.float32).tobytes())
+    subprocess.run([driver(), "posetxt", inp, out], check=True, timeout=60)
+    assert open(out).read() == "".join(format_pose_txt(P) for P in poses)
