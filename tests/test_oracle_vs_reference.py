@@ -243,3 +243,33 @@ def test_depth_preprocessing_matches_reference_kernels(oracle):
         nr, xr = R.depth_to_normals(filt, _kinv4(oracle, pb.K))
         assert np.array_equal(bits(xo), bits(xr))
         assert np.array_equal(bits(no), bits(nr))
+
+
+def test_random_windows_oracle_vs_reference(oracle):
+    """The same forty seeded random windows the GPU test runs through the HIP path (tests/test_gpu_vs_reference.py), here oracle
+    against the reference's own solver: the well-conditioned class within 1e-4 (it is the bar), the weakly conditioned
+    class (100 %-valid frames, the dense term alone, 40 matches per pair next to it) within the 5e-3 the reference itself is
+    reproducible to there."""
+    rng = np.random.default_rng(2024)
+    worst_strict = worst_loose = 0.0
+    n_strict = 0
+    for trial in range(40):
+        K = int(rng.integers(2, 10))
+        m = int(rng.choice([0, 40, 150, 400]))
+        bg = bool(rng.integers(0, 2))
+        wd = float(rng.choice([0.0, 1.0, 1.0]))
+        if m == 0 and wd == 0.0:
+            wd = 1.0
+        pb = S.make_problem(K, m, 5000 + trial, background=bg, full_res=False, perturb_deg=float(rng.uniform(0.5, 3.0)), perturb_m=float(rng.uniform(0.001, 0.008)))
+        campos, normals, intr = S.analytic_cache(pb)
+        ref, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, weight_dense=wd)
+        tr = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=wd, n_threads=4))
+        err = max(max(S.pose_error(tr.poses[k], ref[k])) for k in range(K))
+        if (m >= 150) and (wd == 0.0 or not bg) and K >= 3:
+            worst_strict = max(worst_strict, err); n_strict += 1
+            assert err < 1e-4, (trial, K, m, bg, wd, err)
+        else:
+            worst_loose = max(worst_loose, err)
+            assert err < 5e-3, (trial, K, m, bg, wd, err)
+    print(f"random windows, oracle vs reference: {n_strict} well-conditioned, worst {worst_strict:.2e}; {40 - n_strict} weakly conditioned, worst {worst_loose:.2e}")
+    assert n_strict >= 6
