@@ -41,7 +41,7 @@ def _gen(args):
     angles = S.pruned_pool_angles(60, 30, seed) if K == 30 else None        # c4: 60-keyframe pool pruned to 30 (greedy-rot) before the timed region
     pb = S.make_problem(K, m, seed, background=not masked, full_res=False, angles=angles)
     campos, normals, intr = S.analytic_cache(pb)
-    zn = np.ascontiguousarray(np.concatenate([pb.cache_depth[..., None], pb.cache_normals[..., :3]], -1), np.float32)       # compact cache: (z, nx, ny, nz)
+    zn = S.compact_cache(pb)       # compact cache: (z, nx, ny, nz)
     return dict(campos=campos, normals=normals, intr=intr, corr=pb.corr, poses=pb.poses_init, zn=zn, K=pb.K, H=pb.H, W=pb.W)
 
 

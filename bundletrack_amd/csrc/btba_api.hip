@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <memory>
 #include <vector>
@@ -402,6 +403,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.corr_stride = corr_stride;
     D.order_flag = order_flag;
     D.tile_major = (prm->flags & BTBA_FLAG_PAIR_MAJOR) ? 0 : 1;
+    D.walk_blocks = (Wd % 8 == 0 && Hd % 8 == 0 && !std::getenv("BTBA_NO_BLOCK_WALK")) ? 1 : 0;
     D.n_gn = prm->n_gn_iters;
     int zn_layout = 0;
     if (use_zn) {
@@ -413,7 +415,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         D.zn_scale_w = (float)(Z.W - 1) / (float)(Wd - 1);
         D.zn_scale_h = (float)(Z.H - 1) / (float)(Hd - 1);
         const float *ki = D.zn_ki;
-        D.zn_simple = (ki[1] == 0.f && ki[3] == 0.f && ki[4] == 0.f && ki[7] == 0.f && ki[12] == 0.f && ki[13] == 0.f && ki[14] == 0.f) ? 1 : 0;
+        D.zn_simple = (ki[1] == 0.f && ki[3] == 0.f && ki[4] == 0.f && ki[7] == 0.f && ki[12] == 0.f && ki[13] == 0.f && ki[14] == 0.f && ki[15] == 1.0f) ? 1 : 0;     // pinhole: z = d exactly
         zn_layout = D.zn_simple ? 1 : 2;
     }
     D.trace_on = (trace != nullptr) && (prm->flags & BTBA_FLAG_TRACE);

@@ -21,6 +21,13 @@
 // Summation is deterministic (fixed DPP tree inside a wave, fixed order across waves, tiles and
 // pairs); the reference uses float atomics (SURVEY.md section 5 "race detection").
 #pragma once
+// tuning switches of the pinhole dense sweep (A/B builds override them on the command line)
+#ifndef BTBA_AB_BUILD
+#define BTBA_PINHOLE_SGPR_POSE
+#define BTBA_PINHOLE_SGPR_CONST
+#define BTBA_PAIR_ACC
+#define BTBA_FUSED_WAVES 6
+#endif
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -61,6 +68,7 @@ struct SolveDims {
     int64_t tr_x, tr_T, tr_rhs, tr_prec, tr_pcg, tr_delta, tr_dpair, tr_A, tr_clk;
     int n_gn;
     int pairsum_in_lds;  // 1: stage reduced pair sums in LDS, 0: in global scratch
+    int walk_blocks;     // pinhole sweep on the compact cache: waves walk 8 x 8 pixel blocks (width and height multiples of 8)
     int tile_major;      // dense work order inside an instance: 1 = (tile, pair) -- all pairs' band t of the images together -- 0 = (pair, tile)
     int *order_flag;     // non-null: the sparse sweep ORs 1 into it when an entry does not belong to the pair of its segment
     // compact (z, nx, ny, nz) frame cache: how a cached pixel maps back to camera space -- the arithmetic of k_build_cache
@@ -218,8 +226,10 @@ __global__ void __launch_bounds__(kBlock) k_build_cache_zn(int W, int H, int Wd,
             const size_t s = (size_t)yi * W + xi;
             const float d = depth[f][s];
             const float4 nr = reinterpret_cast<const float4 *>(normals[f])[s];
-            zn_out[(size_t)fo * npix + o] = make_float4(d, nr.x, nr.y, nr.z);
             valid = ((double)d >= 0.1) ? 1 : 0;
+            // GATED depth: 0 where the reference's camPos is (0, 0, 0, 0) (CUDAImageUtil.cu:310-327: d < 0.1, and NaN fails the
+            // comparison too), so that the sweep blends exactly what the reference blends without re-testing every tap
+            zn_out[(size_t)fo * npix + o] = make_float4(valid ? d : 0.0f, nr.x, nr.y, nr.z);
         }
     }
     if (n_valid) {
@@ -635,6 +645,231 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
     block_reduce_store<kDenseVals, 4>(acc, red, out);
 }
 
+// ---- the dense sweep for pinhole intrinsics on the GATED compact cache --------------------------------------------
+// Same arithmetic per accepted pixel as dense_block_zn<true, .>, re-shaped around what the VALU of gfx950 actually charges
+// (scripts/valu_calibrate.hip, profiles/r02/valu_calibration.md): a wave64 fp32 mul / add / fma with VGPR sources issues in
+// 2 cycles, but v_cmp*, v_cndmask*, v_cvt*, v_floor, v_min / v_max, v_lshlrev, every VOP3 integer op (v_lshl_add_u32,
+// v_mul_lo_u32, ...) and ANY VALU op with an SGPR source take 4, transcendentals 8.  The old loop spent 71 of its 222
+// instructions on compares, selects and integer index arithmetic and 35 more on 2-cycle operations slowed down by an SGPR
+// operand.  Here:
+//   * the cache stores the GATED depth (0 where the reference's camPos is 0: d < 0.1 or NaN, CUDAImageUtil.cu:310-327),
+//     so the per-tap `d >= 0.1 ? d : 0` select (5 compares + 5 selects per pixel) is done once, by the cache builder;
+//   * a pinhole K^-1 has [15] == 1, so z = d without a multiply;
+//   * the projection is CLAMPED to the image, uc = med3(u, 0, W - 1): the in-image test of the rounded coordinates
+//     (-0.5 < u < W - 0.5, SolverBundlingDenseUtil.h:91-94) is |u - uc| < 0.5 -- exact, both differences are exact -- and
+//     the bilinear taps are floor(uc), ceil(uc): a tap the reference skips because it lies outside the image
+//     (ICPUtil.h:96-102) gets weight 0 here, and where the reference renormalises by the surviving weight, alpha / alpha,
+//     the clamped coordinate has weight exactly 1.  No tap-validity compares, no weight selects, no reciprocals; when all
+//     four taps are in the image the reference divides by (1 - alpha) + alpha = 1 +- 1 ulp, which is dropped (the
+//     reference itself is built with -use_fast_math);
+//   * tap addresses are computed in fp32 (exact: byte offsets < 2^24) and converted once per tap: 4 v_cvt instead of
+//     8 clamps, 2 integer multiplies and 8 shift-adds; LDS look-up addresses likewise;
+//   * depth-range tests are one unsigned compare of the bit patterns: for positive floats order is bit order, negative
+//     values, zeros and NaN fall outside after the subtraction wraps;
+//   * wave-uniform operands of 2-cycle operations (relative pose, intrinsics) live in VGPRs.
+struct PinholeCtx {
+    float R[9], t[3];                 // relative pose source camera -> target camera
+    float fx, fy, cx, cy, wm1, hm1, wm2, hm2, w16, normal_thresh, dist2_thresh, wdelta, w_dense, ybase4;
+    unsigned row16;                   // bytes per cache row
+    unsigned zmin_bits, zrange_bits;  // depth_min < z < depth_max  <=>  bits(z) - (bits(depth_min) + 1) < zrange_bits (unsigned)
+};
+
+__device__ __forceinline__ float lds_f32_at(const float *base, unsigned byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); }
+__device__ __forceinline__ float2 lds_f32x2_at(const float *base, unsigned byte_off) { const char *q = reinterpret_cast<const char *>(base) + byte_off; return make_float2(*reinterpret_cast<const float *>(q), *reinterpret_cast<const float *>(q + 4)); }
+__device__ __forceinline__ float4 gather16(const float4 *base, unsigned byte_off) { return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off); }
+// opaque copies: keep a wave-uniform value in a VGPR (the compiler would otherwise fold it back into an SGPR operand, 4 cycles)
+#ifdef BTBA_PINHOLE_SGPR_CONST
+__device__ __forceinline__ float in_vgpr(float x) { return x; }
+__device__ __forceinline__ unsigned in_vgpr(unsigned x) { return x; }
+#else
+__device__ __forceinline__ float in_vgpr(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ unsigned in_vgpr(unsigned x) { asm volatile("" : "+v"(x)); return x; }
+#endif
+__device__ __forceinline__ unsigned opaque_vgpr(unsigned x) { asm volatile("" : "+v"(x)); return x; }
+
+template <int WALK>     // 0: 64-pixel row strips   1: the source frame's valid-pixel list   2: 8 x 8 pixel blocks per wave (cache width and height multiples of 8)
+__device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
+                                                    const float *__restrict__ T, const float *__restrict__ Tinv,
+                                                    float *__restrict__ partials, int tile, int p, int b, float *red,
+                                                    const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts, float *lut)
+{
+    // lut[0 .. Wd) = K^-1[0][0] x_full(x) + K^-1[0][2] per cache column, lut[Wd .. Wd+Hd) the same for rows (as dense_block_zn<true>)
+    for (int e = (int)threadIdx.x; e < D.width + D.height; e += kBlock) {
+        const bool is_x = e < D.width;
+        const float c = (float)(is_x ? zn_src_coord(e, D.zn_scale_w) : zn_src_coord(e - D.width, D.zn_scale_h));
+        lut[e] = is_x ? D.zn_ki[0] * c + D.zn_ki[2] : D.zn_ki[5] * c + D.zn_ki[6];
+    }
+    __syncthreads();
+    const int2 ij = dense_pairs[p];
+    const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
+    const size_t fb = (size_t)b * D.n_frames;
+    const Mat4 Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), load_mat4(T + 16 * (fb + fj)));
+    PinholeCtx C;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+#ifdef BTBA_PINHOLE_SGPR_POSE
+        for (int c = 0; c < 3; c++) C.R[3 * r + c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Tij.m[4 * r + c])));
+        C.t[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Tij.m[4 * r + 3])));
+#else
+        for (int c = 0; c < 3; c++) C.R[3 * r + c] = in_vgpr(Tij.m[4 * r + c]);
+        C.t[r] = in_vgpr(Tij.m[4 * r + 3]);
+#endif
+    }
+    C.fx = in_vgpr(D.fx); C.fy = in_vgpr(D.fy); C.cx = in_vgpr(D.cx); C.cy = in_vgpr(D.cy);
+    C.wm1 = (float)(D.width - 1); C.hm1 = (float)(D.height - 1); C.wm2 = (float)(D.width - 2); C.hm2 = (float)(D.height - 2);
+    C.w16 = in_vgpr(16.0f * (float)D.width); C.row16 = in_vgpr(16u * (unsigned)D.width);
+    C.ybase4 = in_vgpr(4.0f * (float)D.width);            // LDS byte offset of the row table
+    C.normal_thresh = D.normal_thresh; C.dist2_thresh = D.dist_thresh * D.dist_thresh;
+    C.wdelta = in_vgpr(D.w_dense * D.robust_delta); C.w_dense = in_vgpr(D.w_dense);
+    C.zmin_bits = in_vgpr(__float_as_uint(D.depth_min) + 1u); C.zrange_bits = __float_as_uint(D.depth_max) - __float_as_uint(D.depth_min) - 1u;
+    const size_t slot_t = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fi));
+    const size_t slot_s = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fj));
+    const float4 *zn_t = zn + slot_t * (size_t)D.npix, *zn_s = zn + slot_s * (size_t)D.npix;
+    constexpr bool LISTS = (WALK == 1);
+    float acc[kDenseVals];
+#pragma unroll
+    for (int k = 0; k < kDenseVals; k++) acc[k] = 0.0f;
+
+    // one source pixel: zs = its (gated depth, normal), ox / oy = LDS byte offsets of its column / row terms
+    auto pixel = [&](const float4 &zs, unsigned ox, unsigned oy) {
+        // source pixel -> camera space (gated depth: 0 where invalid), depth-range test on the bit pattern
+        const float d = zs.x;
+        const bool src_ok = (__float_as_uint(d) - C.zmin_bits) < C.zrange_bits;
+        const float sx = lds_f32_at(lut, ox) * d, sy = lds_f32_at(lut, oy) * d;
+        // rotate the normal, transform the point, project
+        const float nqx = C.R[0] * zs.y + C.R[1] * zs.z + C.R[2] * zs.w;
+        const float nqy = C.R[3] * zs.y + C.R[4] * zs.z + C.R[5] * zs.w;
+        const float nqz = C.R[6] * zs.y + C.R[7] * zs.z + C.R[8] * zs.w;
+        const float qx = C.R[0] * sx + C.R[1] * sy + C.R[2] * d + C.t[0];
+        const float qy = C.R[3] * sx + C.R[4] * sy + C.R[5] * d + C.t[1];
+        const float qz = C.R[6] * sx + C.R[7] * sy + C.R[8] * d + C.t[2];
+        const float rqz = fast_rcp(qz);
+        const float u = qx * C.fx * rqz + C.cx, v = qy * C.fy * rqz + C.cy;
+        const float uc = __builtin_amdgcn_fmed3f(u, 0.0f, C.wm1), vc = __builtin_amdgcn_fmed3f(v, 0.0f, C.hm1);      // NaN -> 0: addresses stay in the frame
+        const bool valid = src_ok & (fabsf(u - uc) < 0.5f) & (fabsf(v - vc) < 0.5f);
+        if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
+        // taps (x0, x0 + 1) x (y0, y0 + 1) with x0 = min(floor(uc), W - 2): at the right / bottom edge (uc = W - 1) the weights are (0, 1)
+        // instead of (1, -) -- the same blend, and the four taps are always the 2 x 2 block at ONE computed address
+        const float fx0 = fminf(floorf(uc), C.wm2), fy0 = fminf(floorf(vc), C.hm2);
+        const float alpha = uc - fx0, beta = vc - fy0;
+        const unsigned o00 = (unsigned)(fy0 * C.w16 + 16.0f * fx0), o01 = o00 + C.row16;      // byte offsets, fp32-exact below 2^24
+        const float4 z00 = gather16(zn_t, o00), z10 = gather16(zn_t, o00 + 16u), z01 = gather16(zn_t, o01), z11 = gather16(zn_t, o01 + 16u);
+        const float2 xi2 = lds_f32x2_at(lut, (unsigned)(4.0f * fx0)), yi2 = lds_f32x2_at(lut, (unsigned)(4.0f * fy0 + C.ybase4));
+        const float a0 = 1.0f - alpha, b0 = 1.0f - beta;
+        // blend of the taps' camera-space points (x = column term * z, y = row term * z, z = gated depth) and normals; the
+        // column / row terms are shared by the taps of a column / row, so they multiply the partial sums
+        const float t00 = (b0 * a0) * z00.x, t10 = (b0 * alpha) * z10.x, t01 = (beta * a0) * z01.x, t11 = (beta * alpha) * z11.x;
+        const float c00 = b0 * a0, c10 = b0 * alpha, c01 = beta * a0, c11 = beta * alpha;
+        const float cix = xi2.x * (t00 + t01) + xi2.y * (t10 + t11);
+        const float ciy = yi2.x * (t00 + t10) + yi2.y * (t01 + t11);
+        const float ciz = (t00 + t01) + (t10 + t11);
+        const float nix = c00 * z00.y + c10 * z10.y + c01 * z01.y + c11 * z11.y;
+        const float niy = c00 * z00.z + c10 * z10.z + c01 * z01.z + c11 * z11.z;
+        const float niz = c00 * z00.w + c10 * z10.w + c01 * z01.w + c11 * z11.w;
+        const float dx = qx - cix, dy = qy - ciy, dz = qz - ciz;
+        const float dist2 = dx * dx + dy * dy + dz * dz;
+        const float dn = nqx * nix + nqy * niy + nqz * niz;
+        const bool ok = valid & ((__float_as_uint(ciz) - C.zmin_bits) < C.zrange_bits) & (dn >= C.normal_thresh) & (dist2 <= C.dist2_thresh);
+        // rejected pixels contribute exact zeros: AND with 0 / ~0 (one select, then 2-cycle v_and_b32; NaN-safe, unlike a multiply)
+        const unsigned keep = opaque_vgpr(ok ? 0xFFFFFFFFu : 0u);
+        auto masked = [keep](float x) { return __uint_as_float(__float_as_uint(x) & keep); };
+        const float res = masked(-(dx * nix + dy * niy + dz * niz));
+        // Huber (SolverBundlingUtil.h:24-40) times the dense weight: rho' = 1 for e <= delta^2, delta / sqrt(e) above  <=>  min(1, delta rsq(e))
+        const float wgt = masked(fminf(C.w_dense, C.wdelta * fast_rsq(res * res)));
+        const float mx = masked(nix), my = masked(niy), mz = masked(niz);
+        const float a[6] = { -mx, -my, -mz, my * qz - mz * qy, mz * qx - mx * qz, mx * qy - my * qx };
+        int k = 0;
+#ifdef BTBA_PAIR_ACC
+        // acc += wa_r * a_c is a read-modify-write FMA: it issues at full rate only when its two multiplicands sit in VGPRs of
+        // different parity (profiles/r02/valu_calibration.md).  (wa_r, a_r) held as an aligned register PAIR puts every wa in an
+        // even and every a in an odd register, whatever the allocator does with the rest.
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        f2v pr[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) { pr[r] = (f2v){ wgt * a[r], a[r] }; asm volatile("" : "+v"(pr[r])); }
+        f2v rr = (f2v){ wgt, res };
+        asm volatile("" : "+v"(rr));
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+#pragma unroll
+            for (int c = r; c < 6; c++) acc[k++] += pr[r].x * pr[c].y;
+            acc[21 + r] += pr[r].x * rr.y;
+        }
+#else
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const float wa = wgt * a[r];
+#pragma unroll
+            for (int c = r; c < 6; c++) acc[k++] += wa * a[c];
+            acc[21 + r] += wa * res;
+        }
+#endif
+        acc[27] += masked(1.0f);
+    };
+
+    if (WALK == 2) {
+        // Wave w of the workgroup walks the 8 x 8 pixel blocks w, w + 4, ... of this band of block rows; lane = (row, column) inside
+        // the block.  The region of a source frame that projects into the target is a compact blob, so whole blocks fall outside it
+        // and are skipped (49 % of the wave trips carry a valid pixel at c3, against 69 % for 64 x 1 strips), and a block's taps land
+        // in a compact patch of the target.  Block coordinates are wave-uniform: they advance in scalar registers.
+        const int bw = D.width >> 3, bh = D.height >> 3;
+        const int rows_per = (bh + D.dense_tiles - 1) / D.dense_tiles;
+        const int r0 = min(bh, rows_per * tile), r1 = min(bh, rows_per * (tile + 1));
+        const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        const unsigned lx = (unsigned)lane & 7u, ly = (unsigned)lane >> 3;
+        const unsigned lane_px = ly * (unsigned)D.width + lx;          // pixel offset of the lane inside its block
+        const unsigned ox_l = 4u * lx, oy_l = 4u * ly + 4u * (unsigned)D.width;
+        // (bx, by) of this wave's current and next block, advanced without divisions (scalar registers)
+        int bx = wave % bw, by = r0 + wave / bw;
+        auto advance = [&](int &x, int &y) { x += kBlock / 64; while (x >= bw) { x -= bw; y++; } };
+        int bxn = bx, byn = by;
+        advance(bxn, byn);
+        float4 zs_n = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (by < r1) zs_n = zn_s[(unsigned)(by * 8 * D.width + bx * 8) + lane_px];
+        while (by < r1) {
+            const float4 zs = zs_n;
+            if (byn < r1) zs_n = zn_s[(unsigned)(byn * 8 * D.width + bxn * 8) + lane_px];        // next block's stream loads
+            pixel(zs, ox_l + 32u * (unsigned)bx, oy_l + 32u * (unsigned)by);
+            bx = bxn; by = byn;
+            advance(bxn, byn);
+        }
+    } else {
+        const int n_src = LISTS ? valid_counts[slot_s] : D.npix;
+        const uint32_t *list = LISTS ? valid_lists + slot_s * (size_t)D.npix : nullptr;
+        const int per = (n_src + D.dense_tiles - 1) / D.dense_tiles;
+        const int lo = min(n_src, per * tile), hi = min(n_src, per * (tile + 1));
+        const float inv_w = 1.0f / (float)D.width;
+        int t = lo + (int)threadIdx.x;
+        int s_n = (t < hi) ? (LISTS ? (int)list[t] : t) : 0;
+        // direct walk: LDS byte offsets of the pixel's column / row entries (row table behind the column table), advanced by
+        // one workgroup stride per trip
+        const unsigned w4 = 4u * (unsigned)D.width;
+        unsigned px4 = 4u * (unsigned)(s_n % D.width), py4 = 4u * (unsigned)(s_n / D.width) + w4;
+        const unsigned step_x4 = in_vgpr(4u * (unsigned)(kBlock % D.width)), step_y4 = in_vgpr(4u * (unsigned)(kBlock / D.width));
+        float4 zs_n = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < hi) zs_n = zn_s[s_n];
+        for (; t < hi; t += kBlock) {
+            const float4 zs = zs_n;
+            const int s = s_n;
+            if (t + kBlock < hi) { s_n = LISTS ? (int)list[t + kBlock] : t + kBlock; zs_n = zn_s[s_n]; }      // next pixel's stream loads
+            unsigned ox, oy;
+            if (!LISTS) {
+                ox = px4; oy = py4;
+                px4 += step_x4; py4 += step_y4;
+                if (px4 >= w4) { px4 -= w4; py4 += 4u; }
+            } else {
+                const float sf = (float)s;
+                const float pyf = floorf((sf + 0.5f) * inv_w);              // exact: the margin 0.5 / W is far above the rounding of the product
+                ox = (unsigned)(4.0f * (sf - pyf * (float)D.width)); oy = (unsigned)(4.0f * pyf + C.ybase4);
+            }
+            pixel(zs, ox, oy);
+        }
+    }
+    float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
+    block_reduce_store<kDenseVals, 4>(acc, red, out);
+}
+
 template <bool SIMPLE, bool LISTS>
 __global__ void __launch_bounds__(kBlock, 5) k_dense_sweep_zn(SolveDims D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
                                                              const float *__restrict__ T, const float *__restrict__ Tinv, float *__restrict__ partials,
@@ -667,8 +902,11 @@ __global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, cons
 // n_s sparse workgroups (HBM-streaming) so the two overlap on every CU instead of running back to back.
 // Per XCD x (blocks g = 8 s + x, s = slot): a contiguous range of dense items (L2 locality, as in xcd_remap)
 // and every R_x-th slot a sparse item.
+#ifndef BTBA_FUSED_WAVES
+#define BTBA_FUSED_WAVES 3
+#endif
 template <int LAYOUT>   // 0: float4 camPos + float4 normals; compact cache: 1 zero-skew K, 2 general K, 3 / 4 the same walking valid-pixel lists
-__global__ void __launch_bounds__(kBlock, 3) k_fused_sweeps(SolveDims D, unsigned n_d, unsigned n_s,
+__global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_fused_sweeps(SolveDims D, unsigned n_d, unsigned n_s,
                                                            const float4 *__restrict__ campos, const float4 *__restrict__ normals,
                                                            const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
                                                            float *__restrict__ dense_partials,
@@ -699,9 +937,10 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused_sweeps(SolveDims D, unsigne
         const int tile = D.tile_major ? (int)(Lb / (unsigned)D.n_dense_pairs) : (int)(Lb % (unsigned)D.dense_tiles);
         const int p = D.tile_major ? (int)(Lb % (unsigned)D.n_dense_pairs) : (int)(Lb / (unsigned)D.dense_tiles);
         if (LAYOUT == 0) dense_block<1>(D, campos, normals, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
-        else if (LAYOUT == 1) dense_block_zn<true, false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);     // `campos` carries the compact cache
+        else if (LAYOUT == 1 && D.walk_blocks) dense_block_pinhole<2>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+        else if (LAYOUT == 1) dense_block_pinhole<0>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);     // `campos` carries the compact cache
         else if (LAYOUT == 2) dense_block_zn<false, false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
-        else if (LAYOUT == 3) dense_block_zn<true, true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+        else if (LAYOUT == 3) dense_block_pinhole<1>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
         else dense_block_zn<false, true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
     }
 }

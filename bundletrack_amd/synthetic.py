@@ -276,6 +276,15 @@ def analytic_cache(pb: Problem):
     return campos, pb.cache_normals.astype(np.float32), intr
 
 
+def compact_cache(pb: Problem):
+    """Compact (z, nx, ny, nz) frame cache [N, Hd, Wd, 4] built on the host (include/btba.h, "ZN"): the z lane is the GATED
+    depth -- 0 where the reference's camPos is zero (d < 0.1 or NaN), like btba_build_cache_zn writes it."""
+    d = pb.cache_depth.astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        d = np.where(d >= np.float32(0.1), d, np.float32(0.0)).astype(np.float32)
+    return np.ascontiguousarray(np.concatenate([d[..., None], pb.cache_normals[..., :3].astype(np.float32)], -1), np.float32)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # A synthetic tracking SEQUENCE (SURVEY.md 8(d) config c1): frames on an orbit handed one by one to
 # bundler.Bundler, with a stand-in for the feature front end (LF-Net / matching / RANSAC are out of scope).

@@ -266,7 +266,10 @@ BTBA_API int btba_depth_to_normals(btba_workspace *ws, int H, int W, const float
  * camPos is a pure function of (full-resolution pixel, depth) -- CUDAImageUtil.cu:310-327 -- so the cache can hold
  * float4 (z, nx, ny, nz) per pixel, 16 B instead of the reference's 32 B (CUDACachedFrame, CUDACacheUtil.h:10-53), and
  * the sweep re-derives camPos with the cache builder's exact fp32 operations: identical results, half the bytes,
- * half the load instructions.  btba_optimize_frames uses it internally (BTBA_FLAG_FLOAT4_CACHE switches back). */
+ * half the load instructions.  btba_optimize_frames uses it internally (BTBA_FLAG_FLOAT4_CACHE switches back).
+ * CONTRACT of the z lane: it is the GATED depth -- 0 wherever the reference's cached camPos is (0, 0, 0, 0), i.e. where
+ * the full-resolution depth is below 0.1 m or NaN (CUDAImageUtil.cu:310-327) -- exactly camPos.z of the reference
+ * layout.  btba_build_cache_zn and btba_pack_zn produce it; a caller that fills the cache itself must apply the gate. */
 BTBA_API int btba_build_cache_zn(btba_workspace *ws, int n_frames, int H, int W, const float *K_rowmajor,
                                  float image_downscale, const float *const *depth_dev, const float *const *normal_dev,
                                  float *zn_dev /* float4[n_frames][Hd*Wd] */, int32_t *n_valid_dev, float *intr_out);

@@ -18,7 +18,7 @@ def hip_solve(pb, wd):
     dev = torch.device("cuda:0")
     bs = BatchSolver(Workspace(), weight_dense_depth=wd)
     corr, offs, mx = bs.pack_correspondences([pb.corr], pb.n_frames)
-    zn = np.ascontiguousarray(np.concatenate([pb.cache_depth[..., None], pb.cache_normals[..., :3]], -1), np.float32)   # astype() alone keeps a strided layout
+    zn = S.compact_cache(pb)   # astype() alone keeps a strided layout
     zn_d = torch.from_numpy(zn[None]).to(dev)
     corr_d = torch.from_numpy(corr.view(np.uint8).reshape(1, -1, 32)).to(dev)
     offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)

@@ -25,7 +25,7 @@ def main(want):
             if layout == "float4":
                 t = bs.solve(torch.from_numpy(campos[None]).to(dev), torch.from_numpy(normals[None]).to(dev), intr, corr_d, offs_d, mx, poses_d, trace=True)
             else:
-                zn = np.ascontiguousarray(np.concatenate([pb.cache_depth[..., None], pb.cache_normals[..., :3]], -1), np.float32)
+                zn = S.compact_cache(pb)
                 t = bs.solve_zn(torch.from_numpy(zn[None]).to(dev), pb.H, pb.W, pb.K, corr_d, offs_d, mx, poses_d, trace=True)
             tv = bs.trace_view(t)
             P = K * (K - 1) // 2
