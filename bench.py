@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 
 METRIC = "Gauss-Newton iters/sec (K=15, 2k corr/frame-pair) + achieved HBM GB/s"
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
+VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector peak = dense f32 MFMA peak (64 flop/clk/SIMD, unpacked v_fma_f32; profiles/r02/valu_calibration.md)
 CONFIGS = {
     "c2": dict(K=10, m=1000, w_dense=0.0, config=2, desc="K=10, 1k corr/pair, feature residuals only"),
     "c3": dict(K=15, m=2000, w_dense=1.0, config=3, desc="K=15, 2k corr/pair, feature + dense point-to-plane ICP + Huber"),
@@ -58,6 +59,28 @@ def generate_instances(cfg, ids, masked=False):
     return [_gen(j) for j in jobs]
 
 
+def kernel_source_hash():
+    """sha256 over the sources libbtba.so is built from: counter summaries under profiles/ are only quoted for the kernels they were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "bundletrack_amd", "csrc")
+    for f in sorted(os.listdir(src)) + ["../../include/btba.h"]:
+        h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled_counters(config, B, masked, float4_cache, fused):
+    """PMC summary of the dominant kernel written by scripts/summarize_profiles.py -- only if it was taken on THESE sources and this workload."""
+    tp = os.path.join(ROOT, "profiles", "sweep_counters.json")
+    try:
+        tj = json.load(open(tp))
+    except Exception:
+        return None
+    same = (tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("instances") == B and tj.get("config") == config
+            and bool(tj.get("fused")) == fused and bool(tj.get("masked")) == masked and bool(tj.get("float4_cache")) == float4_cache)
+    return tj if same else None
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -68,14 +91,20 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(cfg, inst, budget_s=20.0):
-    """The CPU oracle (a port: the reference has no CPU path) timed on this box's host cores on a bounded
-    sample of the same workload: whole solves of ONE instance, single-thread and all-threads."""
+def cpu_baseline(cfg, insts, budget_s=24.0):
+    """The CPU oracle (a port: the reference has no CPU path) timed on this box's host cores on a bounded sample of the same
+    workload: whole solves (7 GN x 5 PCG) -- one instance on 1 thread, one instance on 16 OpenMP threads (frame pairs / correspondence
+    chunks), and the c5 way: ALL host CPUs, one single-threaded solve per CPU over distinct instances (the GPU path's own sharding)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
-    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    inst = insts[0]
     out = {}
-    nmt = min(ncpu, 16)       # the oracle parallelises over frame pairs / frames: more threads than that only add overhead
-    for label, nt, share in (("1t", 1, 0.4), ("all", nmt, 0.6)):
+    nmt = min(ncpu, 16)       # one instance parallelises over frame pairs / frames: more threads than that only add overhead
+    for label, nt, share in (("1t", 1, 0.25), ("omp", nmt, 0.25)):
         prm = O.default_params(weight_dense_depth=cfg["w_dense"], n_threads=nt)
         t0 = time.perf_counter()
         n = 0
@@ -86,6 +115,21 @@ def cpu_baseline(cfg, inst, budget_s=20.0):
                 break
         dt = time.perf_counter() - t0
         out[label] = (7.0 * n / dt, n, dt, nt)
+    # all CPUs, instance-parallel: ctypes releases the GIL inside orc_solve, every worker thread runs single-threaded solves
+    per_solve = 7.0 / out["1t"][0]
+    reps = max(1, int(budget_s * 0.5 / per_solve))
+    prm1 = O.default_params(weight_dense_depth=cfg["w_dense"], n_threads=1)
+
+    def work(w):
+        for r in range(reps):
+            q = insts[(w + r) % len(insts)]
+            O.solve(q["campos"], q["normals"], q["intr"], q["corr"], q["poses"], params=prm1, want_trace=False)
+        return reps
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=ncpu) as ex:
+        done = sum(ex.map(work, range(ncpu)))
+    dt = time.perf_counter() - t0
+    out["all"] = (7.0 * done / dt, done, dt, ncpu)
     best = max(out.values(), key=lambda v: v[0])
     ref_note = None
     try:        # the reference's own solver, compiled for the CPU and run through the sequential launch emulator (oracle/_ref):
@@ -98,8 +142,11 @@ def cpu_baseline(cfg, inst, budget_s=20.0):
     except Exception:
         ref_note = None
     return {"value": round(best[0], 3), "unit": "GN iterations/s", "cores": best[3], "kind": "port", "reference_emulated": ref_note,
-            "sample": f"{best[1]} full solves (7 GN x 5 PCG) of one {cfg['desc']} instance in {best[2]:.1f} s; "
-                      f"1 thread: {out['1t'][0]:.2f} it/s, {nmt} threads: {out['all'][0]:.2f} it/s (gcc -O3 AVX2 + OpenMP, oracle/btba_oracle.c)",
+            "sample": f"{best[1]} full solves (7 GN x 5 PCG) of {cfg['desc']} instances in {best[2]:.1f} s; "
+                      f"1 thread, 1 instance: {out['1t'][0]:.2f} it/s; {nmt} OpenMP threads, 1 instance: {out['omp'][0]:.2f} it/s; "
+                      f"{ncpu} CPUs x 1 thread, {min(len(insts), ncpu)} distinct instances in parallel: {out['all'][0]:.2f} it/s (gcc -O3 AVX2, oracle/btba_oracle.c)",
+            "one_thread": round(out["1t"][0], 3), "omp_single_instance": {"value": round(out["omp"][0], 3), "threads": nmt},
+            "all_cpus_instance_parallel": {"value": round(out["all"][0], 3), "cpus": ncpu, "solves": done, "seconds": round(dt, 2)},
             "host_cpus": ncpu, "host_cpu_model": _cpu_model()}
 
 
@@ -126,7 +173,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--instances", type=int, default=32, help="instances per GPU")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic instances generated per GPU (tiled to --instances)")
+    ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic instances generated per GPU (seeds 1234 + 1000 config + global instance id; tiled to --instances if fewer)")
     ap.add_argument("--masked", action="store_true", help="realistic ~5%%-valid object mask instead of the 100%%-valid roofline variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -222,41 +269,46 @@ def main():
             "per_rank": [{"seconds": round(s, 6), "gn_iters": g} for s, g in per_rank],
         }
         if not args.no_kernel_timing and st["n_dense_launches"] > 0:
-            # dominant kernel = the Jacobian sweep.  Algorithmic bytes per launch (no credit for cache reuse):
-            # dense 64 B x pairs x pixels x instances (source camPos+normal 32 B + target camPos+normal 32 B per pixel pair)
-            # + 32 B per correspondence when the sparse sweep rides in the same launch (fused_sweeps).
+            # Dominant kernel = the Jacobian sweep (fused: dense + sparse workgroups in one launch).  It is bound by VALU issue, not by
+            # HBM (PMC: the vector pipe is ~87 % busy, HBM at ~0.2 of peak), so the roofline is the fp32 vector peak -- 157.3 TFLOP/s on
+            # MI355X, equal to the dense f32 MFMA peak -- against SURVEY.md 8(d)'s ALGORITHMIC flops: 200 per (frame pair, valid source
+            # pixel), 120 per correspondence.  The 8(d) HBM accounting (64 B per pair-pixel, 32 B per correspondence, no credit for the
+            # reuse of a frame by its 14 pairs) is kept as context with the measured traffic next to it.
             avg_ms = st["ms_dense_sweep"] / st["n_dense_launches"]
             fused = bool(st.get("fused_sweeps", 0))
-            bytes_alg = 64 * P * npix * B + (32 * n_corr if fused else 0)
-            achieved = bytes_alg / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "dense_sweep_traffic.json")
-            if os.path.exists(tp):
-                try:
-                    tj = json.load(open(tp))
-                    if tj.get("instances") == B and tj.get("config") == args.config and bool(tj.get("fused", False)) == fused and bool(tj.get("masked", False)) == args.masked and bool(tj.get("float4_cache", True)) == args.float4_cache:
-                        traffic = tj.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            res["roofline"] = {"bound": "hbm", "kernel": "k_fused_sweeps (dense + sparse workgroups)" if fused else "k_dense_sweep",
-                               "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_dense_launches"],
-                               "note": "achieved = ALGORITHMIC bytes / time: every frame pair is charged a full read of both frames, so L2/MALL reuse "
-                                       "of a frame across its 14 pairs pushes it above the HBM peak; `traffic` is what actually crossed the L2<->fabric "
-                                       "boundary (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"}
+            depth = np.stack([p["zn"][..., 0] for p in pick]) if not args.float4_cache else np.stack([p["campos"][..., 2] for p in pick])
+            nvalid = (depth >= 0.1).reshape(B, K, -1).sum(-1)                        # valid source pixels per frame
+            pair_pixels = int((nvalid * np.arange(K)[None, :]).sum())                # frame j is the source of its j pairs (i < j)
+            flops_alg = 200.0 * pair_pixels + (120.0 * n_corr if fused else 0.0)
+            bytes_alg = 64 * pair_pixels + (32 * n_corr if fused else 0)
+            tflops = flops_alg / (avg_ms * 1e-3) / 1e12
+            pc = profiled_counters(args.config, B, args.masked, args.float4_cache, fused)
+            traffic = pc.get("hbm_bytes_per_launch") if pc else None
+            res["roofline"] = {"bound": "valu", "kernel": "k_fused_sweeps (dense + sparse workgroups)" if fused else "k_dense_sweep",
+                               "achieved": round(tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
+                               "traffic": traffic, "algorithmic_flops_per_launch": flops_alg, "pair_pixels_per_launch": pair_pixels,
+                               "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_dense_launches"],
+                               "note": "fp32 vector (VALU) roofline: algorithmic flops / launch time against 157.3 TFLOP/s (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz = the "
+                                       "dense f32 MFMA peak); durations from hipEvents on the workspace stream inside the timed region"}
+            if pc and pc.get("valu_busy_frac") is not None:
+                res["roofline"]["valu_issue"] = {"busy_frac": pc["valu_busy_frac"], "cycles_per_instruction": pc.get("valu_cycles_per_inst"),
+                                                 "dual_issued_frac": pc.get("valu_dual_issued_frac"), "waves_per_simd": pc.get("waves_per_simd"),
+                                                 "source": pc.get("source_sq"), "kernel_source_hash": pc.get("kernel_source_hash"),
+                                                 "formula": "4 (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / 1024 SIMDs / (SQ_BUSY_CYCLES / 32); units pinned in profiles/r02/valu_calibration.md"}
+            else:
+                res["roofline"]["valu_issue"] = None          # no counter pass on these sources / this workload (scripts/profile_bench.sh)
+            hb = {"achieved_GBps": round(bytes_alg / (avg_ms * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_alg,
+                  "note": "SURVEY.md 8(d) accounting; it exceeds the HBM peak because every pair is charged both frames while a frame is reused by its 14 pairs "
+                          "out of L2 -- not a bandwidth measurement"}
             if traffic:
-                res["roofline"]["hbm_traffic_GBps"] = round(traffic / (avg_ms * 1e-3) / 1e9, 1)
-            # what actually limits the kernel (VALU issue, 66 % busy): the same launch against the fp32 vector
-            # peak, from SURVEY.md 8(d)'s algorithmic flops (200 per pixel pair, 120 per correspondence) -- context, not `frac`
-            flops_alg = 200.0 * P * npix * B + (120.0 * n_corr if fused else 0.0)
-            res["roofline"]["valu_context"] = {"algorithmic_flops_per_launch": flops_alg, "achieved_TFLOPs": round(flops_alg / (avg_ms * 1e-3) / 1e12, 2),
-                                               "peak_TFLOPs_f32_vector": 157.3, "peak_TFLOPs_f32_vector_unpacked": 78.6,
-                                               "note": "157.3 TF is the packed (v_pk_fma_f32) figure of MI355X_MICROARCH.md; the sweep's scalar fp32 code can reach half of it"}
+                compulsory = (32 if args.float4_cache else 16) * B * K * npix + (32 * n_corr if fused else 0)       # every cached pixel and every correspondence once
+                hb.update({"hbm_traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1), "hbm_traffic_frac_of_peak": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "algorithmic_over_traffic": round(bytes_alg / traffic, 2), "traffic_over_compulsory": round(traffic / compulsory, 2),
+                           "source": pc.get("source_hbm")})
+            res["roofline"]["hbm_algorithmic"] = hb
             if world == 1:
                 copy_bw = measured_copy_bandwidth(torch, dev)
-                res["roofline"]["peak_measured_copy"] = round(copy_bw, 1)
-                res["roofline"]["frac_of_measured_copy"] = round(achieved / copy_bw, 4)
+                res["roofline"]["hbm_algorithmic"]["peak_measured_copy_GBps"] = round(copy_bw, 1)
             sweeps_ms = (st["ms_dense_sweep"] + st["ms_sparse_sweep"]) / args.steps
             res["kernels_ms_per_step"] = {
                 "sweeps": round(sweeps_ms, 4), "fused_sweeps": fused,            # fused: ONE launch per iteration carries both sweeps
@@ -293,7 +345,7 @@ def main():
             tb = time.perf_counter()
             res["single_instance"] = {"gn_iters_per_s": round(7 * reps / (tb - ta), 1), "ms_per_solve": round(1e3 * (tb - ta) / reps, 4)}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg, inst[0])
+            res["cpu_baseline"] = cpu_baseline(cfg, inst)
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -18,9 +18,10 @@ SRC_DIR = os.path.join(_PKG, "csrc")
 HEADER = os.path.join(_ROOT, "include", "btba.h")
 
 BTBA_OK, BTBA_EINVAL, BTBA_EHIP, BTBA_ENUMERIC, BTBA_ENOMEM = 0, 1, 2, 3, 4
-PAIRS_TARGET_LOWER, PAIRS_TARGET_MORE_VALID, PAIRS_EXPLICIT = 0, 1, 2
-FLAG_TRACE, FLAG_TIME_KERNELS, FLAG_PAIR_MAJOR = 1, 2, 4
-FLAG_DENSE_2PIX, FLAG_DENSE_4WAVE, FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_FUSE, FLAG_FLOAT4_CACHE, FLAG_NO_COMPACTION, FLAG_COMPACTION = 8, 16, 32, 64, 128, 256, 512, 1024
+PAIRS_TARGET_LOWER, PAIRS_TARGET_MORE_VALID, PAIRS_EXPLICIT, PAIRS_TARGET_HIGHER = 0, 1, 2, 3
+REDUCE_DETERMINISTIC, REDUCE_ATOMIC = 0, 1
+FLAG_TRACE, FLAG_TIME_KERNELS = 1, 2
+FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_FLOAT4_CACHE, FLAG_NO_COMPACTION, FLAG_COMPACTION = 32, 64, 256, 512, 1024
 
 ENTRYJ_DTYPE = np.dtype(
     [("imgIdx_i", "<u4"), ("imgIdx_j", "<u4"), ("pos_i", "<f4", (3,)), ("pos_j", "<f4", (3,))]
@@ -30,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "btba_params_default", "btba_strerror", "btba_last_hip_error", "btba_version",
     "btba_workspace_create", "btba_workspace_create_on_stream", "btba_workspace_destroy", "btba_workspace_sync",
     "btba_workspace_wait_stream", "btba_workspace_signal_stream",
-    "btba_optimize_frames", "btba_optimize_frames_keyed", "btba_frame_cache_clear", "btba_ransac_pairs", "btba_build_cache", "btba_solve_batch", "btba_collect_stats",
+    "btba_optimize_frames", "btba_optimize_frames_keyed", "btba_frame_cache_clear", "btba_frame_cache_evict", "btba_ransac_pairs", "btba_build_cache", "btba_solve_batch", "btba_solve_cached", "btba_collect_stats",
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
     "btba_process_depth", "btba_depth_to_normals",
@@ -44,7 +45,7 @@ class Params(C.Structure):
         ("robust_delta", C.c_float), ("dense_dist_thresh", C.c_float), ("dense_normal_thresh", C.c_float),
         ("depth_min", C.c_float), ("depth_max", C.c_float),
         ("weight_sparse", C.c_float), ("weight_dense_depth", C.c_float), ("image_downscale", C.c_float),
-        ("pair_policy", C.c_int32), ("dense_tiles", C.c_int32), ("sparse_chunks", C.c_int32), ("flags", C.c_int32),
+        ("pair_policy", C.c_int32), ("dense_tiles", C.c_int32), ("sparse_chunks", C.c_int32), ("flags", C.c_int32), ("reduction_mode", C.c_int32),
     ]
 
 
@@ -146,6 +147,10 @@ def lib() -> C.CDLL:
             C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_void_p,
             C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Stats)]
         L.btba_frame_cache_clear.argtypes = [C.c_void_p]
+        L.btba_frame_cache_evict.argtypes = [C.c_void_p, C.c_uint64]
+        L.btba_solve_cached.argtypes = [
+            C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_void_p,
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.btba_build_cache.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.btba_solve_batch.argtypes = [

@@ -201,11 +201,11 @@ class Bundler:
         forget_frame(frame)                -> None
     """
 
-    def __init__(self, optimizer, feature_manager, K, H, W, *, window_size=5, max_BA_frames=15, min_rot_deg=10.0,
+    def __init__(self, optimizer, feature_manager, K, H, W, *, window_size=2, max_BA_frames=15, min_rot_deg=10.0,
                  min_feat_num=0, min_fm_edges_newframe=5, pose_dir=None, persistent_frame_cache=False):
         self.opt, self.fm = optimizer, feature_manager
         self.K, self.H, self.W = np.asarray(K, np.float32), int(H), int(W)
-        self.window_size = int(window_size)                        # bundle.window_size
+        self.window_size = int(window_size)                        # bundle.window_size (config_ycbineoat.yml:26 ships 2)
         self.min_fm_edges_newframe = int(min_fm_edges_newframe)    # bundle.min_fm_edges_newframe
         self.memory = KeyframeMemory(min_rot_deg=min_rot_deg, min_feat_num=min_feat_num, max_BA_frames=max_BA_frames)
         self.frames: list = []                                     # _frames (deque)
@@ -255,11 +255,18 @@ class Bundler:
         if frame.status == "FAIL":
             self.fm.forget_frame(frame)
             self.frames.pop()
+            self._evict_cached(frame)                  # its id is handed out again to the next frame (last.id + 1)
             self.need_reinit = True
             return
         self.memory.check_and_add_keyframe(frame)
         if self.pose_dir is not None:
             self.save_newframe_result()
+
+    def _evict_cached(self, frame) -> None:
+        """A frame dropped after BA has cached it must not leave its (z, n) cache behind under an id the next frame reuses."""
+        if self.persistent_frame_cache and getattr(self.opt, "workspace", None) is not None:
+            from .optimizer import frame_cache_evict
+            frame_cache_evict(self.opt.workspace, frame.id)
 
     def optimize_gpu(self) -> None:
         """Bundler::optimizeGPU (:279-359): match every pair of the window, marshal, gate, optimise, write back."""

@@ -10,11 +10,11 @@
 
 namespace btba {
 
-OptimizerGpu::OptimizerGpu(std::shared_ptr<Config> yml1) : yml(std::move(yml1))
+OptimizerGpu::OptimizerGpu(std::shared_ptr<Config> yml1, void *hip_stream) : yml(std::move(yml1))
 {
     if (!yml) yml = std::make_shared<Config>();
-    const int rc = btba_workspace_create(&ws_, nullptr);
-    if (rc != BTBA_OK) throw Error(rc, "btba_workspace_create");
+    const int rc = btba_workspace_create_on_stream(&ws_, hip_stream);       // nullptr = the legacy NULL stream, as the reference
+    if (rc != BTBA_OK) throw Error(rc, "btba_workspace_create_on_stream");
 }
 
 OptimizerGpu::~OptimizerGpu() { btba_workspace_destroy(ws_); }
@@ -38,13 +38,16 @@ void OptimizerGpu::optimizeFrames(const std::vector<EntryJ> &global_corres, cons
     for (int i = 0; i < n_frames; i++) for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) P[16 * (size_t)i + 4 * r + c] = poses[i](r, c);
     std::vector<const float *> depth(n_frames), nrm(n_frames);
     for (int i = 0; i < n_frames; i++) { depth[i] = depths_gpu[i]; nrm[i] = reinterpret_cast<const float *>(normals_gpu[i]); }
+    // stored and never read by the reference (SBA.cpp:85): any length is legal there; only a vector of P = n(n-1)/2 segment
+    // lengths is handed on (it lets the library skip its host pass), anything else is ignored
+    const int *nm = ((long)n_match_per_pair.size() == (long)n_frames * (n_frames - 1) / 2) ? n_match_per_pair.data() : nullptr;
     int rc;
     if (persistent_frame_cache) {
         if ((int)frame_ids.size() != n_frames) throw Error(BTBA_EINVAL, "optimizeFrames: frame_ids");
-        rc = btba_optimize_frames_keyed(ws_, &prm, n_frames, H, W, Krm, global_corres.data(), (uint32_t)global_corres.size(), n_match_per_pair.data(),
+        rc = btba_optimize_frames_keyed(ws_, &prm, n_frames, H, W, Krm, global_corres.data(), (uint32_t)global_corres.size(), nm,
                                         depth.data(), nrm.data(), frame_ids.data(), nullptr, 0, P.data(), &last_stats);
     } else {
-        rc = btba_optimize_frames(ws_, &prm, n_frames, H, W, Krm, global_corres.data(), (uint32_t)global_corres.size(), n_match_per_pair.data(),
+        rc = btba_optimize_frames(ws_, &prm, n_frames, H, W, Krm, global_corres.data(), (uint32_t)global_corres.size(), nm,
                                   depth.data(), nrm.data(), nullptr, 0, P.data(), &last_stats);
     }
     if (rc != BTBA_OK) throw Error(rc, "btba_optimize_frames");

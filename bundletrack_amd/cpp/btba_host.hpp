@@ -65,8 +65,12 @@ public:
     bool persistent_frame_cache = false;         // hand frame ids to btba_optimize_frames_keyed (needs frame_ids below)
     std::vector<uint64_t> frame_ids;             // Frame::_id of every window frame, when persistent_frame_cache is set
 
-    explicit OptimizerGpu(std::shared_ptr<Config> yml1);
+    // The reference runs the whole path on the legacy NULL stream (no explicit streams anywhere in src/cuda), so the drop-in
+    // does too: depth / normal maps produced by earlier default-stream work are ordered before the cache build.  A caller with
+    // its own non-blocking producer stream passes it (the workspace then runs there) or orders with workspace().
+    explicit OptimizerGpu(std::shared_ptr<Config> yml1, void *hip_stream = nullptr);
     ~OptimizerGpu();
+    btba_workspace *workspace() const { return ws_; }      // btba_workspace_wait_stream / _signal_stream / _frame_cache_evict
     OptimizerGpu(const OptimizerGpu &) = delete;
     OptimizerGpu &operator=(const OptimizerGpu &) = delete;
 

@@ -113,6 +113,7 @@ void btba_params_default(btba_params *p)
     p->dense_tiles = 0;
     p->sparse_chunks = 0;
     p->flags = 0;
+    p->reduction_mode = BTBA_REDUCE_DETERMINISTIC;
 }
 
 const char *btba_strerror(int status)
@@ -331,6 +332,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
 {
     if (!ws || !prm || B < 1 || N < 2 || Hd < 2 || Wd < 2 || !intr || !poses) return BTBA_EINVAL;
     if (prm->n_gn_iters < 1 || prm->n_pcg_iters < 0) return BTBA_EINVAL;   // MLIB_ASSERT, CUDASolverBundling.cpp:194
+    if (prm->reduction_mode != BTBA_REDUCE_DETERMINISTIC) return BTBA_EINVAL;   // the reference's float atomics are not reproduced
     if (N > BTBA_MAX_FRAMES) return BTBA_EINVAL;                            // MAX_NUM_IMAGES of the reference (GlobalDefines.h:8) is 85 as well
     const int P = N * (N - 1) / 2;
     const bool use_sparse = prm->weight_sparse > 0.0f && corr && pair_offsets && max_corr_per_pair > 0;
@@ -402,7 +404,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;
     D.order_flag = order_flag;
-    D.tile_major = (prm->flags & BTBA_FLAG_PAIR_MAJOR) ? 0 : 1;
+    D.tile_major = std::getenv("BTBA_PAIR_MAJOR") ? 0 : 1;      // developer A/B only: (pair, band) instead of (band, pair) work order, same bits
     D.walk_blocks = (Wd % 8 == 0 && Hd % 8 == 0 && !std::getenv("BTBA_NO_BLOCK_WALK")) ? 1 : 0;
     D.n_gn = prm->n_gn_iters;
     int zn_layout = 0;
@@ -454,6 +456,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     S.bytes_dense_alg = use_dense ? (int64_t)64 * D.n_dense_pairs * npix * B : 0;
     S.bytes_sparse_alg = 0;   // filled by callers that know C (optimize_frames) or from offsets on request
 
+    {   // whether the two sweeps ride in one launch (same rule as in the loop below), reported whatever the timing flags
+        const int nb0 = (B >= 8 && (prm->flags & BTBA_FLAG_OVERLAP)) ? B / 2 : B;
+        S.fused_sweeps = (use_sparse && use_dense && (unsigned)chunks * P * nb0 >= 64u && (unsigned)tiles * D.n_dense_pairs * nb0 >= 64u && !(prm->flags & BTBA_FLAG_NO_FUSE)) ? 1 : 0;
+    }
     size_t reg;
     if ((rc = time_begin(ws, timing || ws->always_time_region, 3, &reg))) return rc;
     // Log, Exp, inverse of the incoming matrices
@@ -516,8 +522,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             // one interleaved launch of both sweeps: the dense workgroups are VALU-bound, the sparse ones stream HBM, and the
             // two fill each other's idle pipes -- measured at c3 (scripts/ab_dense.py, fused vs separate step time):
             // B=1 0.486 / 0.554 ms, B=8 0.871 / 0.950 ms, B=32 2.271 / 2.380 ms
-            const bool fuse = use_sparse && use_dense && n_s >= 64 && n_d >= 64 &&
-                              !(prm->flags & (BTBA_FLAG_NO_FUSE | BTBA_FLAG_DENSE_2PIX | BTBA_FLAG_DENSE_4WAVE));
+            const bool fuse = use_sparse && use_dense && n_s >= 64 && n_d >= 64 && !(prm->flags & BTBA_FLAG_NO_FUSE);
             if (fuse) {
                 // one launch: HBM-streaming sparse workgroups interleaved with the VALU-bound dense ones
                 if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
@@ -530,7 +535,6 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                 else k_fused_sweeps<4><<<dim3(n_d + n_s), kBlock, lut_bytes, H.st>>>(BTBA_FUSED_ARGS(zn_h));
 #undef BTBA_FUSED_ARGS
                 if ((rc = time_end(ws, slot, H.st))) return rc;
-                S.fused_sweeps = 1;
             } else {
                 if (use_sparse) {
                     if ((rc = time_begin(ws, timing, 1, &slot, H.st))) return rc;
@@ -545,9 +549,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                     else if (zn_layout == 2 && !compaction) k_dense_sweep_zn<false, false><<<dgrid, kBlock, lut_bytes, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
                     else if (zn_layout == 1) k_dense_sweep_zn<true, true><<<dgrid, kBlock, lut_bytes, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
                     else if (zn_layout == 2) k_dense_sweep_zn<false, true><<<dgrid, kBlock, lut_bytes, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
-                    else if (prm->flags & BTBA_FLAG_DENSE_2PIX) k_dense_sweep<2, 2><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
-                    else if (prm->flags & BTBA_FLAG_DENSE_4WAVE) k_dense_sweep<1, 4><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
-                    else k_dense_sweep<1, 3><<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
+                    else k_dense_sweep<<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
 #undef BTBA_DENSE_ARGS
                     if ((rc = time_end(ws, slot, H.st))) return rc;
                 }
@@ -617,6 +619,15 @@ int btba_solve_batch(btba_workspace *ws, const btba_params *params, int n_instan
                          pair_offsets_dev, max_corr_per_pair, dense_pairs, dense_pairs ? n_dense_pairs : -1, poses_dev, trace_dev);
 }
 
+int btba_solve_cached(btba_workspace *ws, const btba_params *params, int n_frames, int Hd, int Wd, const float *intr,
+                      const float *campos_dev, const float *normals_dev, const btba_entryj *corr_dev, uint32_t n_corr,
+                      const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
+                      float *poses_dev, float *trace_dev)
+{
+    return btba_solve_batch(ws, params, 1, n_frames, Hd, Wd, intr, campos_dev, normals_dev, corr_dev, (int64_t)(n_corr ? n_corr : 1), pair_offsets_dev,
+                            max_corr_per_pair, dense_pairs, n_dense_pairs, poses_dev, trace_dev);
+}
+
 static void scaled_intrinsics(int H, int W, int Hd, int Wd, const float *K, float intr[4], Mat4 *Kinv)
 {
     // CUDACache.cpp:20-24
@@ -667,6 +678,7 @@ int btba_build_cache(btba_workspace *ws, int n_frames, int H, int W, const float
     if (n_valid_dev) HIP_TRY(hipMemsetAsync(n_valid_dev, 0, sizeof(int32_t) * n_frames, ws->stream));
     const int npix = Wd * Hd;
     size_t slot;
+    if (ws->events.size() > 4096) { for (auto &ep : ws->events) { ws->event_pool.push_back(ep.a); ws->event_pool.push_back(ep.b); } ws->events.clear(); }     // callers that never collect
     if ((rc = time_begin(ws, true, 4, &slot))) return rc;
     k_build_cache<<<dim3((npix + kBlock - 1) / kBlock, n_frames), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, Kinv, ws->ptrs.as<const float *>(), ws->ptrs.as<const float *>() + n_frames,
                                                                                          reinterpret_cast<float4 *>(campos_dev), reinterpret_cast<float4 *>(normals_dev), n_valid_dev);
@@ -691,7 +703,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     if (prm.pair_policy == BTBA_PAIRS_EXPLICIT && (!dense_pairs || n_dense_pairs < 0)) return BTBA_EINVAL;
     btba_workspace *ws = ws_in;
     int rc = BTBA_OK;
-    if (!ws) { if ((rc = btba_workspace_create(&ws, nullptr))) return rc; }
+    if (!ws) { if ((rc = btba_workspace_create_on_stream(&ws, nullptr))) return rc; }       // the reference's stream: the legacy NULL stream
     auto finish = [&](int code) { if (!ws_in) btba_workspace_destroy(ws); return code; };
     for (auto &ep : ws->events) { ws->event_pool.push_back(ep.a); ws->event_pool.push_back(ep.b); }
     ws->events.clear();
@@ -794,6 +806,9 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
                 else { pairs.push_back(j); pairs.push_back(i); }
             }
         pairs_ptr = pairs.data(); n_pairs_dense = (int)pairs.size() / 2;
+    } else if (prm.pair_policy == BTBA_PAIRS_TARGET_HIGHER) {
+        for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) { pairs.push_back(j); pairs.push_back(i); }      // target = j, source = i
+        pairs_ptr = pairs.data(); n_pairs_dense = (int)pairs.size() / 2;
     } else if (prm.pair_policy != BTBA_PAIRS_TARGET_LOWER) {
         return finish(BTBA_EINVAL);
     }
@@ -880,6 +895,13 @@ int btba_frame_cache_clear(btba_workspace *ws)
 {
     if (!ws) return BTBA_EINVAL;
     for (auto &sl : ws->pool_slots) sl = btba_workspace::FrameSlot{};
+    return BTBA_OK;
+}
+
+int btba_frame_cache_evict(btba_workspace *ws, uint64_t frame_key)
+{
+    if (!ws) return BTBA_EINVAL;
+    for (auto &sl : ws->pool_slots) if (sl.live && sl.key == frame_key) sl = btba_workspace::FrameSlot{};
     return BTBA_OK;
 }
 
@@ -1030,6 +1052,7 @@ int btba_build_cache_zn(btba_workspace *ws, int n_frames, int H, int W, const fl
     if (n_valid_dev) HIP_TRY(hipMemsetAsync(n_valid_dev, 0, sizeof(int32_t) * n_frames, ws->stream));
     const int npix = Wd * Hd;
     size_t slot;
+    if (ws->events.size() > 4096) { for (auto &ep : ws->events) { ws->event_pool.push_back(ep.a); ws->event_pool.push_back(ep.b); } ws->events.clear(); }
     if ((rc = time_begin(ws, true, 4, &slot))) return rc;
     k_build_cache_zn<<<dim3((npix + kBlock - 1) / kBlock, n_frames), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, ws->ptrs.as<const float *>(), ws->ptrs.as<const float *>() + n_frames,
                                                                                             reinterpret_cast<float4 *>(zn_dev), n_valid_dev, nullptr);

@@ -439,7 +439,6 @@ __device__ __forceinline__ void pixel_accumulate(const DenseCtx &C, const PixelG
 // 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).  Lane = consecutive source pixel (coalesced
 // float4 loads of the source camPos / normal); two pixels per lane per trip, sixteen target-tap gathers in
 // flight; the taps stay in L1/L2 because neighbouring source pixels project to neighbouring target pixels.
-template <int PIX>
 __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__restrict__ campos, const float4 *__restrict__ normals,
                                             const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
                                             float *__restrict__ partials, int tile, int p, int b, float *red)
@@ -461,23 +460,7 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
 #pragma unroll
     for (int k = 0; k < kDenseVals; k++) acc[k] = 0.0f;
 
-    if (PIX == 2) {
-        for (int s = lo + (int)threadIdx.x; s < hi; s += 2 * kBlock) {
-            const int s2 = s + kBlock;
-            const bool in2 = s2 < hi;
-            const int s2c = in2 ? s2 : s;
-            const float4 csA = cam_s[s], nsA = nrm_s[s], csB = cam_s[s2c], nsB = nrm_s[s2c];
-            const PixelGeom gA = pixel_geom(C, csA, nsA);
-            PixelGeom gB = pixel_geom(C, csB, nsB);
-            gB.valid = gB.valid && in2;
-            const float4 cA00 = C.cam_t[gA.i00], cA10 = C.cam_t[gA.i10], cA01 = C.cam_t[gA.i01], cA11 = C.cam_t[gA.i11];
-            const float4 nA00 = C.nrm_t[gA.i00], nA10 = C.nrm_t[gA.i10], nA01 = C.nrm_t[gA.i01], nA11 = C.nrm_t[gA.i11];
-            const float4 cB00 = C.cam_t[gB.i00], cB10 = C.cam_t[gB.i10], cB01 = C.cam_t[gB.i01], cB11 = C.cam_t[gB.i11];
-            const float4 nB00 = C.nrm_t[gB.i00], nB10 = C.nrm_t[gB.i10], nB01 = C.nrm_t[gB.i01], nB11 = C.nrm_t[gB.i11];
-            pixel_accumulate(C, gA, cA00, cA10, cA01, cA11, nA00, nA10, nA01, nA11, acc);
-            pixel_accumulate(C, gB, cB00, cB10, cB01, cB11, nB00, nB10, nB01, nB11, acc);
-        }
-    } else {
+    {
         int s = lo + (int)threadIdx.x;
         float4 cs_n = make_float4(0.f, 0.f, 0.f, 0.f), ns_n = cs_n;
         if (s < hi) { cs_n = cam_s[s]; ns_n = nrm_s[s]; }
@@ -881,12 +864,15 @@ __global__ void __launch_bounds__(kBlock, 5) k_dense_sweep_zn(SolveDims D, const
     const int tile = (int)(L % (unsigned)D.dense_tiles);
     const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
     const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
-    dense_block_zn<SIMPLE, LISTS>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+    // pinhole intrinsics: the same block as in the fused launch (same partial sums, bit for bit)
+    if (SIMPLE && LISTS) dense_block_pinhole<1>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+    else if (SIMPLE && D.walk_blocks) dense_block_pinhole<2>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+    else if (SIMPLE) dense_block_pinhole<0>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+    else dense_block_zn<false, LISTS>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
 }
 
 // 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).
-template <int PIX, int WAVES>
-__global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, const float4 *__restrict__ campos, const float4 *__restrict__ normals,
+__global__ void __launch_bounds__(kBlock, 3) k_dense_sweep(SolveDims D, const float4 *__restrict__ campos, const float4 *__restrict__ normals,
                                                               const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
                                                               float *__restrict__ partials)
 {
@@ -895,7 +881,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) k_dense_sweep(SolveDims D, cons
     const int tile = (int)(L % (unsigned)D.dense_tiles);
     const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
     const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
-    dense_block<PIX>(D, campos, normals, dense_pairs, T, Tinv, partials, tile, p, b, red);
+    dense_block(D, campos, normals, dense_pairs, T, Tinv, partials, tile, p, b, red);
 }
 
 // Both sweeps of one Gauss-Newton iteration in ONE launch: n_d dense workgroups (VALU-bound) interleaved with
@@ -936,7 +922,7 @@ __global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_fused_sweeps(Solve
         const unsigned Lb = L - (unsigned)b * (unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs;
         const int tile = D.tile_major ? (int)(Lb / (unsigned)D.n_dense_pairs) : (int)(Lb % (unsigned)D.dense_tiles);
         const int p = D.tile_major ? (int)(Lb % (unsigned)D.n_dense_pairs) : (int)(Lb / (unsigned)D.dense_tiles);
-        if (LAYOUT == 0) dense_block<1>(D, campos, normals, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
+        if (LAYOUT == 0) dense_block(D, campos, normals, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
         else if (LAYOUT == 1 && D.walk_blocks) dense_block_pinhole<2>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
         else if (LAYOUT == 1) dense_block_pinhole<0>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);     // `campos` carries the compact cache
         else if (LAYOUT == 2) dense_block_zn<false, false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);

@@ -132,7 +132,9 @@ class OptimizerGpu:
             if d.numel() != H * W or n.numel() != 4 * H * W:
                 raise ValueError("depth must hold H*W floats and normals H*W float4")
         Kf = np.ascontiguousarray(K, np.float32).reshape(9)
-        nm = None if n_match_per_pair is None else np.ascontiguousarray(n_match_per_pair, np.int32)
+        nm = None if n_match_per_pair is None else np.ascontiguousarray(n_match_per_pair, np.int32).reshape(-1)
+        if nm is not None and nm.shape[0] != n_frames * (n_frames - 1) // 2:
+            nm = None         # the reference stores this vector and never reads it (SBA.cpp:85): any other length is legal there and is ignored here
         P = np.ascontiguousarray(poses, np.float32).reshape(n_frames, 16).copy()
         dp = None
         if dense_pairs is not None:
@@ -154,8 +156,21 @@ class OptimizerGpu:
             rc = lib().btba_optimize_frames_keyed(*head, keys.ctypes.data, *tail)
         check(rc, "btba_optimize_frames")
         self.last_stats = st.as_dict()
-        np.asarray(poses)[...] = P.reshape(n_frames, 4, 4)
+        out = P.reshape(n_frames, 4, 4)
+        if isinstance(poses, np.ndarray):
+            poses[...] = out.reshape(poses.shape)          # the reference's in/out `poses&`
+        else:                                              # a list of 4x4 arrays (std::vector<Eigen::Matrix4f> in the reference): update each element
+            for k in range(n_frames):
+                if isinstance(poses[k], np.ndarray):
+                    poses[k][...] = out[k]
+                else:
+                    poses[k] = out[k].copy()
         return poses
+
+
+def frame_cache_evict(ws: Workspace, key: int) -> None:
+    """Forget one frame kept under `key` (a tracker that drops a frame and may reuse its id)."""
+    check(lib().btba_frame_cache_evict(ws.handle, C.c_uint64(int(key))), "btba_frame_cache_evict")
 
 
 def frame_cache_clear(ws: Workspace) -> None:

@@ -56,19 +56,26 @@ enum {
     BTBA_PAIRS_TARGET_LOWER      = 0,  /* every i<j once, target = i (BundleFusion behaviour; default) */
     BTBA_PAIRS_TARGET_MORE_VALID = 1,  /* target = frame with more valid depth pixels, ties i<j; literal
                                           FlipJtJ semantics: the cross block vanishes when target > source */
-    BTBA_PAIRS_EXPLICIT          = 2   /* caller passes the ordered (target, source) list */
+    BTBA_PAIRS_EXPLICIT          = 2,  /* caller passes the ordered (target, source) list */
+    BTBA_PAIRS_TARGET_HIGHER     = 3   /* every i<j once, target = j: what FindImageImageCorr_Kernel emits when the per-frame
+                                          d_num_valid_points allocations have ASCENDING addresses in frame order (one cudaMalloc per
+                                          frame in a fresh CUDACache, CUDACacheUtil.h:14) -- every dense cross block is then above
+                                          the diagonal and erased by FlipJtJ_Kernel (SolverBundling.cu:49-59) */
+};
+
+/* Reduction order of the sweeps' partial sums.  The reference adds with float atomics in whatever order the hardware
+ * serialises them (SolverBundlingDenseUtil.h:217-285); only the fixed-order, run-to-run reproducible tree is implemented. */
+enum {
+    BTBA_REDUCE_DETERMINISTIC = 0,
+    BTBA_REDUCE_ATOMIC        = 1   /* reserved: BTBA_EINVAL */
 };
 
 enum {
     BTBA_FLAG_TRACE         = 1,    /* record per-GN-iterate trace (btba_trace_layout)                            */
     BTBA_FLAG_TIME_KERNELS  = 2,    /* bracket every sweep / solve launch with hipEvents (btba_stats)             */
-    BTBA_FLAG_PAIR_MAJOR    = 4,    /* tuning / A-B: fused dense work ordered (pair, tile) inside an instance; default (tile, pair) */
-    BTBA_FLAG_DENSE_2PIX    = 8,    /* tuning, reference-layout cache only: dense sweep with two pixels per lane per trip */
-    BTBA_FLAG_DENSE_4WAVE   = 16,   /* tuning, reference-layout cache only: registers capped for 4 waves per SIMD */
     BTBA_FLAG_OVERLAP       = 32,   /* split a batch over two streams (main + low-priority) so one half's k_system_solve
                                        overlaps the other half's sweeps; per-kernel timings then overlap too (+4 % at c3 x 32) */
     BTBA_FLAG_NO_FUSE       = 64,   /* launch the sparse and the dense sweep separately (default: ONE interleaved launch) */
-    BTBA_FLAG_FUSE          = 128,  /* accepted for compatibility: fusing is the default whenever both sweeps run  */
     BTBA_FLAG_FLOAT4_CACHE  = 256,  /* btba_optimize_frames: build the reference-layout float4 cache instead of the compact one */
     BTBA_FLAG_NO_COMPACTION = 512,  /* compact cache: always walk all Wd x Hd source pixels                        */
     BTBA_FLAG_COMPACTION    = 1024  /* compact cache: walk each source frame's ordered list of pixels that carry a depth
@@ -94,6 +101,7 @@ typedef struct btba_params {
     int32_t dense_tiles;          /* workgroups per dense frame pair (0 = auto)                        */
     int32_t sparse_chunks;        /* workgroups per correspondence segment (0 = auto)                  */
     int32_t flags;                /* BTBA_FLAG_*                                                        */
+    int32_t reduction_mode;       /* BTBA_REDUCE_* (deterministic only)                                 */
 } btba_params;
 
 /* Timing / diagnostics filled by the solve entry points (all times in milliseconds, measured
@@ -150,7 +158,8 @@ BTBA_API int btba_last_hip_error(void);
 BTBA_API int btba_version(void);
 
 /* One workspace = one HIP stream + reusable device scratch.  `stream` may be NULL (the
- * workspace then creates and owns a non-blocking stream).  Re-entrant across workspaces. */
+ * workspace then creates and owns a non-blocking stream: the caller orders it against its own streams with
+ * btba_workspace_wait_stream / _signal_stream).  Re-entrant across workspaces. */
 BTBA_API int btba_workspace_create(btba_workspace **out, void *stream);
 /* Same, but `stream` is used as given even when it is the NULL (legacy default) stream -- what a framework whose
  * "current stream" is the default stream (PyTorch) needs so that its own copies and kernels order with the solver. */
@@ -178,7 +187,12 @@ BTBA_API int btba_workspace_signal_stream(btba_workspace *ws, void *stream);
  *   poses_rowmajor    : host float[n_frames*16], camera->model, in/out  (LossGPU.cu:88-97,121-130)
  *   K_rowmajor        : host float[9] full-resolution intrinsics
  *   dense_pairs       : BTBA_PAIRS_EXPLICIT only: n_dense_pairs (target, source) int32 pairs, host.
- * ws may be NULL: like the reference, everything is then allocated and freed inside the call.
+ * ws may be NULL: like the reference, everything is then allocated and freed inside the call, and the call runs on the
+ * legacy NULL stream like the reference does -- depth / normal maps produced by earlier work on the default stream (or by
+ * any blocking stream) are ordered before the cache build without the caller doing anything.  A caller that passes NULL
+ * only for some calls must not race them against its own non-blocking streams.
+ * n_match_per_pair must hold P = n_frames (n_frames - 1) / 2 ints when non-NULL (the host wrappers pass NULL when the
+ * caller's vector has another length).
  * Synchronous: poses are valid on return. */
 BTBA_API int btba_optimize_frames(btba_workspace *ws, const btba_params *params,
                          int n_frames, int H, int W, const float *K_rowmajor,
@@ -203,6 +217,9 @@ BTBA_API int btba_optimize_frames_keyed(btba_workspace *ws, const btba_params *p
                          const int32_t *dense_pairs, int n_dense_pairs,
                          float *poses_rowmajor, btba_stats *stats);
 BTBA_API int btba_frame_cache_clear(btba_workspace *ws);
+/* Forget ONE cached frame (a tracker dropping a frame whose id it may hand out again, Bundler.cpp:96-104: a failed frame is
+ * popped and the next one gets the same id).  Unknown keys are not an error. */
+BTBA_API int btba_frame_cache_evict(btba_workspace *ws, uint64_t frame_key);
 
 /* Frame cache build alone (CUDACache::CUDACache + storeFrame, CUDACache.cpp:14-38,76-88).
  * Outputs (device): campos float4[n_frames][Hd*Wd], normals float4[n_frames][Hd*Wd],
@@ -228,6 +245,14 @@ BTBA_API int btba_solve_batch(btba_workspace *ws, const btba_params *params,
                      int n_instances, int n_frames, int Hd, int Wd, const float *intr,
                      const float *campos_dev, const float *normals_dev,
                      const btba_entryj *corr_dev, int64_t corr_stride,
+                     const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair,
+                     const int32_t *dense_pairs, int n_dense_pairs,
+                     float *poses_dev, float *trace_dev);
+/* SURVEY.md 8(b)'s single-instance cached entry (one tracker, frame cache already built by btba_build_cache): the same
+ * solve as btba_solve_batch with n_instances = 1 and corr_stride = n_corr. */
+BTBA_API int btba_solve_cached(btba_workspace *ws, const btba_params *params, int n_frames, int Hd, int Wd, const float *intr,
+                     const float *campos_dev, const float *normals_dev,
+                     const btba_entryj *corr_dev, uint32_t n_corr,
                      const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair,
                      const int32_t *dense_pairs, int n_dense_pairs,
                      float *poses_dev, float *trace_dev);

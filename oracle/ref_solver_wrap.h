@@ -11,16 +11,23 @@
 
 static float4x4 rs_load4(const float *m) { float4x4 M; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) M(r, c) = m[4 * r + c]; return M; }
 
+// addr_rank (may be NULL): a permutation of 0 .. N-1 giving the ORDER of the frames' d_num_valid_points addresses -- frame k's
+// pointer is &nvalid[addr_rank[k]], so frame a's address is above frame b's iff addr_rank[a] > addr_rank[b].
+// FindImageImageCorr_Kernel (SolverBundling.cu:17-47) keeps the ordered pair (i, j) = (target, source) iff address_i > address_j:
+// NULL = descending addresses in frame order (target = lower index, BTBA_PAIRS_TARGET_LOWER); addr_rank[k] = k is what one
+// cudaMalloc per frame in a fresh CUDACache typically yields (ascending: target = higher index, every dense cross block written
+// above the diagonal and erased by FlipJtJ_Kernel, :49-59 -- BTBA_PAIRS_TARGET_HIGHER); any other permutation gives the
+// corresponding explicit orientation (BTBA_PAIRS_TARGET_MORE_VALID, BTBA_PAIRS_EXPLICIT).
 extern "C" __attribute__((visibility("default")))
-int ref_solve(int N, int Wd, int Hd, const float *intr, const float *campos, const float *normals, const float *corr_in, int C,
-              float *poses_io /* [N][16] row-major, camera -> model */, int n_gn, int n_pcg, float w_sparse, float w_dense, float robust_delta,
-              float dist_thresh, float normal_thresh, float depth_min, float depth_max, float *x_out /* [N][6] rot, trans; may be NULL */)
+int ref_solve2(int N, int Wd, int Hd, const float *intr, const float *campos, const float *normals, const float *corr_in, int C,
+               float *poses_io /* [N][16] row-major, camera -> model */, int n_gn, int n_pcg, float w_sparse, float w_dense, float robust_delta,
+               float dist_thresh, float normal_thresh, float depth_min, float depth_max, float *x_out /* [N][6] rot, trans; may be NULL */,
+               const int *addr_rank)
 {
     const size_t npix = (size_t)Wd * Hd;
     const unsigned maxCorrPerImage = C > 0 ? (unsigned)C : 1u, maxPairs = (unsigned)(N * (N - 1) / 2 > 0 ? N * (N - 1) / 2 : 1);
     // frames: CUDACachedFrame[] with the float4 camPos / normal maps; the orientation of a dense pair is decided by comparing the
-    // frames' d_num_valid_points POINTERS (FindImageImageCorr_Kernel, SolverBundling.cu:25-33), so they are laid out in descending
-    // address order: target = the lower frame index, like the GPU run the oracle models (pair policy TARGET_LOWER)
+    // frames' d_num_valid_points POINTERS (FindImageImageCorr_Kernel, SolverBundling.cu:25-33): addr_rank chooses their order
     std::vector<CUDACachedFrame> frames(N);
     std::vector<int> nvalid(N, 0);
     std::vector<float> depth(npix * N);
@@ -30,7 +37,7 @@ int ref_solve(int N, int Wd, int Hd, const float *intr, const float *campos, con
         frames[k].d_normalsDownsampled = const_cast<float4 *>(reinterpret_cast<const float4 *>(normals) + k * npix);
         for (size_t q = 0; q < npix; q++) depth[k * npix + q] = campos[4 * (k * npix + q) + 2];
         frames[k].d_depthDownsampled = depth.data() + k * npix;
-        frames[k].d_num_valid_points = &nvalid[N - 1 - k];
+        frames[k].d_num_valid_points = &nvalid[addr_rank ? addr_rank[k] : N - 1 - k];
     }
     std::vector<EntryJ> corr(C > 0 ? C : 1);
     if (C > 0) memcpy(corr.data(), corr_in, sizeof(EntryJ) * (size_t)C);
@@ -83,4 +90,13 @@ int ref_solve(int N, int Wd, int Hd, const float *intr, const float *campos, con
                         st.d_corrCountColor, st.d_sumResidualColor };
     for (void *q : to_free) free(q);
     return 0;
+}
+
+extern "C" __attribute__((visibility("default")))
+int ref_solve(int N, int Wd, int Hd, const float *intr, const float *campos, const float *normals, const float *corr_in, int C,
+              float *poses_io, int n_gn, int n_pcg, float w_sparse, float w_dense, float robust_delta,
+              float dist_thresh, float normal_thresh, float depth_min, float depth_max, float *x_out)
+{
+    return ref_solve2(N, Wd, Hd, intr, campos, normals, corr_in, C, poses_io, n_gn, n_pcg, w_sparse, w_dense, robust_delta, dist_thresh, normal_thresh,
+                      depth_min, depth_max, x_out, nullptr);
 }

@@ -173,19 +173,27 @@ def lib_solver() -> C.CDLL:
 
 
 def solve(campos, normals, intr, corr, poses, n_gn=7, n_pcg=5, weight_sparse=1.0, weight_dense=1.0, robust_delta=0.005,
-          dist_thresh=0.02, normal_thresh=float(np.cos(np.pi / 4)), depth_min=0.1, depth_max=9999.0):
+          dist_thresh=0.02, normal_thresh=float(np.cos(np.pi / 4)), depth_min=0.1, depth_max=9999.0, addr_rank=None):
     """solveBundlingStub (SolverBundling.cu:931-1003) and everything under it, run by the reference's own code.
-    Returns (poses [N,4,4] after n_gn Gauss-Newton iterations, x [N,6] = (rot, trans))."""
+    Returns (poses [N,4,4] after n_gn Gauss-Newton iterations, x [N,6] = (rot, trans)).
+    addr_rank: permutation of 0..N-1 ordering the frames' d_num_valid_points ADDRESSES, which is what orients the dense pairs in
+    the reference (FindImageImageCorr_Kernel keeps (target i, source j) iff address_i > address_j): None = descending in frame
+    order (target = lower index), np.arange(N) = ascending (target = higher index, cross blocks erased by FlipJtJ)."""
     campos, normals = _f(campos, normals)
     N, Hd, Wd = campos.shape[:3]
     (intr,) = _f(intr)
     corr = np.ascontiguousarray(corr)
     P = np.ascontiguousarray(poses, np.float32).reshape(N, 16).copy()
     x = np.zeros((N, 6), np.float32)
-    f = lib_solver().ref_solve
-    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 7 + [C.c_void_p]
+    f = lib_solver().ref_solve2
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 7 + [C.c_void_p, C.c_void_p]
+    rank = None
+    if addr_rank is not None:
+        rank = np.ascontiguousarray(addr_rank, np.int32)
+        if sorted(rank.tolist()) != list(range(N)):
+            raise ValueError("addr_rank must be a permutation of 0..N-1")
     f(N, Wd, Hd, _p(intr), _p(campos), _p(normals), _p(corr), len(corr), _p(P), n_gn, n_pcg, weight_sparse, weight_dense, robust_delta,
-      dist_thresh, normal_thresh, depth_min, depth_max, _p(x))
+      dist_thresh, normal_thresh, depth_min, depth_max, _p(x), _p(rank) if rank is not None else None)
     return P.reshape(N, 4, 4), x
 
 
@@ -231,3 +239,11 @@ def depth_to_normals(depth, Kinv4):
     f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     f(W, H, _p(Kinv4), _p(depth), _p(nrm), _p(xyz))
     return nrm, xyz
+
+
+def pairs_from_addr_rank(addr_rank):
+    """The ordered (target, source) list FindImageImageCorr_Kernel emits for a given address order: (i, j) iff rank_i > rank_j,
+    listed in canonical pair order (the reference's own list order is whatever its atomicAdd hands out)."""
+    r = list(addr_rank)
+    N = len(r)
+    return np.array([(i, j) if r[i] > r[j] else (j, i) for i in range(N) for j in range(i + 1, N)], np.int32)

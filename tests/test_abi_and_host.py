@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_header():
-    assert C.sizeof(_lib.Params) == 14 * 4
+    assert C.sizeof(_lib.Params) == 15 * 4
     assert _lib.ENTRYJ_DTYPE.itemsize == 32          # struct EntryJ, SIFTImageManager.h:44-59
     L = _lib.TraceLayout()
     _lib.lib().btba_trace_layout_get(15, 105, 5, C.byref(L))

@@ -44,6 +44,60 @@ def test_hip_matches_the_reference_solver(name, K, m, wd, seed, bg):
     assert worst < 1e-4, worst
 
 
+def test_c4_matches_the_reference_solver():
+    """BASELINE configs[3] at full size (K = 30, 4 000 correspondences per pair, 60-keyframe pool pruned to 30) directly against
+    the reference's own solver (about 40 s of thread-by-thread emulation), not only through the oracle."""
+    pb = S.make_problem(30, 4000, S.config_seed(4), background=True, full_res=False, angles=S.pruned_pool_angles(60, 30, S.config_seed(4)))
+    campos, normals, intr = S.analytic_cache(pb)
+    ref, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, weight_dense=1.0)
+    got = hip_solve(pb, 1.0)
+    worst = max(max(S.pose_error(got[k], ref[k])) for k in range(30))
+    print(f"c4: HIP vs the reference's own solver: worst pose difference {worst:.2e}")
+    assert worst < 1e-4, worst
+
+
+@pytest.mark.parametrize("policy", ["TARGET_HIGHER", "TARGET_MORE_VALID", "EXPLICIT"])
+def test_pair_orientation_policies_against_the_reference_address_compare(policy):
+    """The reference orients a dense pair by comparing the ADDRESSES of the frames' d_num_valid_points allocations
+    (FindImageImageCorr_Kernel, SolverBundling.cu:17-47) and FlipJtJ_Kernel (:49-59) then erases the cross block of every pair
+    whose target index is above its source index.  oracle/_ref runs exactly that code with the addresses laid out in a chosen
+    order; the boundary's pair policies must reproduce it: ascending addresses = TARGET_HIGHER, addresses ordered by valid-pixel
+    count = TARGET_MORE_VALID, an arbitrary order = an EXPLICIT list."""
+    import torch
+    from bundletrack_amd import _lib
+    from bundletrack_amd.optimizer import OptimizerGpu, Workspace
+    dev = torch.device("cuda:0")
+    # frames masked to the object with DIFFERENT valid-pixel counts (orbit + distinct semi-axes), so MORE_VALID is a real permutation
+    pb = S.make_problem(5, 300, seed=41, background=False)
+    N = pb.n_frames
+    from oracle import oracle as O            # only for the reference-ordered cache (checked bit-exact elsewhere)
+    caches = [O.build_cache(pb.depth[k], pb.normals[k], pb.K) for k in range(N)]
+    campos, normals, intr = np.stack([c["campos"] for c in caches]), np.stack([c["normals"] for c in caches]), caches[0]["intr"]
+    nvalid = np.array([int((c["campos"][..., 3] == 1).sum()) for c in caches])
+    if policy == "TARGET_HIGHER":
+        rank = np.arange(N)
+        kw = dict(pair_policy=_lib.PAIRS_TARGET_HIGHER); pairs = None
+    elif policy == "TARGET_MORE_VALID":
+        assert len(set(nvalid.tolist())) > 2, nvalid
+        order = sorted(range(N), key=lambda k: (nvalid[k], -k))        # ascending count; ties: the lower index counts as "more valid" (i < j kept)
+        rank = np.empty(N, np.int64); rank[order] = np.arange(N)
+        kw = dict(pair_policy=_lib.PAIRS_TARGET_MORE_VALID); pairs = None
+    else:
+        rank = np.array([3, 0, 4, 1, 2])
+        kw = dict(pair_policy=_lib.PAIRS_EXPLICIT); pairs = R.pairs_from_addr_rank(rank)
+    ref, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, addr_rank=rank)
+    ref_lower, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init)
+    assert max(max(S.pose_error(ref[k], ref_lower[k])) for k in range(N)) > 3e-4      # the orientation matters on this window
+    opt = OptimizerGpu(workspace=Workspace(), **kw)
+    d = [torch.from_numpy(pb.depth[k]).to(dev) for k in range(N)]
+    n = [torch.from_numpy(pb.normals[k]).to(dev) for k in range(N)]
+    poses = pb.poses_init.copy()
+    opt.optimizeFrames(pb.corr, pb.n_match_per_pair, N, pb.H, pb.W, d, None, n, poses, pb.K, dense_pairs=pairs)
+    worst = max(max(S.pose_error(poses[k], ref[k])) for k in range(N))
+    print(f"{policy}: HIP vs the reference run with address order {rank.tolist()}: worst pose difference {worst:.2e}")
+    assert worst < 1e-4, worst
+
+
 def test_large_window_matches_the_reference_solver():
     """40 frames (above BTBA_MAX_FRAMES_LDS = 31: matrix in the global scratch, 16-wave PCG) on 32 x 24 caches against the
     reference's own solver, whose limit is MAX_NUM_IMAGES = 85."""

@@ -211,6 +211,26 @@ def _kinv4(oracle, K):
     return oracle.mat4_inverse(K4)
 
 
+@pytest.mark.parametrize("rank", [None, [0, 1, 2, 3, 4], [3, 0, 4, 1, 2]])
+def test_pair_orientation_follows_the_reference_address_compare(oracle, rank):
+    """FindImageImageCorr_Kernel keeps (target i, source j) iff the address of frame i's d_num_valid_points is above frame j's
+    (SolverBundling.cu:25-33) and FlipJtJ_Kernel erases the cross blocks written above the diagonal (:49-59).  The reference's own
+    code, run with the addresses in descending / ascending / arbitrary order, against the oracle given the corresponding explicit
+    (target, source) list: the oracle's flip semantics are the reference's."""
+    pb = S.make_problem(5, 300, seed=41, background=False)
+    N = pb.n_frames
+    caches = [oracle.build_cache(pb.depth[k], pb.normals[k], pb.K) for k in range(N)]
+    campos, normals, intr = np.stack([c["campos"] for c in caches]), np.stack([c["normals"] for c in caches]), caches[0]["intr"]
+    ref, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, addr_rank=rank)
+    pairs = R.pairs_from_addr_rank(rank if rank is not None else list(range(N))[::-1])
+    got = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, pairs=pairs, want_trace=False).poses
+    worst = max(max(S.pose_error(got[k], ref[k])) for k in range(N))
+    assert worst < 1e-5, worst
+    if rank is not None:
+        lower = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, want_trace=False).poses
+        assert max(max(S.pose_error(lower[k], ref[k])) for k in range(N)) > 3e-4       # a different orientation is a different problem
+
+
 def test_frame_cache_matches_reference_kernels(oracle):
     """CUDACache::storeFrame = convertDepthFloatToCameraSpaceFloat4 + resampleFloat4 x2 + resampleFloat + countNumValidDepth
     (CUDACache.cpp:76-88), run by the reference's kernels, against orc_build_cache: bit for bit, masked and full frames,
