@@ -672,6 +672,29 @@ static void apply_JTJ_dense(int k, int N, const float *JtJ, const float *pRot, c
  * intr = (fx, fy, cx, cy) downscaled, corr: C EntryJ (copied; overflow may invalidate),
  * pairs: P ordered (target, source) dense pairs, poses: [N][16] row-major in/out
  * (SBA::align, SBA.cpp:106-115: Log before, Exp after).  Returns 0 on success. */
+/* Many independent instances at once, one single-threaded solve per OpenMP thread (bench.py's all-core CPU baseline: the
+ * c5 configuration shards instances, so the CPU gets the same parallelisation).  Job j solves instance j % B from a private copy of
+ * its poses; results are discarded, the return value is the number of solves completed. */
+ORC_API int orc_solve(const orc_params *prm, int N, int Wd, int Hd, const float *intr, const float *campos, const float *normals,
+                      const orc_entryj *corr_in, int C, const int32_t *pairs, int P, float *poses, orc_trace *tr);
+ORC_API int orc_solve_jobs(const orc_params *prm_in, int n_jobs, int n_workers, int B, int N, int Wd, int Hd, const float *intr,
+                           const float *const *campos, const float *const *normals, const orc_entryj *const *corr, const int32_t *C,
+                           const int32_t *pairs, int P, const float *const *poses)
+{
+    int done = 0;
+    orc_params prm = *prm_in;
+    prm.n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_workers > 0 ? n_workers : 1) reduction(+ : done)
+    for (int j = 0; j < n_jobs; j++) {
+        const int b = j % B;
+        float *p = (float *)malloc(sizeof(float) * 16 * (size_t)N);
+        memcpy(p, poses[b], sizeof(float) * 16 * (size_t)N);
+        if (orc_solve(&prm, N, Wd, Hd, intr + 4 * b, campos[b], normals[b], corr[b], C[b], pairs, P, p, NULL) == 0) done++;
+        free(p);
+    }
+    return done;
+}
+
 ORC_API int orc_solve(const orc_params *prm, int N, int Wd, int Hd, const float *intr,
                       const float *campos, const float *normals,
                       const orc_entryj *corr_in, int C,

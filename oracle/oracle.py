@@ -213,6 +213,25 @@ def solve(campos, normals, intr, corr, poses, pairs=None, params: OrcParams | No
     return t
 
 
+def solve_jobs(instances, n_jobs, n_workers, params: OrcParams | None = None) -> int:
+    """n_jobs whole solves over `instances` (dicts with campos, normals, intr, corr, poses; job j takes instance j % len) on
+    n_workers OpenMP threads, one single-threaded solve each (orc_solve_jobs).  Returns the number of solves completed."""
+    prm = params or default_params()
+    B = len(instances)
+    cam = [np.ascontiguousarray(q["campos"], np.float32) for q in instances]
+    nrm = [np.ascontiguousarray(q["normals"], np.float32) for q in instances]
+    cor = [np.ascontiguousarray(q["corr"], ENTRYJ_DTYPE) for q in instances]
+    pos = [np.ascontiguousarray(q["poses"], np.float32).reshape(-1, 16) for q in instances]
+    N, Hd, Wd = cam[0].shape[:3]
+    intr = np.ascontiguousarray(np.stack([q["intr"] for q in instances]), np.float32)
+    pairs = np.ascontiguousarray(target_lower_pairs(N), np.int32).reshape(-1, 2)
+    arr = lambda xs: (C.c_void_p * B)(*[x.ctypes.data for x in xs])
+    nC = np.array([c.shape[0] for c in cor], np.int32)
+    f = lib().orc_solve_jobs
+    f.restype = C.c_int
+    return int(f(C.byref(prm), int(n_jobs), int(n_workers), B, N, Wd, Hd, _p(intr), arr(cam), arr(nrm), arr(cor), _p(nC), _p(pairs), pairs.shape[0], arr(pos)))
+
+
 def sparse_apply(corr, T, p, params: OrcParams | None = None) -> np.ndarray:
     """Matrix-free sparse J^T J p exactly as PCGStep_Kernel0 + PCGStep_Kernel1a apply it."""
     prm = params or default_params()

@@ -28,12 +28,61 @@ class ParityOptimizer:
     """Runs the HIP optimiser and the oracle on identical inputs, records the worst pose difference of every call
     and hands the HIP result on (so a whole tracking session is driven by the product path)."""
 
-    def __init__(self, hip_opt, oracle_opt, pose_error):
+    def __init__(self, hip_opt, oracle_opt, pose_error, classify=None):
         self.hip, self.ora, self.pose_error = hip_opt, oracle_opt, pose_error
         self.diffs = []
+        self.classify = classify          # callable(call inputs) -> first differing decision, run on the calls that leave the 1e-4 bar
+        self.divergences = {}
 
     def optimizeFrames(self, global_corres, n_match_per_pair, n_frames, H, W, depths, colors, normals, poses, K):
         ref = np.array(poses, np.float32, copy=True)
+        self._remember(poses)
         self.ora.optimizeFrames(global_corres, n_match_per_pair, n_frames, H, W, depths, colors, normals, ref, K)
         self.hip.optimizeFrames(global_corres, n_match_per_pair, n_frames, H, W, depths, colors, normals, poses, K)
         self.diffs.append(max(max(self.pose_error(poses[k], ref[k])) for k in range(n_frames)))
+        if self.classify and self.diffs[-1] >= 1e-4:
+            self.divergences[len(self.diffs) - 1] = self.classify(global_corres, n_frames, H, W, depths, normals, self._start, K)
+
+    def _remember(self, poses):
+        self._start = np.array(poses, np.float32, copy=True)
+
+
+# ---- decision traces (SURVEY.md section 7: "compare decisions first, then values") ---------------------------------
+def first_decision_divergence(hip_pcg, hip_counts, ora_pcg, ora_counts):
+    """First discrete decision the HIP path and the oracle take differently, or None.
+    pcg [G, L, 4] = (pAp, alpha, r.z, beta) per Gauss-Newton iterate and PCG step; counts [G, Pd] accepted pixels per dense pair.
+    Decisions: a dense pair accepting a different number of pixels (the accept tests <= 2 cm, >= cos 45 deg, depth range, in-image,
+    SolverBundlingDenseUtil.h:78-110), alpha = 0 (pAp <= 1e-6) and beta = 0 (r.z <= 1e-6) of PCGStep_Kernel2/3
+    (SolverBundling.cu:746-818).  Returns (iterate, kind, detail)."""
+    G = ora_pcg.shape[0]
+    for it in range(G):
+        if hip_counts is not None and ora_counts is not None and hip_counts.shape[-1] and ora_counts.shape[-1]:
+            hc, oc = np.rint(hip_counts[it]).astype(np.int64), np.asarray(ora_counts[it], np.int64)
+            n = min(hc.shape[0], oc.shape[0])
+            bad = np.nonzero(hc[:n] != oc[:n])[0]
+            if bad.size:
+                return (it, "accept", {"pair": int(bad[0]), "hip": int(hc[bad[0]]), "oracle": int(oc[bad[0]]), "pairs_differing": int(bad.size)})
+        for li in range(ora_pcg.shape[1]):
+            for col, kind in ((1, "alpha"), (3, "beta")):
+                if (hip_pcg[it, li, col] == 0) != (ora_pcg[it, li, col] == 0):
+                    return (it, kind, {"pcg_step": li, "hip": float(hip_pcg[it, li, col]), "oracle": float(ora_pcg[it, li, col]),
+                                       "guarded_value_hip": float(hip_pcg[it, li, col - 1]), "guarded_value_oracle": float(ora_pcg[it, li, col - 1])})
+    return None
+
+
+def check_parity_with_decisions(hip_T, ora_T, div, pose_error, tol=1e-4, tol_after_divergence=1e-3, what=""):
+    """Per-iterate parity rule: every iterate BEFORE the first differing decision must meet the 1e-4 bar; from the iterate of the
+    first differing decision on, the looser bound applies (a flipped accept test or epsilon guard is a different -- equally
+    legitimate -- trajectory of the reference's own discontinuous algorithm).  Returns (worst before, worst after)."""
+    G, N = ora_T.shape[0], ora_T.shape[1]
+    first = div[0] if div is not None else G
+    wb = wa = 0.0
+    for it in range(G):
+        e = max(max(pose_error(hip_T[it, k], ora_T[it, k])) for k in range(N))
+        if it < first:
+            wb = max(wb, e)
+            assert e < tol, f"{what}: iterate {it} differs by {e:.2e} although every decision so far was identical (first divergence: {div})"
+        else:
+            wa = max(wa, e)
+            assert e < tol_after_divergence, f"{what}: iterate {it} differs by {e:.2e} after divergence {div}"
+    return wb, wa

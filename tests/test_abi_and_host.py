@@ -161,15 +161,24 @@ def test_python_constants_match_the_header():
     assert defines["BTBA_MAX_FRAMES"] == 85 and defines["BTBA_MAX_FRAMES_LDS"] == 31     # the reference's MAX_NUM_IMAGES; the LDS-resident limit
 
 
-def test_traffic_file_matches_the_committed_pmc_summary():
-    """profiles/dense_sweep_traffic.json (what bench.py reports as roofline.traffic) must be the number in the PMC summary
-    it names -- both are written by scripts/summarize_profiles.py, and a hand edit of one would leave the bench line with a
-    byte count no committed profile backs."""
-    import csv, json, os, re
+def test_counter_file_matches_the_committed_pmc_summaries():
+    """profiles/sweep_counters.json (what bench.py quotes as roofline.traffic / roofline.valu_issue) must carry the numbers of the PMC
+    summaries it names -- both are written by scripts/summarize_profiles.py -- and bench.py must ignore it when it was taken on other
+    kernel sources (kernel_source_hash) or another workload."""
+    import csv, json, os
+    import bench
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tj = json.load(open(os.path.join(root, "profiles", "dense_sweep_traffic.json")))
-    src = re.match(r"(profiles/r01/\S+\.csv)", tj["source"]).group(1)
-    rows = [r for r in csv.DictReader(open(os.path.join(root, src))) if r["kernel"] == tj["kernel"]]
+    path = os.path.join(root, "profiles", "sweep_counters.json")
+    if not os.path.exists(path):
+        pytest.skip("no counter summary committed")
+    tj = json.load(open(path))
+    rows = [r for r in csv.DictReader(l for l in open(os.path.join(root, tj["source_hbm"])) if not l.startswith("#")) if r["kernel"] == tj["kernel"]]
     assert len(rows) == 1 and int(rows[0]["hbm_bytes_per_launch_corrected"]) == tj["hbm_bytes_per_launch"]
     fetch_kib, write_kib = float(rows[0]["FETCH_SIZE_KiB_mean"]), float(rows[0]["WRITE_SIZE_KiB_mean"])
     assert abs(int(fetch_kib * 1024 * 2 + write_kib * 1024) - tj["hbm_bytes_per_launch"]) <= 2048      # the guide's gfx950 correction
+    sq = {r["counter"]: float(r["mean_per_launch"]) for r in csv.DictReader(l for l in open(os.path.join(root, tj["source_sq"])) if not l.startswith("#")) if r["kernel"] == tj["kernel"]}
+    busy = 4.0 * (sq["SQ_ACTIVE_INST_VALU"] - sq["SQ_ACTIVE_INST_VALU2"]) / 1024.0 / (sq["SQ_BUSY_CYCLES"] / 32.0)
+    assert abs(busy - tj["valu_busy_frac"]) < 2e-3 and 0.0 < busy <= 1.0
+    got = bench.profiled_counters(tj["config"], tj["instances"], tj["masked"], tj["float4_cache"], tj["fused"])
+    assert (got is not None) == (tj["kernel_source_hash"] == bench.kernel_source_hash())                # stale sources -> not quoted
+    assert bench.profiled_counters(tj["config"], tj["instances"] + 1, tj["masked"], tj["float4_cache"], tj["fused"]) is None

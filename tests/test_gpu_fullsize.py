@@ -19,18 +19,24 @@ def gpu():
     return g
 
 
-def run_gpu(g, pbs, **params):
+def run_gpu(g, pbs, layout="zn", **params):
+    """Batched solve with a trace.  layout "zn" = the compact (gated z, normal) cache and the pinhole sweep -- what bench.py and
+    btba_optimize_frames run; "float4" = the reference-layout caches (btba_solve_batch)."""
     caches = [S.analytic_cache(pb) for pb in pbs]
     bs = g.BatchSolver(g.ws, **params)
     N = pbs[0].n_frames
     corr, offs, mx = bs.pack_correspondences([pb.corr for pb in pbs], N)
     B = len(pbs)
-    cam_d = g.torch.from_numpy(np.stack([c[0] for c in caches])).to(g.dev)
-    nrm_d = g.torch.from_numpy(np.stack([c[1] for c in caches])).to(g.dev)
     corr_d = g.torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(g.dev)
     offs_d = g.torch.from_numpy(offs.astype(np.int32)).to(g.dev)
     poses_d = g.torch.from_numpy(np.stack([pb.poses_init for pb in pbs])).to(g.dev)
-    tr = bs.solve(cam_d, nrm_d, caches[0][2], corr_d, offs_d, mx, poses_d, trace=True)
+    if layout == "zn":
+        zn_d = g.torch.from_numpy(np.stack([S.compact_cache(pb) for pb in pbs])).to(g.dev)
+        tr = bs.solve_zn(zn_d, pbs[0].H, pbs[0].W, pbs[0].K, corr_d, offs_d, mx, poses_d, trace=True)
+    else:
+        cam_d = g.torch.from_numpy(np.stack([c[0] for c in caches])).to(g.dev)
+        nrm_d = g.torch.from_numpy(np.stack([c[1] for c in caches])).to(g.dev)
+        tr = bs.solve(cam_d, nrm_d, caches[0][2], corr_d, offs_d, mx, poses_d, trace=True)
     tv = bs.trace_view(tr)
     return poses_d.cpu().numpy(), tv, caches
 
@@ -47,12 +53,13 @@ def sparse_objective(pb, poses, delta=0.005):
     dict(name="c2", K=10, m=1000, wd=0.0, config=2),      # K=10, 1k corr/pair, feature residuals only
     dict(name="c3", K=15, m=2000, wd=1.0, config=3),      # K=15, 2k corr/pair, feature + dense ICP + Huber (the headline)
     dict(name="c4", K=30, m=4000, wd=1.0, config=4),      # K=30, 4k corr/pair, 60-keyframe pool pruned to 30 by greedy-rot
+    dict(name="c3-float4-cache", K=15, m=2000, wd=1.0, config=3, layout="float4"),      # the reference-layout caches (btba_solve_batch)
 ], ids=lambda c: c["name"])
 def test_baseline_configs_match_oracle(gpu, oracle, cfg):
     seed = S.config_seed(cfg["config"])
     angles = S.pruned_pool_angles(60, 30, seed) if cfg["name"] == "c4" else None
     pb = S.make_problem(cfg["K"], cfg["m"], seed, background=True, full_res=False, angles=angles)
-    out, tv, caches = run_gpu(gpu, [pb], weight_dense_depth=cfg["wd"])
+    out, tv, caches = run_gpu(gpu, [pb], layout=cfg.get("layout", "zn"), weight_dense_depth=cfg["wd"])
     campos, normals, intr = caches[0]
     ref = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=cfg["wd"]))
     worst_r = worst_t = 0.0
@@ -62,6 +69,14 @@ def test_baseline_configs_match_oracle(gpu, oracle, cfg):
             worst_r, worst_t = max(worst_r, r), max(worst_t, t)
     print(f"{cfg['name']}: worst per-iterate diff rot {worst_r:.3e} rad trans {worst_t:.3e} m")
     assert worst_r < 1e-4 and worst_t < 1e-4
+    # decisions: the epsilon guards of PCGStep_Kernel2/3 take the same branch at every PCG step of every
+    # iterate, and the accept tests agree up to the handful of pixels that sit on a threshold (v_rcp / v_rsq vs IEEE division)
+    hp, op = tv.pcg_scalars[0], ref.pcg_scalars
+    assert np.array_equal(hp[..., 1] == 0, op[..., 1] == 0) and np.array_equal(hp[..., 3] == 0, op[..., 3] == 0), "alpha / beta guard traces differ"
+    if cfg["wd"] > 0:
+        dc = np.abs(np.rint(tv.dense_pair[0][..., 27]).astype(np.int64) - ref.dense_count.astype(np.int64))
+        print(f"{cfg['name']}: accepted-pixel counts differ by at most {dc.max()} per pair ({(dc > 0).mean():.1%} of (iterate, pair) cells)")
+        assert dc.max() <= 8, dc.max()
     assert np.isfinite(out).all()
     assert sparse_objective(pb, out[0]) < 0.5 * sparse_objective(pb, pb.poses_init)
     e0 = max(S.pose_error(pb.poses_init[k], pb.poses_gt[k])[0] for k in range(pb.n_frames))
@@ -90,8 +105,8 @@ def test_c5_shape_batch_properties(gpu):
     from bundletrack_amd import _lib
     out3, _, _ = run_gpu(gpu, pbs32, flags=_lib.FLAG_OVERLAP)         # two-stream half-batch pipeline: same bits as one stream
     assert np.array_equal(out, out3)
-    out4, _, _ = run_gpu(gpu, pbs32, flags=_lib.FLAG_NO_FUSE)         # sparse and dense sweeps as separate launches: same per-workgroup arithmetic
-    assert np.array_equal(out, out4)
+    out4, _, _ = run_gpu(gpu, pbs32, flags=_lib.FLAG_NO_FUSE)         # sparse and dense sweeps as separate launches: the same functions compiled into other kernels
+    assert max(max(S.pose_error(out4[b, k], out[b, k])) for b in range(32) for k in range(15)) < 5e-5
     out5, _, _ = run_gpu(gpu, [pbs32[(b + 7) % 32] for b in range(32)])
     for b in range(32):
         assert np.array_equal(out5[b], out[(b + 7) % 32])    # same instance data -> same bits wherever it sits in the grid

@@ -172,7 +172,11 @@ def test_parity_on_weakly_conditioned_scenes(gpu, oracle, case):
     cam_d, nrm_d = gpu.torch.from_numpy(ocam[None]).to(gpu.dev), gpu.torch.from_numpy(onrm[None]).to(gpu.dev)
     corr_d, offs_d, mx, poses_d = batch_inputs(gpu, bs, ocam[None], onrm[None], [pb.corr], [pb.poses_init])
     tv = bs.trace_view(bs.solve(cam_d, nrm_d, ointr, corr_d, offs_d, mx, poses_d, trace=True))
-    worst = assert_iterates_close(tv.T_after[0], ref.T_after, tol, tol)
+    # decisions first, then values: an iterate may exceed the 1e-4 bar only from the first differing accept / guard decision on
+    from helpers import check_parity_with_decisions, first_decision_divergence
+    div = first_decision_divergence(tv.pcg_scalars[0], tv.dense_pair[0][..., 27], ref.pcg_scalars, ref.dense_count)
+    worst = check_parity_with_decisions(tv.T_after[0], ref.T_after, div, S.pose_error, 1e-4, tol, f"weakly conditioned {case}")
+    print(f"first differing decision: {div}")
     print(f"weakly conditioned {case}: oracle summation spread {floor:.2e}, HIP vs oracle worst {max(worst):.2e}, bar {tol:.2e}")
 
 

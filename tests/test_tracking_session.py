@@ -90,10 +90,33 @@ def test_c1_sliding_window_hip_vs_oracle(oracle, tmp_path):
     from bundletrack_amd.optimizer import OptimizerGpu, Workspace
     dev = torch.device("cuda:0")
     n = 60
-    par = ParityOptimizer(OptimizerGpu(workspace=Workspace()), OracleOptimizer(oracle), S.pose_error)
+    from bundletrack_amd import _lib
+    from bundletrack_amd.optimizer import BatchSolver, build_cache_zn
+    from helpers import first_decision_divergence
+    ws = Workspace()
+
+    def classify(corr, N, H, W, depths, normals, poses_in, K):
+        """The same call again with traces on both sides (compact cache + batched solve = what the boundary runs inside):
+        which accept / epsilon-guard decision differs first."""
+        caches = [oracle.build_cache(depths[k].cpu().numpy().reshape(H, W), normals[k].cpu().numpy().reshape(H, W, 4), K) for k in range(N)]
+        ora = oracle.solve(np.stack([c["campos"] for c in caches]), np.stack([c["normals"] for c in caches]), caches[0]["intr"], corr, poses_in)
+        zn, nvalid, _ = build_cache_zn(ws, depths, normals, H, W, K, 4.0)
+        bs = BatchSolver(ws)
+        if int(nvalid.sum()) * 10 < N * zn.shape[1] * zn.shape[2] * 6:
+            bs.params.flags |= _lib.FLAG_COMPACTION                     # btba_optimize_frames' own rule for masked frames
+        c, o, mx = bs.pack_correspondences([corr], N)
+        tv = bs.trace_view(bs.solve_zn(zn[None], H, W, K, torch.from_numpy(c.view(np.uint8).reshape(1, -1, 32)).to(dev), torch.from_numpy(o.astype(np.int32)).to(dev), mx,
+                                       torch.from_numpy(np.asarray(poses_in, np.float32)[None].copy()).to(dev), trace=True))
+        return first_decision_divergence(tv.pcg_scalars[0], tv.dense_pair[0][..., 27], ora.pcg_scalars, ora.dense_count)
+
+    par = ParityOptimizer(OptimizerGpu(workspace=ws), OracleOptimizer(oracle), S.pose_error, classify=classify)
     seq, bundler, frames, errs = run_session(par, n, tmp_path=str(tmp_path), to_device=lambda a: torch.from_numpy(a).to(dev))
     assert len(par.diffs) == n - 1
     d = np.array(par.diffs)
+    # every call that leaves the 1e-4 bar is explained by a decision the two sides took differently
+    for call in np.nonzero(d >= 1e-4)[0]:
+        print(f"BA call {call}: diff {d[call]:.2e}, first differing decision {par.divergences.get(int(call))}")
+        assert par.divergences.get(int(call)) is not None, f"BA call {call} differs by {d[call]:.2e} with identical accept / guard decisions"
     # A converged window sits on the reference's PCG guard (r.z <= 1e-6 => no step, SolverBundling.cu:728-818): r.z
     # hovers at 0.9-1.1e-6 and last-bit rounding decides whether one more ~1e-4 step is taken in an iteration.  The
     # oracle's own two summation orders disagree on those calls (tests/tools/dbg_session.py); one or two flipped steps move a
