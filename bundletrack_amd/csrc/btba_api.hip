@@ -299,7 +299,7 @@ static int pick_chunks(const btba_params *prm, int B, int P, uint32_t max_corr_p
     if (want > 16) want = 16;
     return want;
 }
-static int pick_tiles(const btba_params *prm, int B, int Pd, int npix)
+static int pick_tiles(const btba_params *prm, int B, int Pd, int npix, bool lists)
 {
     if (prm->dense_tiles > 0) return prm->dense_tiles;
     if (Pd == 0) return 1;
@@ -309,6 +309,9 @@ static int pick_tiles(const btba_params *prm, int B, int Pd, int npix)
     //   relative pose, block reduction), so a big batch wants few, large tiles; B=8 0.871 / 0.886 / 0.874 / 0.900 ms per step for
     //   4 / 5 / 6 / 8; a single instance wants 10-15 (0.486 ms) to fill the chip
     const long blocks = (long)B * Pd;
+    // masked frames walked through their valid-pixel lists (~5 % of the image): one workgroup per pair is enough work per set-up
+    // once the batch fills the chip (c3 x 32 masked, fused sweep per launch: 56.6 / 66.0 / 97.5 / 87.5 us for 1 / 2 / 3 / 4 tiles)
+    if (lists && blocks >= 2048) return 1;
     int want = blocks >= 2048 ? 2 : blocks >= 512 ? 4 : (int)((2048 + blocks - 1) / blocks);
     const int cap = (npix + kBlock - 1) / kBlock;
     if (want > cap) want = cap;
@@ -352,7 +355,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     }
     const int npix = Hd * Wd;
     const int chunks = use_sparse ? pick_chunks(prm, B, P, max_corr_per_pair) : 1;
-    const int tiles = use_dense ? pick_tiles(prm, B, Pd, npix) : 1;
+    const int tiles = use_dense ? pick_tiles(prm, B, Pd, npix, use_zn && (prm->flags & BTBA_FLAG_COMPACTION)) : 1;
     const bool timing = (prm->flags & BTBA_FLAG_TIME_KERNELS) != 0;
 
     int rc;
@@ -433,7 +436,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     const size_t lds_limit = 160 * 1024;
     const bool a_global = n * ld * sizeof(float) + lds_rest > lds_limit;
     const size_t lds_core = (a_global ? 0 : n * ld * sizeof(float)) + lds_rest;
-    const size_t lds_pairs = ((size_t)P * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals) * sizeof(float);
+    const size_t lds_pairs = ((size_t)P * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals) * sizeof(float);
     D.pairsum_in_lds = (lds_core + lds_pairs <= 64 * 1024) ? 1 : 0;   // keep two workgroups per CU when it fits
     if (!D.pairsum_in_lds && lds_core + lds_pairs <= lds_limit && B <= 256) D.pairsum_in_lds = 1;
     const size_t lds_bytes = lds_core + (D.pairsum_in_lds ? lds_pairs : 0);

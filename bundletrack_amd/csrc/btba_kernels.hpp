@@ -40,6 +40,7 @@ constexpr int kSolveBlock = 1024;    // 16 waves: the per-instance solve is late
 constexpr int kSparseVals = 44;      // per-pair sparse partial record
 constexpr int kDenseVals = 28;       // per-pair dense partial record: S(21) g(6) count(1)
 constexpr float kEps = 0.000001f;    // FLOAT_EPSILON, SolverUtil.h:10
+constexpr int kRedFloats = 4 * kSparseVals + 8;   // LDS scratch of a sweep workgroup: 4 waves x 44 sparse sums, or 4 x 28 dense sums + their total (28) + M (36)
 
 // sparse record layout
 //  0      n (valid count)
@@ -316,7 +317,7 @@ __device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *_
 __global__ void __launch_bounds__(kBlock) k_sparse_sweep(SolveDims D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
                                                         const float *__restrict__ T, float *__restrict__ partials)
 {
-    __shared__ float red[4 * kSparseVals];
+    __shared__ float red[kRedFloats];
     sparse_block(D, corr, pair_offsets, T, partials, blockIdx.x, blockIdx.y, blockIdx.z, red);
 }
 
@@ -436,6 +437,72 @@ __device__ __forceinline__ void pixel_accumulate(const DenseCtx &C, const PixelG
     acc[27] += masked(1.0f);
 }
 
+// index of (r, c), r <= c, in the 21-entry upper-triangle row-major packing of a symmetric 6x6
+__device__ __forceinline__ int tri21(int r, int c) { if (r > c) { const int t = r; r = c; c = t; } return r * 6 - r * (r - 1) / 2 + (c - r); }
+
+// Epilogue of a dense workgroup: fixed-order reduction of the 28 per-lane sums over the workgroup, then the camera-frame ->
+// model-frame congruence S = M S' M^T, g = M g' with M = [[R_i, 0], [[t_i]x R_i, R_i]] of the TARGET frame's pose of this iterate
+// (see pixel_accumulate), then one 112-byte record per workgroup.  The congruence is linear, so applying it per tile and summing
+// the tiles in k_system_solve equals applying it to the sum; doing it here (27 lanes, ~40 FMAs each, once per workgroup) takes it
+// off the single-workgroup critical path of k_system_solve (it was 8.4 k of its 55 k cycles).
+__device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *red, float *out, const float *__restrict__ T_target)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kDenseVals; k++) {
+        const float s = wave_sum_to_lane63(acc[k]);
+        if (lane == 63) red[wave * kDenseVals + k] = s;
+    }
+    __syncthreads();
+    float *Sp = red + 4 * kDenseVals;                    // the workgroup's camera-frame sums (28) ...
+    float *Mt = Sp + kDenseVals + 4;                     // ... and M (36)
+    if (threadIdx.x < kDenseVals) {
+        float s = red[threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < 4; w++) s += red[w * kDenseVals + threadIdx.x];
+        Sp[threadIdx.x] = s;
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + 36) {
+        const int e = (int)threadIdx.x - 64, r = e / 6, c = e % 6;
+        float v;
+        if (r < 3) v = (c < 3) ? T_target[4 * r + c] : 0.0f;
+        else {
+            const int q = r - 3, qa = (q + 1) % 3, qb = (q + 2) % 3;     // ([t]x R)[q][c] = t[qa] R[qb][c] - t[qb] R[qa][c]
+            v = (c < 3) ? T_target[4 * qa + 3] * T_target[4 * qb + c] - T_target[4 * qb + 3] * T_target[4 * qa + c] : T_target[4 * q + (c - 3)];
+        }
+        Mt[e] = v;
+    }
+    __syncthreads();
+    const int idx = (int)threadIdx.x;
+    if (idx < 21) {
+        int r = 0, rem = idx;
+        while (rem >= 6 - r) { rem -= 6 - r; r++; }
+        const int c = r + rem;
+        float S[21];
+#pragma unroll
+        for (int k2 = 0; k2 < 21; k2++) S[k2] = Sp[k2];
+        float Mr[6], Mc[6];
+#pragma unroll
+        for (int l = 0; l < 6; l++) { Mr[l] = Mt[6 * r + l]; Mc[l] = Mt[6 * c + l]; }
+        float a = 0.0f;
+#pragma unroll
+        for (int k2 = 0; k2 < 6; k2++) {
+            float u = 0.0f;                                   // u = (S' Mc^T)[k2]
+#pragma unroll
+            for (int l = 0; l < 6; l++) u += S[tri21(k2, l)] * Mc[l];
+            a += Mr[k2] * u;
+        }
+        out[idx] = a;
+    } else if (idx < 27) {
+        const int r = idx - 21;
+        float a = 0.0f;
+#pragma unroll
+        for (int k2 = 0; k2 < 6; k2++) a += Mt[6 * r + k2] * Sp[21 + k2];
+        out[idx] = a;
+    } else if (idx == 27) {
+        out[27] = Sp[27];
+    }
+}
+
 // 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).  Lane = consecutive source pixel (coalesced
 // float4 loads of the source camPos / normal); two pixels per lane per trip, sixteen target-tap gathers in
 // flight; the taps stay in L1/L2 because neighbouring source pixels project to neighbouring target pixels.
@@ -476,7 +543,7 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
         }
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
-    block_reduce_store<kDenseVals, 4>(acc, red, out);
+    dense_epilogue(acc, red, out, T + 16 * (fb + fi));
 }
 
 // Ordered list of the pixels of every frame that carry a depth (>= 0.1 m, the cache builder's validity rule).
@@ -625,7 +692,7 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
                          make_float4(z00.y, z00.z, z00.w, 0.f), make_float4(z10.y, z10.z, z10.w, 0.f), make_float4(z01.y, z01.z, z01.w, 0.f), make_float4(z11.y, z11.z, z11.w, 0.f), acc);
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
-    block_reduce_store<kDenseVals, 4>(acc, red, out);
+    dense_epilogue(acc, red, out, T + 16 * (fb + fi));
 }
 
 // ---- the dense sweep for pinhole intrinsics on the GATED compact cache --------------------------------------------
@@ -850,7 +917,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         }
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
-    block_reduce_store<kDenseVals, 4>(acc, red, out);
+    dense_epilogue(acc, red, out, T + 16 * (fb + fi));
 }
 
 template <bool SIMPLE, bool LISTS>
@@ -858,7 +925,7 @@ __global__ void __launch_bounds__(kBlock, 5) k_dense_sweep_zn(SolveDims D, const
                                                              const float *__restrict__ T, const float *__restrict__ Tinv, float *__restrict__ partials,
                                                              const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts)
 {
-    __shared__ float red[4 * kDenseVals];
+    __shared__ float red[kRedFloats];
     extern __shared__ __attribute__((aligned(16))) float zn_lut[];        // (Wd + Hd) floats
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = (int)(L % (unsigned)D.dense_tiles);
@@ -876,7 +943,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_dense_sweep(SolveDims D, const fl
                                                               const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
                                                               float *__restrict__ partials)
 {
-    __shared__ float red[4 * kDenseVals];
+    __shared__ float red[kRedFloats];
     const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = (int)(L % (unsigned)D.dense_tiles);
     const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
@@ -899,7 +966,7 @@ __global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_fused_sweeps(Solve
                                                            const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets, float *__restrict__ sparse_partials,
                                                            const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts)
 {
-    __shared__ float red[4 * kSparseVals];
+    __shared__ float red[kRedFloats];
     extern __shared__ __attribute__((aligned(16))) float zn_lut[];        // (Wd + Hd) floats, compact layouts only
     const unsigned G = n_d + n_s, g = blockIdx.x, xcd = g & 7u, slot = g >> 3;
     const unsigned qd = n_d >> 3, rd = n_d & 7u;
@@ -932,8 +999,6 @@ __global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_fused_sweeps(Solve
 }
 
 // ---- system solve -------------------------------------------------------------------------------
-// index of (r, c), r <= c, in the 21-entry upper-triangle row-major packing of a symmetric 6x6
-__device__ __forceinline__ int tri21(int r, int c) { if (r > c) { const int t = r; r = c; c = t; } return r * 6 - r * (r - 1) / 2 + (c - r); }
 // symmetric 3x3 packed xx xy xz yy yz zz
 __device__ __forceinline__ float sym3(const float *m, int r, int c) { if (r > c) { const int t = r; r = c; c = t; } return m[r * 3 - r * (r - 1) / 2 + (c - r)]; }
 // [v]x (r, c)
@@ -1054,9 +1119,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     float *ps;
     float *x_l = reinterpret_cast<float *>(entry_lut + 288);       // this iterate's x (6 N floats, padded to 16 bytes): phase D would otherwise start with a fabric-latency load
     if (LDS_PAIRS) ps = x_l + ((6 * N + 3) & ~3);
-    else ps = pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + 2 * (size_t)D.n_dense_pairs * kDenseVals);
+    else ps = pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals);
     float *pd = ps + (size_t)D.n_pairs * kSparseVals;          // model-frame dense pair sums (S, g, count)
-    float *pdr = pd + (size_t)D.n_dense_pairs * kDenseVals;     // camera-frame sums as the sweep produced them
     float *tr = D.trace_on ? trace + ((size_t)b * D.n_gn + iter) * D.trace_record : nullptr;
 
     const long long clk0 = tr ? (long long)clock64() : 0;
@@ -1120,7 +1184,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     // items per lane per trip: one trip covers the c3 window (105 pairs: 4 620 sparse / 2 940 dense sums over 1 024 lanes)
     if (D.use_sparse) reduce_partials(std::integral_constant<int, kSparseVals>{}, std::integral_constant<int, 5>{}, sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals, ps, D.n_pairs, D.sparse_chunks);
     else for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) ps[e] = 0.0f;
-    if (D.use_dense) reduce_partials(std::integral_constant<int, kDenseVals>{}, std::integral_constant<int, 3>{}, dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals, pdr, D.n_dense_pairs, D.dense_tiles);
+    if (D.use_dense) reduce_partials(std::integral_constant<int, kDenseVals>{}, std::integral_constant<int, 3>{}, dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals, pd, D.n_dense_pairs, D.dense_tiles);
     BTBA_STAMP(7);
     // the staged values: first trip from the registers loaded above, the rest (windows beyond 64 frames / 1 024 pairs) by loops
     if (tid < 16 * N) vT[tid] = st_T;
@@ -1137,60 +1201,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     for (int e = tid; e < n * ld; e += nthr) A[e] = 0.0f;
     __syncthreads();
     BTBA_STAMP(0);
-    // Phase A2: camera-frame -> model-frame congruence of the dense pair sums, S = M S' M^T, g = M g',
-    // M = [[R_i, 0], [[t_i]x R_i, R_i]] with T_i the TARGET frame's pose of this iterate.
-    // One (pair, upper-triangle entry) per lane + one (pair, g row) per lane; S' held in registers.
-    if (D.use_dense) {
-        // M of every frame once (36 N entries, one lane each), parked in the vector region that is not written before
-        // phase B2: the per-pair loop below then reads rows of M instead of rebuilding them with divergent branches
-        float *Mf = vb;                                   // 6 ld >= 36 N floats
-        for (int e = tid; e < 36 * N; e += nthr) {
-            const int k = e / 36, r = (e % 36) / 6, c = e % 6;
-            const float *Tt = vT + 16 * k;
-            float v;
-            if (r < 3) v = (c < 3) ? Tt[4 * r + c] : 0.0f;
-            else {
-                const int q = r - 3, qa = (q + 1) % 3, qb = (q + 2) % 3;     // ([t]x R)[q][c] = t[qa] R[qb][c] - t[qb] R[qa][c]
-                v = (c < 3) ? Tt[4 * qa + 3] * Tt[4 * qb + c] - Tt[4 * qb + 3] * Tt[4 * qa + c] : Tt[4 * q + (c - 3)];
-            }
-            Mf[e] = v;
-        }
-        __syncthreads();
-        for (int e = tid; e < D.n_dense_pairs * 27; e += nthr) {
-            const int p = e / 27, idx = e % 27;
-            const float *Mt = Mf + 36 * dense_pairs_lds[2 * p];
-            const float *Sp = pdr + (size_t)p * kDenseVals;
-            float *So = pd + (size_t)p * kDenseVals;
-            if (idx < 21) {
-                int r = 0, rem = idx;
-                while (rem >= 6 - r) { rem -= 6 - r; r++; }
-                const int c = r + rem;
-                float S[21];
-#pragma unroll
-                for (int k2 = 0; k2 < 21; k2++) S[k2] = Sp[k2];
-                float Mr[6], Mc[6];
-#pragma unroll
-                for (int l = 0; l < 6; l++) { Mr[l] = Mt[6 * r + l]; Mc[l] = Mt[6 * c + l]; }
-                float acc = 0.0f;
-#pragma unroll
-                for (int k2 = 0; k2 < 6; k2++) {
-                    float u = 0.0f;                                   // u = (S' Mc^T)[k2]
-#pragma unroll
-                    for (int l = 0; l < 6; l++) u += S[tri21(k2, l)] * Mc[l];
-                    acc += Mr[k2] * u;
-                }
-                So[idx] = acc;
-            } else {
-                const int r = idx - 21;
-                float acc = 0.0f;
-#pragma unroll
-                for (int k2 = 0; k2 < 6; k2++) acc += Mt[6 * r + k2] * Sp[21 + k2];
-                So[21 + r] = acc;
-                if (r == 0) So[27] = Sp[27];
-            }
-        }
-        __syncthreads();
-    }
+    // (the camera-frame -> model-frame congruence of the dense pair sums is done by the sweep workgroups: dense_epilogue)
     if (tr && D.use_dense) for (int e = tid; e < D.n_dense_pairs * kDenseVals; e += nthr) tr[D.tr_dpair + e] = pd[e];
 
     BTBA_STAMP(1);

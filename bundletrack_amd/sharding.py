@@ -25,7 +25,9 @@ def init_from_env(backend: str | None = None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1:
+    # a process group also at world size 1 when launched by torchrun (or BTBA_DIST_FORCE=1): the same RCCL calls -- communicator
+    # set-up, device barrier, device all-gather -- then run on a single-GPU box
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("BTBA_DIST_FORCE"):
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
@@ -48,17 +50,28 @@ def barrier(device=None):
             dist.barrier()
 
 
-def gather_throughput(seconds: float, gn_iters: float, device="cpu"):
-    """All-gather {seconds, gn_iters} of every rank (16 bytes per rank -- latency only).
-    Returns a list of (seconds, gn_iters) indexed by rank."""
+def gather_throughput(seconds: float, gn_iters: float, device="cpu", checksum: float = 0.0):
+    """All-gather {seconds, gn_iters, pose checksum} of every rank (24 bytes per rank -- latency only; the checksum is SURVEY.md 8(e)'s
+    optional consistency check of the sharded run).  Returns a list of (seconds, gn_iters) indexed by rank; the checksums are kept in
+    gather_throughput.checksums."""
     import torch
     import torch.distributed as dist
-    mine = torch.tensor([float(seconds), float(gn_iters)], dtype=torch.float64, device=device)
+    mine = torch.tensor([float(seconds), float(gn_iters), float(checksum)], dtype=torch.float64, device=device)
     if not (dist.is_available() and dist.is_initialized()):
+        gather_throughput.checksums = [float(mine[2])]
         return [(float(mine[0]), float(mine[1]))]
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
+    gather_throughput.checksums = [float(t[2]) for t in out]
     return [(float(t[0]), float(t[1])) for t in out]
+
+
+gather_throughput.checksums = []
+
+
+def backend_name():
+    import torch.distributed as dist
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
 
 
 def aggregate(per_rank):

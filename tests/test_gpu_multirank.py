@@ -33,3 +33,20 @@ def test_two_ranks_through_torchrun():
     assert total == 2 * 4 * 7 * 3                                    # ranks x instances x GN iterations x steps
     assert abs(d["value"] - total / slowest) <= 1e-3 * d["value"]
     assert d["config"]["instances_per_gpu"] == 4
+
+
+def test_one_rank_on_rccl():
+    """The RCCL branch itself, executed: one rank under torchrun with backend nccl (= RCCL on ROCm) -- communicator creation,
+    the device barrier on both sides of the timed region and the closing device all-gather are the calls an 8-GPU run makes,
+    only with one participant (a gpurun box has one GPU)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, BTBA_DIST_BACKEND="nccl", BTBA_BENCH_NPROC="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--instances", "4", "--distinct", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["collective"]["backend"] == "nccl" and d["collective"]["rccl_ranks"] == 1
+    assert d["n_gpus"] == 1 and len(d["per_rank"]) == 1 and d["per_rank"][0]["gn_iters"] == 4 * 7 * 3
+    assert d["per_rank"][0]["pose_checksum"] > 0

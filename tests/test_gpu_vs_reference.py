@@ -72,6 +72,12 @@ def test_pair_orientation_policies_against_the_reference_address_compare(policy)
     # frames masked to the object with DIFFERENT valid-pixel counts (orbit + distinct semi-axes), so MORE_VALID is a real permutation
     pb = S.make_problem(5, 300, seed=41, background=False)
     N = pb.n_frames
+
+    def thin(k, frac):                         # drop the upper part of the object in frame k: on the orbit the counts fall monotonically with k otherwise
+        rows = np.nonzero((pb.depth[k] > 0).any(1))[0]
+        cut = rows[0] + int(frac * len(rows))
+        pb.depth[k][:cut] = 0; pb.normals[k][:cut] = 0
+    thin(0, 0.5); thin(2, 0.25)
     from oracle import oracle as O            # only for the reference-ordered cache (checked bit-exact elsewhere)
     caches = [O.build_cache(pb.depth[k], pb.normals[k], pb.K) for k in range(N)]
     campos, normals, intr = np.stack([c["campos"] for c in caches]), np.stack([c["normals"] for c in caches]), caches[0]["intr"]
