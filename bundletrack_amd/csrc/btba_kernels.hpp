@@ -787,10 +787,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const float d = zs.x;
         const bool src_ok = (__float_as_uint(d) - C.zmin_bits) < C.zrange_bits;
         const float sx = lds_f32_at(lut, ox) * d, sy = lds_f32_at(lut, oy) * d;
-        // rotate the normal, transform the point, project
-        const float nqx = C.R[0] * zs.y + C.R[1] * zs.z + C.R[2] * zs.w;
-        const float nqy = C.R[3] * zs.y + C.R[4] * zs.z + C.R[5] * zs.w;
-        const float nqz = C.R[6] * zs.y + C.R[7] * zs.z + C.R[8] * zs.w;
+        // transform the point, project
         const float qx = C.R[0] * sx + C.R[1] * sy + C.R[2] * d + C.t[0];
         const float qy = C.R[3] * sx + C.R[4] * sy + C.R[5] * d + C.t[1];
         const float qz = C.R[6] * sx + C.R[7] * sy + C.R[8] * d + C.t[2];
@@ -799,6 +796,10 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const float uc = __builtin_amdgcn_fmed3f(u, 0.0f, C.wm1), vc = __builtin_amdgcn_fmed3f(v, 0.0f, C.hm1);      // NaN -> 0: addresses stay in the frame
         const bool valid = src_ok & (fabsf(u - uc) < 0.5f) & (fabsf(v - vc) < 0.5f);
         if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
+        // rotate the normal (only the waves that go on need it: half of the block trips end above)
+        const float nqx = C.R[0] * zs.y + C.R[1] * zs.z + C.R[2] * zs.w;
+        const float nqy = C.R[3] * zs.y + C.R[4] * zs.z + C.R[5] * zs.w;
+        const float nqz = C.R[6] * zs.y + C.R[7] * zs.z + C.R[8] * zs.w;
         // taps (x0, x0 + 1) x (y0, y0 + 1) with x0 = min(floor(uc), W - 2): at the right / bottom edge (uc = W - 1) the weights are (0, 1)
         // instead of (1, -) -- the same blend, and the four taps are always the 2 x 2 block at ONE computed address
         const float fx0 = fminf(floorf(uc), C.wm2), fy0 = fminf(floorf(vc), C.hm2);

