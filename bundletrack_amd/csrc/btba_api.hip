@@ -1096,62 +1096,81 @@ int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, int n_ins
 
 
 // ---- correspondence RANSAC ---------------------------------------------------------
-int btba_ransac_pairs(btba_workspace *ws, int n_pairs, const float *ptsA_host, const float *ptsB_host, const int32_t *n_pts,
-                      int n_trials, float dist_thres, const int32_t *samples_host, uint64_t seed,
-                      int32_t *inlier_ids_out, int32_t *n_inliers_out, int32_t *best_trial_out, float *best_pose_out,
-                      int32_t *trial_counts_out, float *trial_poses_out)
+int btba_ransac_pairs_ex(btba_workspace *ws, int hypothesis, int device_resident, int n_pairs, const float *ptsA, const float *ptsB, const int32_t *n_pts,
+                         int n_trials, float dist_thres, const int32_t *samples, uint64_t seed,
+                         int32_t *inlier_ids_out, int32_t *n_inliers_out, int32_t *best_trial_out, float *best_pose_out,
+                         int32_t *trial_counts_out, float *trial_poses_out)
 {
     if (!ws || n_pairs < 1 || !n_pts || n_trials < 1 || !(dist_thres >= 0.0f) || !inlier_ids_out || !n_inliers_out) return BTBA_EINVAL;
+    if (hypothesis != BTBA_RANSAC_REFERENCE_SVD && hypothesis != BTBA_RANSAC_HORN) return BTBA_EINVAL;
     std::vector<int32_t> offsets(n_pairs + 1, 0);
     for (int p = 0; p < n_pairs; p++) {
         if (n_pts[p] < 0) return BTBA_EINVAL;
         offsets[p + 1] = offsets[p] + n_pts[p];
     }
     const size_t T = (size_t)offsets[n_pairs], NT = (size_t)n_pairs * n_trials;
-    if (T && (!ptsA_host || !ptsB_host)) return BTBA_EINVAL;
+    if (T && (!ptsA || !ptsB)) return BTBA_EINVAL;
+    const bool dev = device_resident != 0;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t o = 0;
-    const size_t o_a = o; o += al(16 * (T ? T : 1));
-    const size_t o_b = o; o += al(16 * (T ? T : 1));
+    const size_t o_a = o; o += dev ? 0 : al(16 * (T ? T : 1));
+    const size_t o_b = o; o += dev ? 0 : al(16 * (T ? T : 1));
     const size_t o_off = o; o += al(4 * (size_t)(n_pairs + 1));
-    const size_t o_smp = o; o += al(samples_host ? 12 * NT : 4);
+    const size_t o_smp = o; o += (samples && !dev) ? al(12 * NT) : al(4);
     const size_t o_pose = o; o += al(48 * NT);
     const size_t o_cnt = o; o += al(4 * NT);
     const size_t o_best = o; o += al(8 * (size_t)n_pairs);
-    const size_t o_ids = o; o += al(4 * (T ? T : 1));
+    const size_t o_ids = o; o += dev ? 0 : al(4 * (T ? T : 1));
     const size_t o_nin = o; o += al(4 * (size_t)n_pairs);
     const size_t o_bt = o; o += al(4 * (size_t)n_pairs);
     const size_t o_bp = o; o += al(64 * (size_t)n_pairs);
     int rc;
-    if ((rc = ws->ransac.ensure(o))) return rc;
+    if ((rc = ws->ransac.ensure(o ? o : 256))) return rc;
     unsigned char *base = ws->ransac.as<unsigned char>();
-    if (T) {
-        HIP_TRY(hipMemcpyAsync(base + o_a, ptsA_host, 16 * T, hipMemcpyHostToDevice, ws->stream));
-        HIP_TRY(hipMemcpyAsync(base + o_b, ptsB_host, 16 * T, hipMemcpyHostToDevice, ws->stream));
+    if (T && !dev) {
+        HIP_TRY(hipMemcpyAsync(base + o_a, ptsA, 16 * T, hipMemcpyHostToDevice, ws->stream));
+        HIP_TRY(hipMemcpyAsync(base + o_b, ptsB, 16 * T, hipMemcpyHostToDevice, ws->stream));
     }
     HIP_TRY(hipMemcpyAsync(base + o_off, offsets.data(), 4 * (size_t)(n_pairs + 1), hipMemcpyHostToDevice, ws->stream));
-    if (samples_host) HIP_TRY(hipMemcpyAsync(base + o_smp, samples_host, 12 * NT, hipMemcpyHostToDevice, ws->stream));
+    HIP_TRY(hipStreamSynchronize(ws->stream));          // `offsets` is a local (16 B per pair: the only host wait of the device-resident form)
+    if (samples && !dev) HIP_TRY(hipMemcpyAsync(base + o_smp, samples, 12 * NT, hipMemcpyHostToDevice, ws->stream));
     HIP_TRY(hipMemsetAsync(base + o_best, 0, 8 * (size_t)n_pairs, ws->stream));
     RansacDims D{};
-    D.n_pairs = n_pairs; D.n_trials = n_trials; D.dist_thres = dist_thres; D.seed = seed; D.has_samples = samples_host ? 1 : 0;
+    D.n_pairs = n_pairs; D.n_trials = n_trials; D.dist_thres = dist_thres; D.seed = seed; D.has_samples = samples ? 1 : 0; D.hypothesis = hypothesis;
+    const float4 *dA = dev ? reinterpret_cast<const float4 *>(ptsA) : reinterpret_cast<const float4 *>(base + o_a);
+    const float4 *dB = dev ? reinterpret_cast<const float4 *>(ptsB) : reinterpret_cast<const float4 *>(base + o_b);
+    const int *dS = (samples && dev) ? samples : reinterpret_cast<const int *>(base + o_smp);
+    // device-resident: results go straight to the caller's device buffers (the optional per-trial tables too)
+    int *d_ids = dev ? inlier_ids_out : reinterpret_cast<int *>(base + o_ids);
+    int *d_nin = dev ? n_inliers_out : reinterpret_cast<int *>(base + o_nin);
+    int *d_bt = (dev && best_trial_out) ? best_trial_out : reinterpret_cast<int *>(base + o_bt);
+    float *d_bp = (dev && best_pose_out) ? best_pose_out : reinterpret_cast<float *>(base + o_bp);
+    int *d_cnt = (dev && trial_counts_out) ? trial_counts_out : reinterpret_cast<int *>(base + o_cnt);
+    float *d_pose = (dev && trial_poses_out) ? trial_poses_out : reinterpret_cast<float *>(base + o_pose);
     k_ransac_vote<<<dim3((n_trials + 255) / 256, n_pairs), 256, 0, ws->stream>>>(
-        D, reinterpret_cast<const float4 *>(base + o_a), reinterpret_cast<const float4 *>(base + o_b), reinterpret_cast<const int *>(base + o_off),
-        reinterpret_cast<const int *>(base + o_smp), reinterpret_cast<float *>(base + o_pose), reinterpret_cast<int *>(base + o_cnt),
-        reinterpret_cast<unsigned long long *>(base + o_best));
+        D, dA, dB, reinterpret_cast<const int *>(base + o_off), dS, d_pose, d_cnt, reinterpret_cast<unsigned long long *>(base + o_best));
     k_ransac_extract<<<n_pairs, 256, 0, ws->stream>>>(
-        D, reinterpret_cast<const float4 *>(base + o_a), reinterpret_cast<const float4 *>(base + o_b), reinterpret_cast<const int *>(base + o_off),
-        reinterpret_cast<const float *>(base + o_pose), reinterpret_cast<const unsigned long long *>(base + o_best),
-        reinterpret_cast<int *>(base + o_ids), reinterpret_cast<int *>(base + o_nin), reinterpret_cast<int *>(base + o_bt), reinterpret_cast<float *>(base + o_bp));
+        D, dA, dB, reinterpret_cast<const int *>(base + o_off), d_pose, reinterpret_cast<const unsigned long long *>(base + o_best), d_ids, d_nin, d_bt, d_bp);
     HIP_TRY(hipGetLastError());
+    if (dev) return BTBA_OK;                          // asynchronous on the workspace stream
     // the inlier lists are written only up to each pair's count: fetch counts first, ids after
-    HIP_TRY(hipMemcpyAsync(n_inliers_out, base + o_nin, 4 * (size_t)n_pairs, hipMemcpyDeviceToHost, ws->stream));
-    if (T) HIP_TRY(hipMemcpyAsync(inlier_ids_out, base + o_ids, 4 * T, hipMemcpyDeviceToHost, ws->stream));
-    if (best_trial_out) HIP_TRY(hipMemcpyAsync(best_trial_out, base + o_bt, 4 * (size_t)n_pairs, hipMemcpyDeviceToHost, ws->stream));
-    if (best_pose_out) HIP_TRY(hipMemcpyAsync(best_pose_out, base + o_bp, 64 * (size_t)n_pairs, hipMemcpyDeviceToHost, ws->stream));
-    if (trial_counts_out) HIP_TRY(hipMemcpyAsync(trial_counts_out, base + o_cnt, 4 * NT, hipMemcpyDeviceToHost, ws->stream));
-    if (trial_poses_out) HIP_TRY(hipMemcpyAsync(trial_poses_out, base + o_pose, 48 * NT, hipMemcpyDeviceToHost, ws->stream));
+    HIP_TRY(hipMemcpyAsync(n_inliers_out, d_nin, 4 * (size_t)n_pairs, hipMemcpyDeviceToHost, ws->stream));
+    if (T) HIP_TRY(hipMemcpyAsync(inlier_ids_out, d_ids, 4 * T, hipMemcpyDeviceToHost, ws->stream));
+    if (best_trial_out) HIP_TRY(hipMemcpyAsync(best_trial_out, d_bt, 4 * (size_t)n_pairs, hipMemcpyDeviceToHost, ws->stream));
+    if (best_pose_out) HIP_TRY(hipMemcpyAsync(best_pose_out, d_bp, 64 * (size_t)n_pairs, hipMemcpyDeviceToHost, ws->stream));
+    if (trial_counts_out) HIP_TRY(hipMemcpyAsync(trial_counts_out, d_cnt, 4 * NT, hipMemcpyDeviceToHost, ws->stream));
+    if (trial_poses_out) HIP_TRY(hipMemcpyAsync(trial_poses_out, d_pose, 48 * NT, hipMemcpyDeviceToHost, ws->stream));
     HIP_TRY(hipStreamSynchronize(ws->stream));
     return BTBA_OK;
+}
+
+int btba_ransac_pairs(btba_workspace *ws, int n_pairs, const float *ptsA_host, const float *ptsB_host, const int32_t *n_pts,
+                      int n_trials, float dist_thres, const int32_t *samples_host, uint64_t seed,
+                      int32_t *inlier_ids_out, int32_t *n_inliers_out, int32_t *best_trial_out, float *best_pose_out,
+                      int32_t *trial_counts_out, float *trial_poses_out)
+{
+    return btba_ransac_pairs_ex(ws, BTBA_RANSAC_REFERENCE_SVD, 0, n_pairs, ptsA_host, ptsB_host, n_pts, n_trials, dist_thres, samples_host, seed,
+                                inlier_ids_out, n_inliers_out, best_trial_out, best_pose_out, trial_counts_out, trial_poses_out);
 }
 
 }  // extern "C"

@@ -6,15 +6,19 @@
 //                                                          an n_trials x n_pts int flag matrix per pair)
 //              findBestTrial                 :1202-1219   (atomicMax + "last writer wins")
 //              host side                     SiftManager::runRansacMultiPairGPU, FeatureManager.cpp:659-741
-// Design here: ONE vote launch for all pairs -- a lane owns a trial, builds its hypothesis in registers (Horn's
-// closed form: the optimal rotation is the dominant eigenvector of a symmetric 4x4, found by cyclic Jacobi; no
-// 3x3 SVD, no reflection case, no "R is not valid" failure) and walks the pair's points, staged through LDS in tiles
+// Design here: ONE vote launch for all pairs -- a lane owns a trial, builds its hypothesis in registers and walks the
+// pair's points.  Two hypothesis builders: BTBA_RANSAC_REFERENCE_SVD (default) is the reference's procrustesKernel with its
+// approximate 3x3 SVD restated operation for operation (btba_svd3.hpp) -- per-trial poses, inlier counts and the winner
+// equal the reference's on identical sample triples; BTBA_RANSAC_HORN is the exact Kabsch optimum by Horn's closed form
+// (the optimal rotation is the dominant eigenvector of a symmetric 4x4, found by cyclic Jacobi; no 3x3 SVD, no reflection
+// case, no "R is not valid" failure; near-collinear samples rejected by the eigenvalue gap).  Points are staged through LDS in tiles
 // that every lane reads at the same index (broadcast reads; no flag matrix, no float atomics); the best trial is an
 // integer atomicMax on (count << 32 | ~trial): deterministic, lowest trial id among equals.  A second small
 // launch re-evaluates the winning pose and writes the ordered inlier list (ballot compaction).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "btba_svd3.hpp"
 
 namespace btba {
 
@@ -137,6 +141,7 @@ struct RansacDims {
     float dist_thres;
     uint64_t seed;
     int has_samples;
+    int hypothesis;      // BTBA_RANSAC_REFERENCE_SVD (0): procrustesKernel with the reference's approximate 3x3 SVD, operation for operation; BTBA_RANSAC_HORN (1)
 };
 
 // grid (ceil(n_trials / 256), n_pairs) x 256.  offsets[pair] .. offsets[pair+1] delimit the pair's points.
@@ -159,8 +164,12 @@ __global__ void __launch_bounds__(256) k_ransac_vote(RansacDims D, const float4 
         const bool in_range = idx[0] >= 0 && idx[1] >= 0 && idx[2] >= 0 && idx[0] < n && idx[1] < n && idx[2] < n;
         if (distinct && in_range) {
             const float4 s[3] = { A[idx[0]], A[idx[1]], A[idx[2]] }, d[3] = { B[idx[0]], B[idx[1]], B[idx[2]] };
-            float gap;
-            good = ransac_procrustes3(s, d, P, gap) && gap >= 1e-4f;        // (near-)collinear samples do not define a motion
+            if (D.hypothesis == 0) {
+                good = svd3::procrustes_reference(s, d, 3, P);              // false <=> the reference's "R is not valid" (P = identity)
+            } else {
+                float gap;
+                good = ransac_procrustes3(s, d, P, gap) && gap >= 1e-4f;    // (near-)collinear samples do not define a motion
+            }
         }
     }
     // the pair's points go through LDS in tiles of 256 (coalesced 16-byte loads by the whole workgroup); every lane then

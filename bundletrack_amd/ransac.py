@@ -38,8 +38,9 @@ def pack_points(ptsA, ptsB):
 
 
 def ransac_packed(ws, a_all, b_all, n_pts, n_trials: int = 2000, inlier_dist: float = 0.01, samples=None, seed: int = 0,
-                  want_trials: bool = False) -> list[dict]:
-    """btba_ransac_pairs on already packed points (see pack_points)."""
+                  want_trials: bool = False, hypothesis: int = 0) -> list[dict]:
+    """btba_ransac_pairs_ex on already packed points (see pack_points).  hypothesis: _lib.RANSAC_REFERENCE_SVD (0, default: the
+    reference's procrustesKernel with its approximate 3x3 SVD, operation for operation) or _lib.RANSAC_HORN (1: exact Kabsch)."""
     n_pairs, T = len(n_pts), int(np.sum(n_pts))
     smp = None
     if samples is not None:
@@ -52,10 +53,10 @@ def ransac_packed(ws, a_all, b_all, n_pts, n_trials: int = 2000, inlier_dist: fl
     pose = np.zeros((n_pairs, 16), np.float32)
     counts = np.zeros((n_pairs, n_trials), np.int32) if want_trials else None
     poses = np.zeros((n_pairs, n_trials, 12), np.float32) if want_trials else None
-    f = lib().btba_ransac_pairs
-    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_uint64,
+    f = lib().btba_ransac_pairs_ex
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_uint64,
                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    check(f(ws.handle, n_pairs, a_all.ctypes.data, b_all.ctypes.data, n_pts.ctypes.data, int(n_trials), float(inlier_dist),
+    check(f(ws.handle, int(hypothesis), 0, n_pairs, a_all.ctypes.data, b_all.ctypes.data, n_pts.ctypes.data, int(n_trials), float(inlier_dist),
             smp.ctypes.data if smp is not None else None, int(seed), ids.ctypes.data, n_in.ctypes.data, best.ctypes.data,
             pose.ctypes.data, counts.ctypes.data if want_trials else None, poses.ctypes.data if want_trials else None),
           "btba_ransac_pairs")
@@ -69,13 +70,35 @@ def ransac_packed(ws, a_all, b_all, n_pts, n_trials: int = 2000, inlier_dist: fl
     return out
 
 
+def ransac_packed_device(ws, a_dev, b_dev, n_pts, n_trials: int = 2000, inlier_dist: float = 0.01, samples_dev=None, seed: int = 0, hypothesis: int = 0):
+    """Device-resident form (btba_ransac_pairs_ex, device_resident = 1): a_dev / b_dev float32 CUDA tensors [T, 4] of all pairs'
+    points back to back, n_pts host int32 [n_pairs].  Returns CUDA tensors (inlier_ids [T], n_inliers [n_pairs], best_trial
+    [n_pairs], best_pose [n_pairs, 16]); asynchronous on the workspace stream -- no point or result crosses PCIe."""
+    import torch
+    from .optimizer import _dev_ptr
+    n_pts = np.ascontiguousarray(n_pts, np.int32)
+    n_pairs, T = len(n_pts), int(n_pts.sum())
+    dev = a_dev.device
+    ids = torch.zeros(max(T, 1), dtype=torch.int32, device=dev)
+    n_in = torch.zeros(n_pairs, dtype=torch.int32, device=dev)
+    best = torch.zeros(n_pairs, dtype=torch.int32, device=dev)
+    pose = torch.zeros((n_pairs, 16), dtype=torch.float32, device=dev)
+    f = lib().btba_ransac_pairs_ex
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_uint64,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    check(f(ws.handle, int(hypothesis), 1, n_pairs, _dev_ptr(a_dev, "ptsA"), _dev_ptr(b_dev, "ptsB"), n_pts.ctypes.data, int(n_trials), float(inlier_dist),
+            _dev_ptr(samples_dev, "samples") if samples_dev is not None else None, int(seed), _dev_ptr(ids, "ids"), _dev_ptr(n_in, "n_in"), _dev_ptr(best, "best"),
+            _dev_ptr(pose, "pose"), None, None), "btba_ransac_pairs_ex")
+    return ids, n_in, best, pose
+
+
 def ransac_multi_pair(ws, ptsA, ptsB, n_trials: int = 2000, inlier_dist: float = 0.01, samples=None, seed: int = 0,
-                      want_trials: bool = False) -> list[dict]:
+                      want_trials: bool = False, hypothesis: int = 0) -> list[dict]:
     """ptsA[p], ptsB[p]: [n_p,3|4] model-frame points of frame pair p (A is moved onto B).  samples: optional
     int32 [n_pairs, n_trials, 3].  Returns one dict per pair: inlier_ids (ascending), best_trial (-1: none),
     best_pose [4,4], and with want_trials also counts [n_trials] and poses [n_trials,3,4]."""
     a_all, b_all, n_pts = pack_points(ptsA, ptsB)
-    return ransac_packed(ws, a_all, b_all, n_pts, n_trials, inlier_dist, samples, seed, want_trials)
+    return ransac_packed(ws, a_all, b_all, n_pts, n_trials, inlier_dist, samples, seed, want_trials, hypothesis)
 
 
 def run_ransac_multi_pair(ws, pairs, matches: dict, n_trials: int = 2000, inlier_dist: float = 0.01, seed: int = 0) -> None:

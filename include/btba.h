@@ -325,7 +325,21 @@ BTBA_API int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, 
  *   best_pose_out         : may be NULL; float [n_pairs][16] row-major 4x4 of the winning 3-point hypothesis.
  *   trial_counts_out / trial_poses_out : may be NULL; int32 [n_pairs][n_trials], float [n_pairs][n_trials][12] (3x4).
  * Best trial = most inliers, lowest trial id among equals (the reference: whichever thread writes last).
- * Deterministic; synchronous (results valid on return). */
+ * Deterministic; synchronous (results valid on return).
+ * Hypotheses: btba_ransac_pairs uses BTBA_RANSAC_REFERENCE_SVD -- procrustesKernel (cuda_ransac.cu:998-1103) with the reference's
+ * APPROXIMATE 3x3 SVD (McAdams et al., UW-Madison TR1690, pasted into cuda_ransac.cu:48-975) restated operation for operation,
+ * including its "R is not valid" failure: per-trial poses, inlier counts and the winner equal the reference's on identical sample
+ * triples (pinned against the reference's own functions, tests/test_gpu_ransac.py).  BTBA_RANSAC_HORN (btba_ransac_pairs_ex) is the
+ * exact Kabsch optimum by Horn's quaternion method instead: never fails, rejects (near-)collinear samples by the eigenvalue gap;
+ * on 3-point samples the reference's approximate SVD is more than 4e-3 away from it in ~5 % of the trials.
+ * btba_ransac_pairs_ex also takes device_resident = 1: ptsA / ptsB / samples and every output are DEVICE pointers (n_pts stays
+ * on the host), nothing but the 4 (n_pairs + 1)-byte offset table crosses PCIe, and the call is asynchronous on the workspace
+ * stream (the host-buffer form spends ~60 % of a tracker-size call in its copies). */
+enum { BTBA_RANSAC_REFERENCE_SVD = 0, BTBA_RANSAC_HORN = 1 };
+BTBA_API int btba_ransac_pairs_ex(btba_workspace *ws, int hypothesis, int device_resident, int n_pairs, const float *ptsA, const float *ptsB,
+                                  const int32_t *n_pts, int n_trials, float dist_thres, const int32_t *samples, uint64_t seed,
+                                  int32_t *inlier_ids_out, int32_t *n_inliers_out, int32_t *best_trial_out, float *best_pose_out,
+                                  int32_t *trial_counts_out, float *trial_poses_out);
 BTBA_API int btba_ransac_pairs(btba_workspace *ws, int n_pairs, const float *ptsA_host, const float *ptsB_host, const int32_t *n_pts,
                                int n_trials, float dist_thres, const int32_t *samples_host, uint64_t seed,
                                int32_t *inlier_ids_out, int32_t *n_inliers_out, int32_t *best_trial_out, float *best_pose_out,

@@ -143,6 +143,160 @@ ORC_API int orc_procrustes(const float *src, const float *dst, int n_pts, float 
     return 1;
 }
 
+/* ---- the reference's own hypothesis: procrustesKernel with its APPROXIMATE 3x3 SVD ------------------------------------
+ * McAdams, Selle, Tamstorf, Teran, Sifakis: "Computing the Singular Value Decomposition of 3x3 matrices with minimal branching
+ * and elementary floating point operations", UW-Madison TR1690 (2011); the reference carries the report's scalar code,
+ * macro-expanded, in cuda_ransac.cu:48-975.  Restated here stage by stage in the report's operation order (every sum one IEEE
+ * fp32 operation, no contraction; rsqrt correctly rounded like __frsqrt_rn), pinned BIT FOR BIT against that code compiled for
+ * the CPU (tests/test_oracle_vs_reference.py).  Four sweeps of three approximate Jacobi conjugations, V from the accumulated
+ * quaternion, B = A V, columns sorted by norm, Givens QR. */
+typedef struct { float s11, s21, s31, s22, s32, s33, qs, qx, qy, qz; } mc_state;
+static float mc_rsqrt(float x) { return (float)(1.0 / sqrt((double)x)); }
+static float mc_rsqrt1(float x)                /* one Newton step: r + r/2 - x r (r (r/2)) */
+{
+    const float r = mc_rsqrt(x), h = r * 0.5f;
+    volatile float t = r * h; t = r * t; t = x * t;
+    volatile float u = r + h; u = u - t;
+    return u;
+}
+static float mc_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+/* conjugation in the (p, q) plane: pp, qp, qq the 2x2 block; rp, rq the remaining row; rr the remaining diagonal; (a, b, c) the
+ * quaternion's vector part rotated to (p, q, r) */
+static void mc_conj(float *pp, float *qp, float *rp, float *qq, float *rq, float *rr, float *qs, float *a, float *b, float *c)
+{
+    volatile float sh = *qp * 0.5f, d = *pp - *qq, t1, t2, t3, t4, ch, cs, sn;
+    t2 = sh * sh;
+    if (!(t2 >= 1.e-20f)) { sh = 0.0f; ch = 1.0f; } else ch = d;
+    t1 = sh * sh; t2 = ch * ch; t3 = t1 + t2; t4 = mc_rsqrt(t3);
+    sh = t4 * sh; ch = t4 * ch;
+    t1 = 5.8284273147583007813f * t1;
+    if (t2 <= t1) { sh = mc_bits(1053028117u); ch = mc_bits(1064076127u); }        /* sin, cos of pi / 8 */
+    t1 = sh * sh; t2 = ch * ch; cs = t2 - t1; sn = ch * sh; sn = sn + sn;
+    t3 = t1 + t2;
+    *rr = *rr * t3; *rp = *rp * t3; *rq = *rq * t3; *rr = *rr * t3;
+    t1 = sn * *rp; t2 = sn * *rq; *rp = cs * *rp; *rq = cs * *rq; *rp = t2 + *rp; *rq = *rq - t1;
+    t2 = sn * sn; t1 = *qq * t2; t3 = *pp * t2; t4 = cs * cs;
+    *pp = *pp * t4; *qq = *qq * t4; *pp = *pp + t1; *qq = *qq + t3;
+    t4 = t4 - t2; t2 = *qp + *qp; *qp = *qp * t4; t4 = cs * sn; t2 = t2 * t4; d = d * t4;
+    *pp = *pp + t2; *qp = *qp - d; *qq = *qq - t2;
+    t1 = sh * *a; t2 = sh * *b; t3 = sh * *c; sh = sh * *qs;
+    *qs = ch * *qs; *a = ch * *a; *b = ch * *b; *c = ch * *c;
+    *c = *c + sh; *qs = *qs - t3; *a = *a + t2; *b = *b - t1;
+}
+static void mc_sort(float *B, float *V, float *na, float *nb, int ca, int cb, int neg)
+{
+    const int sw = *na < *nb;
+    for (int r = 0; r < 3; r++) {
+        if (sw) { float t = B[3 * r + ca]; B[3 * r + ca] = B[3 * r + cb]; B[3 * r + cb] = t; t = V[3 * r + ca]; V[3 * r + ca] = V[3 * r + cb]; V[3 * r + cb] = t; }
+    }
+    if (sw) { const float t = *na; *na = *nb; *nb = t; }
+    const float sg = 1.0f + (sw ? -2.0f : 0.0f);
+    for (int r = 0; r < 3; r++) { B[3 * r + neg] *= sg; V[3 * r + neg] *= sg; }
+}
+static void mc_givens(float *B, float *U, int p, int q)
+{
+    const float app = B[3 * p + p], aqp = B[3 * q + p];
+    volatile float sh = aqp * aqp, ch, t1, t2, cs, sn;
+    sh = (sh >= 1.e-12f) ? aqp : 0.0f;
+    ch = 0.0f - app; ch = fmaxf(ch, app); ch = fmaxf(ch, 1.e-12f);
+    t1 = ch * ch; t2 = sh * sh; t2 = t1 + t2; t1 = mc_rsqrt1(t2); t1 = t1 * t2;
+    ch = ch + t1;
+    if (!(app >= 0.0f)) { const float t = ch; ch = sh; sh = t; }
+    t1 = ch * ch; t2 = sh * sh; t2 = t1 + t2; t1 = mc_rsqrt1(t2);
+    ch = ch * t1; sh = sh * t1;
+    cs = ch * ch; sn = sh * sh; cs = cs - sn; sn = sh * ch; sn = sn + sn;
+    for (int k = 0; k < 3; k++) {
+        volatile float x = B[3 * p + k], y = B[3 * q + k], sx = sn * x, sy = sn * y, cx = cs * x, cy = cs * y;
+        B[3 * p + k] = cx + sy; B[3 * q + k] = cy - sx;
+        x = U[3 * k + p]; y = U[3 * k + q]; sx = sn * x; sy = sn * y; cx = cs * x; cy = cs * y;
+        U[3 * k + p] = cx + sy; U[3 * k + q] = cy - sx;
+    }
+}
+static void mc_svd(const float *A, float *U, float *sig, float *V)
+{
+    mc_state m;
+    float *S[6] = { &m.s11, &m.s21, &m.s31, &m.s22, &m.s32, &m.s33 };
+    static const int ca[6] = { 0, 1, 2, 1, 2, 2 }, cb[6] = { 0, 0, 0, 1, 1, 2 };
+    for (int k = 0; k < 6; k++) {                   /* S = A^T A, summed top to bottom */
+        volatile float t = A[ca[k]] * A[cb[k]], u = A[3 + ca[k]] * A[3 + cb[k]];
+        t = u + t; u = A[6 + ca[k]] * A[6 + cb[k]]; t = u + t;
+        *S[k] = t;
+    }
+    m.qs = 1.0f; m.qx = m.qy = m.qz = 0.0f;
+    for (int sweep = 0; sweep < 4; sweep++) {
+        mc_conj(&m.s11, &m.s21, &m.s31, &m.s22, &m.s32, &m.s33, &m.qs, &m.qx, &m.qy, &m.qz);
+        mc_conj(&m.s22, &m.s32, &m.s21, &m.s33, &m.s31, &m.s11, &m.qs, &m.qy, &m.qz, &m.qx);
+        mc_conj(&m.s33, &m.s31, &m.s32, &m.s11, &m.s21, &m.s22, &m.qs, &m.qz, &m.qx, &m.qy);
+    }
+    volatile float t1, t2, t3;
+    t2 = m.qs * m.qs; t1 = m.qx * m.qx; t2 = t1 + t2; t1 = m.qy * m.qy; t2 = t1 + t2; t1 = m.qz * m.qz; t2 = t1 + t2;
+    const float nr = mc_rsqrt1(t2);
+    const float qs = m.qs * nr, qx = m.qx * nr, qy = m.qy * nr, qz = m.qz * nr;
+    volatile float v11, v22, v33, v12, v13, v21, v23, v31, v32;
+    t1 = qx * qx; t2 = qy * qy; t3 = qz * qz;
+    v11 = qs * qs; v22 = v11 - t1; v33 = v22 - t2; v33 = v33 + t3; v22 = v22 + t2; v22 = v22 - t3; v11 = v11 + t1; v11 = v11 - t2; v11 = v11 - t3;
+    t1 = qx + qx; t2 = qy + qy; t3 = qz + qz;
+    v32 = qs * t1; v13 = qs * t2; v21 = qs * t3;
+    t1 = qy * t1; t2 = qz * t2; t3 = qx * t3;
+    v12 = t1 - v21; v23 = t2 - v32; v31 = t3 - v13; v21 = t1 + v21; v32 = t2 + v32; v13 = t3 + v13;
+    V[0] = v11; V[1] = v12; V[2] = v13; V[3] = v21; V[4] = v22; V[5] = v23; V[6] = v31; V[7] = v32; V[8] = v33;
+    float B[9];
+    for (int r = 0; r < 3; r++) {                   /* B = A V */
+        const float a1 = A[3 * r], a2 = A[3 * r + 1], a3 = A[3 * r + 2];
+        volatile float b1 = v11 * a1, b2 = v12 * a1, b3 = v13 * a1, t;
+        t = v21 * a2; b1 = b1 + t; t = v31 * a3; b1 = b1 + t;
+        t = v22 * a2; b2 = b2 + t; t = v32 * a3; b2 = b2 + t;
+        t = v23 * a2; b3 = b3 + t; t = v33 * a3; b3 = b3 + t;
+        B[3 * r] = b1; B[3 * r + 1] = b2; B[3 * r + 2] = b3;
+    }
+    float n[3];
+    for (int c = 0; c < 3; c++) { volatile float t = B[c] * B[c], u = B[3 + c] * B[3 + c]; t = t + u; u = B[6 + c] * B[6 + c]; t = t + u; n[c] = t; }
+    mc_sort(B, V, &n[0], &n[1], 0, 1, 1);
+    mc_sort(B, V, &n[0], &n[2], 0, 2, 0);
+    mc_sort(B, V, &n[1], &n[2], 1, 2, 2);
+    for (int k = 0; k < 9; k++) U[k] = (k % 4 == 0) ? 1.0f : 0.0f;
+    mc_givens(B, U, 0, 1); mc_givens(B, U, 0, 2); mc_givens(B, U, 1, 2);
+    sig[0] = B[0]; sig[1] = B[4]; sig[2] = B[8];
+}
+
+/* procrustesKernel (:998-1103) as the reference runs it: fp32 means and correlation, the SVD above, R = V U^T, "R is not valid"
+ * when |R^T R - I|_F >= 1e-3 (returns 0, pose = identity), V's last column flipped when det R < 0, t = dst_mean - R src_mean. */
+ORC_API int orc_procrustes_reference(const float *src, const float *dst, int n_pts, float *pose)
+{
+    for (int k = 0; k < 16; k++) pose[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+    float sm[3] = { 0, 0, 0 }, dm[3] = { 0, 0, 0 };
+    for (int i = 0; i < n_pts; i++)
+        for (int c = 0; c < 3; c++) { sm[c] += src[4 * i + c]; dm[c] += dst[4 * i + c]; }
+    for (int c = 0; c < 3; c++) { sm[c] /= (float)n_pts; dm[c] /= (float)n_pts; }
+    float S[9] = { 0 };
+    for (int i = 0; i < n_pts; i++) {
+        float s[3], d[3];
+        for (int c = 0; c < 3; c++) { s[c] = src[4 * i + c] - sm[c]; d[c] = dst[4 * i + c] - dm[c]; }
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) S[3 * r + c] += s[r] * d[c];
+    }
+    float U[9], V[9], sig[3], R[9];
+    mc_svd(S, U, sig, V);
+    for (int pass = 0; pass < 2; pass++) {
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[3 * r + c] = V[3 * r] * U[3 * c] + V[3 * r + 1] * U[3 * c + 1] + V[3 * r + 2] * U[3 * c + 2];
+        if (pass == 1) break;
+        float diff = 0.0f;
+        for (int h = 0; h < 3; h++) for (int w = 0; w < 3; w++) {
+            const float t = (R[h] * R[w] + R[3 + h] * R[3 + w] + R[6 + h] * R[6 + w]) - (h == w ? 1.0f : 0.0f);
+            diff += t * t;
+        }
+        diff = sqrtf(diff);
+        if ((double)diff >= 1e-3) return 0;
+        const float det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7] - R[6] * R[4] * R[2] - R[7] * R[5] * R[0] - R[8] * R[3] * R[1];
+        if (!(det < 0.0f)) break;
+        for (int r = 0; r < 3; r++) V[3 * r + 2] = -V[3 * r + 2];
+    }
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) pose[4 * r + c] = R[3 * r + c];
+        pose[4 * r + 3] = dm[r] - (R[3 * r] * sm[0] + R[3 * r + 1] * sm[1] + R[3 * r + 2] * sm[2]);
+    }
+    return 1;
+}
+
 /* inlier test of ransacEvalModelKernel (:1190-1195): pose * ptA (float4x4 * float4, w = 1), Euclidean distance to
  * ptB, REJECT when dist > dist_thres (so dist == dist_thres is an inlier). */
 static inline int is_inlier(const float *pose, const float *a, const float *b, float dist_thres)
@@ -161,10 +315,11 @@ static inline int is_inlier(const float *pose, const float *a, const float *b, f
  *   writes last win -- any of the maxima; a fixed rule is needed to compare two implementations).
  *   Outputs: inlier_ids (ascending, capacity n_pts), *n_inliers, *best_trial (-1 if no trial was good), best_pose[16],
  *   and optionally counts[n_trials] (inliers per trial; 0 for skipped trials), poses_out[n_trials*16]. */
-ORC_API int orc_ransac_pair(const float *ptsA, const float *ptsB, int n_pts, int n_trials, float dist_thres,
-                            const int32_t *samples, uint64_t seed, int pair_id,
-                            int32_t *inlier_ids, int32_t *n_inliers, int32_t *best_trial, float *best_pose,
-                            int32_t *counts, float *poses_out)
+ORC_API int orc_ransac_pair_ex(int hypothesis /* 0: the reference's approximate-SVD procrustes; 1: exact Kabsch + collinearity gap */,
+                               const float *ptsA, const float *ptsB, int n_pts, int n_trials, float dist_thres,
+                               const int32_t *samples, uint64_t seed, int pair_id,
+                               int32_t *inlier_ids, int32_t *n_inliers, int32_t *best_trial, float *best_pose,
+                               int32_t *counts, float *poses_out)
 {
     int best = -1, best_cnt = 0;
     float bp[16];
@@ -179,7 +334,7 @@ ORC_API int orc_ransac_pair(const float *ptsA, const float *ptsB, int n_pts, int
             idx[0] < n_pts && idx[1] < n_pts && idx[2] < n_pts) {
             float s[12], d[12], gap;
             for (int k = 0; k < 3; k++) { memcpy(s + 4 * k, ptsA + 4 * idx[k], 16); memcpy(d + 4 * k, ptsB + 4 * idx[k], 16); }
-            good = orc_procrustes(s, d, 3, pose, &gap) && gap >= 1e-4f;
+            good = hypothesis == 0 ? orc_procrustes_reference(s, d, 3, pose) : (orc_procrustes(s, d, 3, pose, &gap) && gap >= 1e-4f);
         }
         if (good)
             for (int i = 0; i < n_pts; i++) cnt += is_inlier(pose, ptsA + 4 * i, ptsB + 4 * i, dist_thres);
@@ -194,4 +349,12 @@ ORC_API int orc_ransac_pair(const float *ptsA, const float *ptsB, int n_pts, int
     *best_trial = best;
     if (best_pose) memcpy(best_pose, bp, sizeof bp);
     return 0;
+}
+
+ORC_API int orc_ransac_pair(const float *ptsA, const float *ptsB, int n_pts, int n_trials, float dist_thres,
+                            const int32_t *samples, uint64_t seed, int pair_id,
+                            int32_t *inlier_ids, int32_t *n_inliers, int32_t *best_trial, float *best_pose,
+                            int32_t *counts, float *poses_out)
+{
+    return orc_ransac_pair_ex(1, ptsA, ptsB, n_pts, n_trials, dist_thres, samples, seed, pair_id, inlier_ids, n_inliers, best_trial, best_pose, counts, poses_out);
 }

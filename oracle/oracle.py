@@ -303,8 +303,20 @@ def ransac_draw(seed, pair, trial, draw, n_pts):
     return int(f(seed, pair, trial, draw, n_pts))
 
 
-def ransac_pair(ptsA, ptsB, n_trials, dist_thres, samples=None, seed=0, pair_id=0):
-    """One frame pair of ransacMultiPairGPU.  Returns dict(inlier_ids, best_trial, best_pose, counts, poses)."""
+def procrustes_reference(src, dst):
+    """procrustesKernel as the reference runs it -- with its approximate 3x3 SVD, restated operation for operation
+    (orc_procrustes_reference): (ok, pose [4,4]); ok False = the reference's "R is not valid"."""
+    s, d = _pts4(src), _pts4(dst)
+    pose = np.zeros(16, np.float32)
+    f = lib().orc_procrustes_reference
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    ok = f(s.ctypes.data, d.ctypes.data, s.shape[0], pose.ctypes.data)
+    return bool(ok), pose.reshape(4, 4)
+
+
+def ransac_pair(ptsA, ptsB, n_trials, dist_thres, samples=None, seed=0, pair_id=0, hypothesis=1):
+    """One frame pair of ransacMultiPairGPU.  hypothesis 0: the reference's approximate-SVD procrustes; 1 (default here): the exact
+    Kabsch optimum with the collinearity gap.  Returns dict(inlier_ids, best_trial, best_pose, counts, poses)."""
     a, b = _pts4(ptsA), _pts4(ptsB)
     n = a.shape[0]
     ids = np.zeros(max(n, 1), np.int32)
@@ -313,10 +325,10 @@ def ransac_pair(ptsA, ptsB, n_trials, dist_thres, samples=None, seed=0, pair_id=
     counts = np.zeros(n_trials, np.int32)
     poses = np.zeros((n_trials, 16), np.float32)
     smp = None if samples is None else np.ascontiguousarray(samples, np.int32).reshape(n_trials, 3)
-    f = lib().orc_ransac_pair
-    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_int,
+    f = lib().orc_ransac_pair_ex
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_int,
                   C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p]
-    f(a.ctypes.data, b.ctypes.data, n, n_trials, dist_thres, smp.ctypes.data if smp is not None else None, seed, pair_id,
+    f(int(hypothesis), a.ctypes.data, b.ctypes.data, n, n_trials, dist_thres, smp.ctypes.data if smp is not None else None, seed, pair_id,
       ids.ctypes.data, C.byref(n_in), C.byref(best), bp.ctypes.data, counts.ctypes.data, poses.ctypes.data)
     return dict(inlier_ids=ids[: n_in.value].copy(), best_trial=int(best.value), best_pose=bp.reshape(4, 4), counts=counts,
                 poses=poses.reshape(n_trials, 4, 4))

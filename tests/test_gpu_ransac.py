@@ -1,4 +1,7 @@
-"""HIP correspondence RANSAC (btba_ransac_pairs) against the CPU oracle, through the C ABI."""
+"""HIP correspondence RANSAC (btba_ransac_pairs / btba_ransac_pairs_ex) through the C ABI: the reference-exact hypotheses against
+the reference's own procrustesKernel / evalPoseKernel (oracle/_ref), the Horn hypotheses against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -25,7 +28,8 @@ def test_hypotheses_and_votes_match_oracle(ws, oracle):
     n_trials = 512
     smp = np.stack([rng.integers(0, len(s[0]), size=(n_trials, 3)) for s in sets]).astype(np.int32)
     smp[:, 0] = [[0, 0, 1]] * len(sets); smp[:, 1, 1] = -1                      # degenerate triples are skipped
-    res = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=n_trials, inlier_dist=0.01, samples=smp, want_trials=True)
+    from bundletrack_amd import _lib
+    res = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=n_trials, inlier_dist=0.01, samples=smp, want_trials=True, hypothesis=_lib.RANSAC_HORN)
     for p, (P, Q, T, mask) in enumerate(sets):
         ref = oracle.ransac_pair(P, Q, n_trials, 0.01, samples=smp[p])
         r = res[p]
@@ -49,7 +53,8 @@ def test_device_sampling_matches_oracle_draws(ws, oracle):
     from bundletrack_amd.ransac import ransac_multi_pair
     rng = np.random.default_rng(6)
     sets = [planted(rng, n, f) for n, f in ((40, 0.25), (500, 0.45), (2000, 0.3))]
-    res = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=99, want_trials=True)
+    from bundletrack_amd import _lib
+    res = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=99, want_trials=True, hypothesis=_lib.RANSAC_HORN)
     for p, (P, Q, T, mask) in enumerate(sets):
         ref = oracle.ransac_pair(P, Q, 2000, 0.01, seed=99, pair_id=p)
         r = res[p]
@@ -58,7 +63,7 @@ def test_device_sampling_matches_oracle_draws(ws, oracle):
         assert np.array_equal(r["inlier_ids"], np.nonzero(mask)[0]) and np.array_equal(r["inlier_ids"], ref["inlier_ids"])
         e = S.pose_error(r["best_pose"], T)
         assert e[0] < 0.05 and e[1] < 0.005
-    again = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=99, want_trials=True)
+    again = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=99, want_trials=True, hypothesis=_lib.RANSAC_HORN)
     for a, b in zip(res, again):                                                 # deterministic, bit for bit
         assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["poses"], b["poses"]) and a["best_trial"] == b["best_trial"]
 
@@ -91,3 +96,82 @@ def test_edge_cases_and_caller_logic(ws):
     run_ransac_multi_pair(ws, [(fa, fb), (fa, fc)], matches, n_trials=500, inlier_dist=0.01, seed=3)
     assert len(matches[(2, 1)][0]) == 64 and np.array_equal(matches[(2, 1)][0], pa[16:])
     assert len(matches[(2, 0)][0]) == 0
+
+
+def test_reference_hypotheses_match_the_reference_kernels(ws):
+    """The default hypothesis (BTBA_RANSAC_REFERENCE_SVD) against the reference's OWN procrustesKernel (with the pasted approximate
+    3x3 SVD) and evalPoseKernel, compiled for the CPU (oracle/_ref/libbtba_ref_ransac.so), on identical explicit sample triples:
+    every trial's pose within 1e-6, every trial's inlier count identical, the same winner, the same inlier list -- on planted
+    sets, on 3-point samples with 1 cm noise (where the approximate SVD is furthest from the Kabsch optimum), and with degenerate
+    triples in the list."""
+    from oracle import reference as R
+    if not os.path.exists(R.SO_RANSAC):
+        pytest.skip("oracle/_ref/libbtba_ref_ransac.so not built")
+    from bundletrack_amd.ransac import ransac_multi_pair
+    rng = np.random.default_rng(15)
+    sets = [planted(rng, n, f) for n, f in ((12, 0.0), (60, 0.3), (300, 0.5), (700, 0.2))]
+    noisy = planted(rng, 300, 0.1)
+    noisy = (noisy[0], (noisy[1] + rng.normal(size=noisy[1].shape).astype(np.float32) * 0.01).astype(np.float32), noisy[2], noisy[3])
+    sets.append(noisy)
+    n_trials = 384
+    smp = np.stack([rng.integers(0, len(s[0]), size=(n_trials, 3)) for s in sets]).astype(np.int32)
+    smp[:, 0] = [[0, 0, 1]] * len(sets); smp[:, 1, 1] = -1                      # skipped like ransacEstimateModelKernel skips them (:1164-1165)
+    res = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=n_trials, inlier_dist=0.01, samples=smp, want_trials=True)
+    worst = 0.0
+    for p, (P, Q, T, mask) in enumerate(sets):
+        r = res[p]
+        want_cnt = np.zeros(n_trials, np.int64)
+        want_pose = np.tile(np.eye(4, dtype=np.float32)[:3], (n_trials, 1, 1))
+        for t in range(n_trials):
+            i = smp[p, t]
+            if len(set(i.tolist())) < 3 or (i < 0).any():
+                continue
+            ok, pose = R.procrustes(P[i], Q[i])
+            if ok:
+                want_pose[t] = pose[:3]
+                want_cnt[t] = len(R.eval_pose(P, Q, pose, 0.01))
+        worst = max(worst, float(np.abs(r["poses"] - want_pose).max()))
+        assert np.abs(r["poses"] - want_pose).max() <= 1e-6
+        assert np.array_equal(r["counts"].astype(np.int64), want_cnt)
+        best = int(np.argmax(want_cnt)) if want_cnt.max() > 0 else -1           # most inliers, lowest trial id among equals
+        assert r["best_trial"] == best
+        if best >= 0:
+            pose4 = np.vstack([want_pose[best], [0, 0, 0, 1]]).astype(np.float32)
+            assert np.array_equal(r["inlier_ids"], R.eval_pose(P, Q, pose4, 0.01))
+    print(f"reference-exact hypotheses: worst |pose - procrustesKernel| over {len(sets) * n_trials} trials = {worst:.1e}")
+
+
+def test_device_resident_ransac_equals_the_host_buffer_form(ws):
+    """btba_ransac_pairs_ex(device_resident = 1): points and results stay on the GPU; same bits as the host-buffer call."""
+    import torch
+    from bundletrack_amd.ransac import pack_points, ransac_packed, ransac_packed_device
+    rng = np.random.default_rng(16)
+    sets = [planted(rng, n, f) for n, f in ((40, 0.25), (300, 0.4), (900, 0.3))]
+    a_all, b_all, n_pts = pack_points([s[0] for s in sets], [s[1] for s in sets])
+    host = ransac_packed(ws, a_all, b_all, n_pts, n_trials=1000, inlier_dist=0.01, seed=5)
+    dev = torch.device("cuda:0")
+    ids, n_in, best, pose = ransac_packed_device(ws, torch.from_numpy(a_all).to(dev), torch.from_numpy(b_all).to(dev), n_pts, n_trials=1000, inlier_dist=0.01, seed=5)
+    ws.sync()
+    ids, n_in, best, pose = ids.cpu().numpy(), n_in.cpu().numpy(), best.cpu().numpy(), pose.cpu().numpy()
+    o = 0
+    for p, h in enumerate(host):
+        assert n_in[p] == len(h["inlier_ids"]) and np.array_equal(ids[o:o + n_in[p]], h["inlier_ids"])
+        assert best[p] == h["best_trial"] and np.array_equal(pose[p].reshape(4, 4), h["best_pose"])
+        o += int(n_pts[p])
+
+
+def test_horn_and_reference_hypotheses_pick_the_same_inliers_on_tracker_size_pairs(ws):
+    """2 000 trials on tracker-size pairs (300 matches, 5-30 % gross outliers, 1 mm noise): the exact Kabsch hypotheses and the
+    reference's approximate-SVD hypotheses end with the same inlier set (the winning trial may differ)."""
+    from bundletrack_amd import _lib
+    from bundletrack_amd.ransac import ransac_multi_pair
+    rng = np.random.default_rng(17)
+    sets = []
+    for f in (0.05, 0.1, 0.2, 0.3):
+        P, Q, T, mask = planted(rng, 300, f)
+        Q = (Q + rng.normal(size=Q.shape).astype(np.float32) * 0.001 * mask[:, None]).astype(np.float32)
+        sets.append((P, Q, T, mask))
+    a = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=7)
+    b = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=7, hypothesis=_lib.RANSAC_HORN)
+    for (P, Q, T, mask), ra, rb in zip(sets, a, b):
+        assert np.array_equal(ra["inlier_ids"], rb["inlier_ids"]) and np.array_equal(ra["inlier_ids"], np.nonzero(mask)[0])

@@ -3,6 +3,8 @@
 projective association and point-to-plane rows) compiled for the CPU where they lie under /root/reference
 (oracle/ref_driver.cpp, oracle/ref_shim/, `make -C oracle ref` -> oracle/_ref/libbtba_ref.so) and called on the same
 inputs as oracle/btba_oracle.c.  Skipped where neither the built library nor the reference checkout exists."""
+import os
+
 import numpy as np
 import pytest
 
@@ -229,6 +231,49 @@ def test_pair_orientation_follows_the_reference_address_compare(oracle, rank):
     if rank is not None:
         lower = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, want_trace=False).poses
         assert max(max(S.pose_error(lower[k], ref[k])) for k in range(N)) > 3e-4       # a different orientation is a different problem
+
+
+def _procrustes_cases(n_cases, seed):
+    rng = np.random.default_rng(seed)
+    for trial in range(n_cases):
+        n = 3 if trial % 4 else int(rng.integers(3, 12))
+        src = (rng.normal(size=(n, 3)) * rng.choice([1e-3, 0.01, 0.1, 1.0, 30.0])).astype(np.float32)
+        ang = rng.normal(size=3); th = np.linalg.norm(ang); k = ang / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        Rm = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        dst = (src @ Rm.T + rng.normal(size=3) * 0.1 + rng.normal(size=(n, 3)) * rng.choice([0, 1e-3, 1e-2])).astype(np.float32)
+        if trial % 7 == 0: dst[:, 2] = -dst[:, 2]                                        # a reflection: det(V U^T) < 0
+        if trial % 11 == 0: src[2] = 2 * src[1] - src[0]; dst[2] = 2 * dst[1] - dst[0]   # collinear samples
+        if trial % 13 == 0: src[:] = src[0]                                              # all points equal: S = 0
+        yield src, dst
+
+
+def test_reference_procrustes_restatements_are_bit_exact(oracle):
+    """procrustesKernel with the reference's pasted approximate 3x3 SVD (cuda_ransac.cu:48-975, 998-1103), run by the reference's own
+    code (oracle/_ref/libbtba_ref_ransac.so), against the two restatements of it: the oracle's (oracle/btba_oracle_ransac.c,
+    orc_procrustes_reference) and the PRODUCT's (bundletrack_amd/csrc/btba_svd3.hpp, compiled here for the host with g++ -- the same
+    header k_ransac_vote includes).  Bit for bit, including the return flag, on 3-point and n-point sets, reflections, collinear and
+    coincident samples, scales from 1e-3 to 30."""
+    import ctypes as C, subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so, src_cpp = os.path.join(here, "cpp", "libsvd3_host.so"), os.path.join(here, "cpp", "svd3_host.cpp")
+    hdr = os.path.join(os.path.dirname(here), "bundletrack_amd", "csrc", "btba_svd3.hpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src_cpp), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-o", so, src_cpp])
+    f = C.CDLL(so).procrustes_reference_host
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]; f.restype = C.c_int
+    n_fail = 0
+    for src, dst in _procrustes_cases(4000, 3):
+        ok_r, pose_r = R.procrustes(src, dst)
+        ok_o, pose_o = oracle.procrustes_reference(src, dst)
+        assert ok_o == ok_r and np.array_equal(pose_o.view(np.uint32), pose_r.view(np.uint32))
+        s4 = np.ascontiguousarray(np.concatenate([src, np.ones((len(src), 1), np.float32)], 1), np.float32)
+        d4 = np.ascontiguousarray(np.concatenate([dst, np.ones((len(dst), 1), np.float32)], 1), np.float32)
+        mine = np.zeros(16, np.float32)
+        ok_m = bool(f(s4.ctypes.data, d4.ctypes.data, len(src), mine.ctypes.data))
+        assert ok_m == ok_r and np.array_equal(mine.reshape(4, 4).view(np.uint32), pose_r.view(np.uint32))
+        n_fail += not ok_r
+    print(f"'R is not valid' returned by the reference on {n_fail} of 4000 cases")
 
 
 def test_frame_cache_matches_reference_kernels(oracle):
