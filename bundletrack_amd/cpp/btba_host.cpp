@@ -44,6 +44,7 @@ void OptimizerGpu::optimizeFrames(const std::vector<EntryJ> &global_corres, cons
     int rc;
     if (persistent_frame_cache) {
         if ((int)frame_ids.size() != n_frames) throw Error(BTBA_EINVAL, "optimizeFrames: frame_ids");
+        if (keyed_correspondences) prm.flags |= BTBA_FLAG_KEYED_CORR;
         rc = btba_optimize_frames_keyed(ws_, &prm, n_frames, H, W, Krm, global_corres.data(), (uint32_t)global_corres.size(), nm,
                                         depth.data(), nrm.data(), frame_ids.data(), nullptr, 0, P.data(), &last_stats);
     } else {

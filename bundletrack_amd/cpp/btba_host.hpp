@@ -64,6 +64,7 @@ public:
     btba_stats last_stats{};
     bool persistent_frame_cache = false;         // hand frame ids to btba_optimize_frames_keyed (needs frame_ids below)
     std::vector<uint64_t> frame_ids;             // Frame::_id of every window frame, when persistent_frame_cache is set
+    bool keyed_correspondences = false;          // with persistent_frame_cache: pair segments stay on the device too (BTBA_FLAG_KEYED_CORR)
 
     // The reference runs the whole path on the legacy NULL stream (no explicit streams anywhere in src/cuda), so the drop-in
     // does too: depth / normal maps produced by earlier default-stream work are ordered before the cache build.  A caller with

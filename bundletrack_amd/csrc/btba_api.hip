@@ -12,6 +12,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <new>
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -78,6 +79,13 @@ struct btba_workspace {
     // live in pool slots that survive across calls; a keyframe is cached once, not once per BA call.
     struct FrameSlot { uint64_t key = 0; const float *depth = nullptr, *normal = nullptr; uint64_t stamp = 0; bool live = false; int32_t n_valid = 0; };
     DevBuf pool_zn, pool_lists, pool_counts, pool_nvalid, pool_map;
+    // keyed correspondence cache (BTBA_FLAG_KEYED_CORR): the EntryJ segment of a frame PAIR stays on the device under the pair's two
+    // frame keys; a sliding window then uploads only the new frame's K - 1 segments
+    struct CorrSeg { uint32_t off = 0, count = 0; };
+    DevBuf corr_pool, corr_desc;
+    std::map<std::pair<uint64_t, uint64_t>, CorrSeg> corr_index;
+    size_t corr_pool_used = 0;                              // in EntryJ
+    void *corr_stage = nullptr; size_t corr_stage_cap = 0;  // pinned host staging of the segments uploaded by one call
     DevBuf ransac;                                          // btba_ransac_pairs staging (points, samples, per-trial poses and counts, results)
     std::vector<FrameSlot> pool_slots;
     int pool_H = 0, pool_W = 0, pool_npix = 0;
@@ -165,8 +173,9 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A, &ws->solve_tab,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts,
-                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->ransac };
+                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->ransac, &ws->corr_pool, &ws->corr_desc };
     for (auto b : bufs) b->release();
+    if (ws->corr_stage) (void)hipHostFree(ws->corr_stage);
     if (ws->aux_stream) (void)hipStreamDestroy(ws->aux_stream);
     if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
     if (ws->ev_join) (void)hipEventDestroy(ws->ev_join);
@@ -763,15 +772,82 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     auto hip_fail = [&](hipError_t e) { g_last_hip_error = (int)e; return finish(BTBA_EHIP); };
     hipError_t e;
     std::vector<float> stage(16 * (size_t)N + 1);             // poses + one word for the device's "not pair-major" flag (0)
+    // Keyed correspondence cache: with frame keys, the trusted pair-major layout and BTBA_FLAG_KEYED_CORR, a pair's segment is looked
+    // up under (key_i, key_j, count); only the segments not seen before cross PCIe (into the pool), then one small kernel gathers
+    // the window's P segments from the pool into the contiguous pair-major array the sweeps read, rewriting imgIdx_i / imgIdx_j to
+    // the frames' CURRENT window positions (they shift as the window slides) and checking the new segments' own indices.
+    int corr_pairs_uploaded = P;
+    // (below 1 MB the whole array crosses PCIe faster than the bookkeeping runs)
+    const char *kc_env = std::getenv("BTBA_KEYED_CORR_MIN_BYTES");        // tests lower the threshold
+    const size_t kc_min = kc_env ? (size_t)std::strtoull(kc_env, nullptr, 10) : ((size_t)1 << 20);
+    bool use_corr_cache = frame_keys != nullptr && trust && ws_in && (prm.flags & BTBA_FLAG_KEYED_CORR) && kept > 0 && (size_t)kept * sizeof(btba_entryj) >= kc_min;
+    std::vector<uint32_t> desc;                                 // outlives the asynchronous copy (the call ends with a synchronisation)
     auto upload_inputs = [&]() -> hipError_t {
         hipError_t r;
-        if (kept && (r = hipMemcpyAsync(ws->corr.p, upload, sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+        if (use_corr_cache && trust) {
+            desc.assign(4 * (size_t)P, 0u);                        // per pair: source offset in the pool, destination offset, length, (i << 16 | j) | fresh << 31
+            size_t need = 0;
+            for (int pass = 0; pass < 2; pass++) {                  // pass 1 only after the pool had to be reset
+                need = 0;
+                int q = 0;
+                for (int i = 0; i < N; i++)
+                    for (int j = i + 1; j < N; j++, q++) {
+                        const uint32_t cnt = offsets[q + 1] - offsets[q];
+                        auto it = ws->corr_index.find({ frame_keys[i], frame_keys[j] });
+                        if (cnt && (it == ws->corr_index.end() || it->second.count != cnt)) need += cnt;
+                    }
+                const size_t cap = ws->corr_pool.cap / sizeof(btba_entryj);
+                if (ws->corr_pool_used + need <= cap) break;
+                // does not fit: start over with an empty pool (sized for a few windows) -- this call then uploads everything once
+                ws->corr_index.clear();
+                ws->corr_pool_used = 0;
+                if (int rc2 = ws->corr_pool.ensure(sizeof(btba_entryj) * std::max<size_t>(16 * (size_t)kept, 1u << 20))) { (void)rc2; return hipErrorOutOfMemory; }      // ~16 windows' worth: resets are rare
+            }
+            corr_pairs_uploaded = 0;
+            // the new segments are packed into ONE pinned staging buffer and cross PCIe in one copy (a pageable hipMemcpyAsync per
+            // segment costs ~10 us each: 14 of them were as slow as uploading everything)
+            if (need * sizeof(btba_entryj) > ws->corr_stage_cap) {
+                if (ws->corr_stage) (void)hipHostFree(ws->corr_stage);
+                ws->corr_stage = nullptr; ws->corr_stage_cap = 0;
+                const size_t want = std::max<size_t>(2 * need * sizeof(btba_entryj), 1u << 20);
+                if ((r = hipHostMalloc(&ws->corr_stage, want, hipHostMallocDefault)) != hipSuccess) return r;
+                ws->corr_stage_cap = want;
+            }
+            const size_t pool_base = ws->corr_pool_used;
+            size_t staged = 0;
+            int q = 0;
+            for (int i = 0; i < N; i++)
+                for (int j = i + 1; j < N; j++, q++) {
+                    const uint32_t cnt = offsets[q + 1] - offsets[q];
+                    uint32_t src = 0, fresh = 0;
+                    if (cnt) {
+                        auto key = std::make_pair(frame_keys[i], frame_keys[j]);
+                        auto it = ws->corr_index.find(key);
+                        if (it == ws->corr_index.end() || it->second.count != cnt) {
+                            src = (uint32_t)(pool_base + staged);
+                            std::memcpy(static_cast<btba_entryj *>(ws->corr_stage) + staged, corres_host + offsets[q], sizeof(btba_entryj) * cnt);
+                            staged += cnt;
+                            ws->corr_index[key] = btba_workspace::CorrSeg{ src, cnt };
+                            corr_pairs_uploaded++;
+                            fresh = 1;
+                        } else src = it->second.off;
+                    }
+                    desc[4 * (size_t)q] = src; desc[4 * (size_t)q + 1] = offsets[q]; desc[4 * (size_t)q + 2] = cnt; desc[4 * (size_t)q + 3] = ((uint32_t)i << 16) | (uint32_t)j | (fresh << 31);
+                }
+            if (staged && (r = hipMemcpyAsync(ws->corr_pool.as<btba_entryj>() + pool_base, ws->corr_stage, sizeof(btba_entryj) * staged, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+            ws->corr_pool_used += staged;
+            if (ws->corr_desc.ensure(sizeof(uint32_t) * desc.size()) != BTBA_OK) return hipErrorOutOfMemory;
+            if ((r = hipMemcpyAsync(ws->corr_desc.p, desc.data(), sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+        } else if (kept && (r = hipMemcpyAsync(ws->corr.p, upload, sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
         if ((r = hipMemcpyAsync(ws->offsets.p, offsets.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
         std::memcpy(stage.data(), poses, sizeof(float) * 16 * N);
         stage[16 * (size_t)N] = 0.0f;
         return hipMemcpyAsync(ws->poses.p, stage.data(), sizeof(float) * stage.size(), hipMemcpyHostToDevice, ws->stream);
     };
     if ((e = upload_inputs()) != hipSuccess) return hip_fail(e);
+    if (use_corr_cache && trust)
+        k_gather_corr<<<P, 256, 0, ws->stream>>>(ws->corr_desc.as<uint4>(), reinterpret_cast<const uint4 *>(ws->corr_pool.p), reinterpret_cast<uint4 *>(ws->corr.p),
+                                                 reinterpret_cast<int *>(ws->poses.as<float>() + 16 * (size_t)N));
     // the sources (caller's arrays, `offsets`, `scattered`, `stage`) outlive the synchronising end of this call; the sync only serves the upload timer
     if ((prm.flags & BTBA_FLAG_TIME_KERNELS) && (e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
     const auto tu1 = std::chrono::steady_clock::now();
@@ -853,6 +929,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
         if (flag) {
             // the array was not pair-major after all: bucket it on the host and solve again from the caller's poses
             trust = false;
+            if (use_corr_cache) { ws->corr_index.clear(); ws->corr_pool_used = 0; use_corr_cache = false; corr_pairs_uploaded = P; }
             if ((rc = bucket_on_host())) { ws->always_time_region = false; return finish(rc); }
             max_per_pair = longest_segment();
             if ((rc = ws->corr.ensure(sizeof(btba_entryj) * (size_t)(kept ? kept : 1)))) { ws->always_time_region = false; return finish(rc); }
@@ -867,6 +944,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     if (stats) {
         S.n_corr = kept;
         S.cache_frames_built = n_built;
+        S.corr_pairs_uploaded = corr_pairs_uploaded;
         S.bytes_sparse_alg = (int64_t)32 * kept;
         S.ms_upload = std::chrono::duration<float, std::milli>(tu1 - tu0).count();
         S.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -898,6 +976,8 @@ int btba_frame_cache_clear(btba_workspace *ws)
 {
     if (!ws) return BTBA_EINVAL;
     for (auto &sl : ws->pool_slots) sl = btba_workspace::FrameSlot{};
+    ws->corr_index.clear();
+    ws->corr_pool_used = 0;
     return BTBA_OK;
 }
 
@@ -905,6 +985,8 @@ int btba_frame_cache_evict(btba_workspace *ws, uint64_t frame_key)
 {
     if (!ws) return BTBA_EINVAL;
     for (auto &sl : ws->pool_slots) if (sl.live && sl.key == frame_key) sl = btba_workspace::FrameSlot{};
+    for (auto it = ws->corr_index.begin(); it != ws->corr_index.end();)          // its correspondence segments go with it (the pool space is reclaimed at the next reset)
+        it = (it->first.first == frame_key || it->first.second == frame_key) ? ws->corr_index.erase(it) : std::next(it);
     return BTBA_OK;
 }
 

@@ -249,6 +249,30 @@ __global__ void __launch_bounds__(kBlock) k_pack_zn(size_t total, const float4 *
     zn[o] = make_float4(c.z, nr.x, nr.y, nr.z);
 }
 
+// ---- keyed correspondence cache: gather the window's pair segments from the pool ------------------------------------
+// grid (P) x 256.  desc[p] = (source offset in the pool, destination offset, length, i << 16 | j | fresh << 31), offsets in EntryJ.
+// An EntryJ is two uint4: (imgIdx_i, imgIdx_j, pos_i.x, pos_i.y) (pos_i.z, pos_j.xyz).  The indices are rewritten to the frames'
+// current window positions; a FRESH segment (uploaded by this call) whose valid entries do not carry (i, j) raises the order flag
+// (the caller's array was not pair-major: host bucketing takes over).  Invalid entries (imgIdx_i = 0xFFFFFFFF) stay invalid.
+__global__ void __launch_bounds__(256) k_gather_corr(const uint4 *__restrict__ desc, const uint4 *__restrict__ pool, uint4 *__restrict__ out, int *__restrict__ order_flag)
+{
+    const uint4 d = desc[blockIdx.x];
+    const uint32_t i = (d.w >> 16) & 0x7FFFu, j = d.w & 0xFFFFu;
+    const bool fresh = (d.w >> 31) != 0;
+    bool misplaced = false;
+    for (uint32_t e = threadIdx.x; e < d.z; e += 256) {
+        uint4 a = pool[2 * (size_t)(d.x + e)];
+        const uint4 b = pool[2 * (size_t)(d.x + e) + 1];
+        const bool valid = a.x != 0xFFFFFFFFu;
+        misplaced |= fresh & valid & ((a.x != i) | (a.y != j));
+        a.x = valid ? i : a.x;
+        a.y = valid ? j : a.y;
+        out[2 * (size_t)(d.y + e)] = a;
+        out[2 * (size_t)(d.y + e) + 1] = b;
+    }
+    if (misplaced) atomicOr(order_flag, 1);
+}
+
 // ---- sparse sweep -----------------------------------------------------------------------------
 // grid (sparse_chunks, P, B).  Workgroup (c, p, b) owns slice c of pair p's contiguous EntryJ
 // segment: two coalesced 16-byte loads per correspondence, 44 register accumulators per lane.

@@ -99,8 +99,9 @@ class OptimizerGpu:
     here `yml` may be a nested dict with the same keys (bundle.num_iter_outter, ...,
     p2p.max_dist, p2p.max_normal_angle) or None for the shipping defaults."""
 
-    def __init__(self, yml: dict | None = None, workspace: Workspace | None = None, **overrides):
+    def __init__(self, yml: dict | None = None, workspace: Workspace | None = None, keyed_correspondences: bool = False, **overrides):
         self.params = default_params()
+        self.keyed_correspondences = bool(keyed_correspondences)      # with frame_keys: keep pair segments on the device (BTBA_FLAG_KEYED_CORR)
         if yml:
             b, p = yml.get("bundle", {}), yml.get("p2p", {})
             if "num_iter_outter" in b: self.params.n_gn_iters = int(b["num_iter_outter"])
@@ -153,7 +154,13 @@ class OptimizerGpu:
                 raise ValueError("need one key per frame")
             if self.workspace is None:
                 raise ValueError("the persistent frame cache lives in a Workspace: construct OptimizerGpu(workspace=...)")
-            rc = lib().btba_optimize_frames_keyed(*head, keys.ctypes.data, *tail)
+            flags0 = self.params.flags
+            if self.keyed_correspondences:
+                self.params.flags |= _lib.FLAG_KEYED_CORR
+            try:
+                rc = lib().btba_optimize_frames_keyed(*head, keys.ctypes.data, *tail)
+            finally:
+                self.params.flags = flags0
         check(rc, "btba_optimize_frames")
         self.last_stats = st.as_dict()
         out = P.reshape(n_frames, 4, 4)

@@ -77,6 +77,12 @@ enum {
                                        overlaps the other half's sweeps; per-kernel timings then overlap too (+4 % at c3 x 32) */
     BTBA_FLAG_NO_FUSE       = 64,   /* launch the sparse and the dense sweep separately (default: ONE interleaved launch) */
     BTBA_FLAG_FLOAT4_CACHE  = 256,  /* btba_optimize_frames: build the reference-layout float4 cache instead of the compact one */
+    BTBA_FLAG_KEYED_CORR    = 128,  /* btba_optimize_frames_keyed: keep every frame PAIR's correspondence segment on the device under the
+                                       pair's two frame keys and upload only segments not seen before (in a sliding window: the new
+                                       frame's n_frames - 1 pairs).  CONTRACT: the correspondences of a pair do not change while both
+                                       frames stay cached -- the reference never recomputes a pair's matches either (findCorres returns
+                                       early when _matches holds the pair, FeatureManager.cpp:176) -- and n_match_per_pair is given.  A
+                                       segment whose length changed is uploaded again; btba_frame_cache_evict / _clear drop segments */
     BTBA_FLAG_NO_COMPACTION = 512,  /* compact cache: always walk all Wd x Hd source pixels                        */
     BTBA_FLAG_COMPACTION    = 1024  /* compact cache: walk each source frame's ordered list of pixels that carry a depth
                                        (masked scenes).  btba_optimize_frames decides by itself from the valid-pixel counts
@@ -130,6 +136,7 @@ typedef struct btba_stats {
     int64_t bytes_sparse_alg;     /* algorithmic bytes of ONE sparse sweep launch (32 * C)             */
     int32_t fused_sweeps;         /* 1: sparse + dense sweeps ran as ONE launch (timed as ms_dense_sweep) */
     int32_t cache_frames_built;   /* optimize_frames: frames cached in this call (n_frames unless keyed and already cached) */
+    int32_t corr_pairs_uploaded;  /* optimize_frames: frame-pair segments that crossed PCIe in this call (all P unless BTBA_FLAG_KEYED_CORR) */
 } btba_stats;
 
 /* Per-instance, per-GN-iteration trace record (floats), written when BTBA_FLAG_TRACE is set.

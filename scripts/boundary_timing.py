@@ -30,6 +30,20 @@ def main():
             assert rep == 0 or opt.last_stats["cache_frames_built"] == 1
         st_keyed = opt.last_stats
         opt.params.flags &= ~_lib.FLAG_TIME_KERNELS
+        # ... and with the pairs' correspondence segments kept on the device as well (BTBA_FLAG_KEYED_CORR): only the new frame's K - 1 segments cross PCIe
+        opt_c = OptimizerGpu(workspace=Workspace(), keyed_correspondences=True)
+        walls_kc, ref_poses = [], None
+        for rep in range(30):
+            poses = pb.poses_init.copy()
+            keys = list(range(K - 1)) + [1000 + rep]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            opt_c.optimizeFrames(pb.corr, pb.n_match_per_pair, K, pb.H, pb.W, depths, None, normals, poses, pb.K, frame_keys=keys)
+            dt = time.perf_counter() - t0
+            if rep >= 5: walls_kc.append(dt)
+            assert rep == 0 or opt_c.last_stats["corr_pairs_uploaded"] in (K - 1, K * (K - 1) // 2), opt_c.last_stats      # all pairs: below the 1 MB threshold, or a pool reset
+            ref_poses = poses
+        poses_kc = ref_poses
         for timed in (False, True):
             if timed: opt.params.flags |= _lib.FLAG_TIME_KERNELS
             for rep in range(25):
@@ -46,6 +60,8 @@ def main():
                          wall_ms_median=round(float(np.median(walls)), 4), wall_ms_min=round(float(walls.min()), 4),
                          gn_iters_per_s=round(7e3 / float(np.median(walls)), 1),
                          wall_ms_median_keyed=round(float(np.median(np.array(walls_keyed) * 1e3)), 4),
+                         wall_ms_median_keyed_frames_and_correspondences=round(float(np.median(np.array(walls_kc) * 1e3)), 4),
+                         keyed_correspondences_same_bits=bool(np.array_equal(poses_kc, poses)),
                          stats_ms={k: round(float(v), 4) for k, v in st.items() if k.startswith("ms_")},
                          stats_ms_keyed={k: round(float(v), 4) for k, v in st_keyed.items() if k.startswith("ms_")},
                          entryj_bytes=int(len(pb.corr)) * 32, err_vs_gt=float(err)))

@@ -153,6 +153,23 @@ def test_session_with_persistent_frame_cache_is_identical():
     for x, y in zip(fa, fb):
         assert np.array_equal(x.pose_in_model, y.pose_in_model)
     assert built[0] == 2 and all(c == 1 for c in built[1:]), built      # first call: frames 0 and 1; afterwards only the new frame
+    # ... and with the pairs' correspondence segments kept on the device too (BTBA_FLAG_KEYED_CORR): still the same bits, and after
+    # the first call only the NEW frame's pairs (window size - 1 segments) cross PCIe (the library skips the bookkeeping below 1 MB
+    # of correspondences; the environment variable lowers that threshold for this small session)
+    os.environ["BTBA_KEYED_CORR_MIN_BYTES"] = "0"
+    c_opt = OptimizerGpu(workspace=Workspace(), keyed_correspondences=True)
+    uploaded, window = [], []
+    orig_c = c_opt.optimizeFrames
+    def counting_c(*a, **k):
+        r = orig_c(*a, **k); uploaded.append(c_opt.last_stats["corr_pairs_uploaded"]); window.append(c_opt.last_stats["n_frames"]); return r
+    c_opt.optimizeFrames = counting_c
+    _, _, fc, _ = run_session(c_opt, n, to_device=up, persistent_frame_cache=True)
+    for x, y in zip(fa, fc):
+        assert np.array_equal(x.pose_in_model, y.pose_in_model)
+    os.environ.pop("BTBA_KEYED_CORR_MIN_BYTES", None)
+    # at least the new frame's w - 1 pairs; more only when the keyframe selection brings two old frames together for the first time
+    odd = [(k, u, w) for k, (u, w) in enumerate(zip(uploaded, window)) if u != w - 1]
+    assert uploaded[0] == 1 and all(w - 1 <= u <= w * (w - 1) // 2 for u, w in zip(uploaded, window)) and len(odd) <= len(uploaded) // 5, odd
 
 
 @pytest.mark.gpu
