@@ -235,7 +235,7 @@ def main():
     ws = Workspace()
     bs = BatchSolver(ws, weight_dense_depth=cfg["w_dense"])
     if not args.no_kernel_timing:
-        bs.params.flags |= _lib.FLAG_TIME_KERNELS
+        bs.params.flags |= _lib.FLAG_TIME_KERNELS | _lib.FLAG_TIME_SAMPLED      # one Gauss-Newton iteration of every solve is bracketed with hipEvents (rotating): every launch costs ~4 %
     bs.params.flags |= int(os.environ.get("BTBA_BENCH_FLAGS", "0"))          # developer A/B of tuning flags
     bs.params.dense_tiles = int(os.environ.get("BTBA_BENCH_TILES", "0"))     # 0 = the library's choice
     if args.masked and not args.float4_cache:
@@ -344,12 +344,16 @@ def main():
             if world == 1:
                 copy_bw = measured_copy_bandwidth(torch, dev)
                 res["roofline"]["hbm_algorithmic"]["peak_measured_copy_GBps"] = round(copy_bw, 1)
-            sweeps_ms = (st["ms_dense_sweep"] + st["ms_sparse_sweep"]) / args.steps
+            # per-step kernel time = average timed launch x launches per step (one iteration of every solve is timed)
+            n_it = int(bs.params.n_gn_iters)
+            per_step = lambda ms, n: ms / max(n, 1) * n_it
             res["kernels_ms_per_step"] = {
-                "sweeps": round(sweeps_ms, 4), "fused_sweeps": fused,            # fused: ONE launch per iteration carries both sweeps
-                "dense_sweep": None if fused else round(st["ms_dense_sweep"] / args.steps, 4),
-                "sparse_sweep": None if fused else round(st["ms_sparse_sweep"] / args.steps, 4),
-                "system_solve": round(st["ms_system_solve"] / args.steps, 4), "solve_region": round(st["ms_solve"] / args.steps, 4),
+                "fused_sweeps": fused,            # fused: ONE launch per iteration carries both sweeps
+                "sweeps": round(per_step(st["ms_dense_sweep"], st["n_dense_launches"]) + per_step(st["ms_sparse_sweep"], st["n_sparse_launches"]), 4),
+                "dense_sweep": None if fused else round(per_step(st["ms_dense_sweep"], st["n_dense_launches"]), 4),
+                "sparse_sweep": None if fused else round(per_step(st["ms_sparse_sweep"], st["n_sparse_launches"]), 4),
+                "system_solve": round(per_step(st["ms_system_solve"], st["n_solve_launches"]), 4), "solve_region": round(st["ms_solve"] / args.steps, 4),
+                "launches_timed": {"sweep": st["n_dense_launches"], "system_solve": st["n_solve_launches"], "of_per_step": n_it},
                 "sparse_alg_GBps": (round(32 * n_corr / max(st["ms_sparse_sweep"] / max(st["n_sparse_launches"], 1), 1e-9) / 1e6, 1) if st["n_sparse_launches"] else None)}
         elif cfg["w_dense"] == 0.0 and not args.no_kernel_timing and st["n_sparse_launches"] > 0:
             avg_ms = st["ms_sparse_sweep"] / st["n_sparse_launches"]

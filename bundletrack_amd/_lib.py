@@ -22,7 +22,7 @@ PAIRS_TARGET_LOWER, PAIRS_TARGET_MORE_VALID, PAIRS_EXPLICIT, PAIRS_TARGET_HIGHER
 REDUCE_DETERMINISTIC, REDUCE_ATOMIC = 0, 1
 RANSAC_REFERENCE_SVD, RANSAC_HORN = 0, 1
 FLAG_TRACE, FLAG_TIME_KERNELS = 1, 2
-FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_KEYED_CORR, FLAG_FLOAT4_CACHE, FLAG_NO_COMPACTION, FLAG_COMPACTION = 32, 64, 128, 256, 512, 1024
+FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_KEYED_CORR, FLAG_FLOAT4_CACHE, FLAG_NO_COMPACTION, FLAG_COMPACTION, FLAG_TIME_SAMPLED = 32, 64, 128, 256, 512, 1024, 2048
 
 ENTRYJ_DTYPE = np.dtype(
     [("imgIdx_i", "<u4"), ("imgIdx_j", "<u4"), ("pos_i", "<f4", (3,)), ("pos_j", "<f4", (3,))]

@@ -64,6 +64,7 @@ struct btba_workspace {
     DevBuf x, T, Tinv, sparse_part, dense_part, pairsum, dense_pairs, ptrs, big_A, solve_tab;
     DevBuf corr, offsets, poses, campos, normals, nvalid;   // optimize_frames staging
     DevBuf valid_lists, valid_counts;                       // per-frame lists of pixels with a depth (compact cache)
+    DevBuf block_ranges;                                    // per (frame, 8 x 8 block) usable depth range: dead-block test of the dense sweep
     std::vector<int32_t> dense_pairs_host;                  // what dense_pairs currently holds
     int dense_pairs_frames = -1;
     int solve_tab_frames = -1;                              // window size solve_tab was built for
@@ -72,8 +73,10 @@ struct btba_workspace {
     btba_stats stats{};
     bool lds_attr_set = false;
     bool always_time_region = false;   // optimize_frames: ms_solve is part of its stats contract
-    hipStream_t aux_stream = nullptr;  // second half of a batch runs here (software pipelining across instances)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_order = nullptr;
+    static constexpr int kMaxGroups = 8;
+    uint64_t solves_enqueued = 0;      // rotates the sampled iteration of BTBA_FLAG_TIME_SAMPLED
+    hipStream_t aux_streams[kMaxGroups - 1] = {};  // groups 1 .. G-1 of a batch run here (software pipelining across instances)
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {}, ev_order = nullptr;
 
     // persistent frame cache (btba_optimize_frames_keyed): compact (z, n) frames, their valid-pixel lists and counts
     // live in pool slots that survive across calls; a keyframe is cached once, not once per BA call.
@@ -172,13 +175,13 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto &ep : ws->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A, &ws->solve_tab,
-                       &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts,
+                       &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts, &ws->block_ranges,
                        &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->ransac, &ws->corr_pool, &ws->corr_desc };
     for (auto b : bufs) b->release();
     if (ws->corr_stage) (void)hipHostFree(ws->corr_stage);
-    if (ws->aux_stream) (void)hipStreamDestroy(ws->aux_stream);
+    for (auto st : ws->aux_streams) if (st) (void)hipStreamDestroy(st);
     if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
-    if (ws->ev_join) (void)hipEventDestroy(ws->ev_join);
+    for (auto e : ws->ev_join) if (e) (void)hipEventDestroy(e);
     if (ws->ev_order) (void)hipEventDestroy(ws->ev_order);
     if (ws->owns_stream) (void)hipStreamDestroy(ws->stream);
     delete ws;
@@ -366,6 +369,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     const int chunks = use_sparse ? pick_chunks(prm, B, P, max_corr_per_pair) : 1;
     const int tiles = use_dense ? pick_tiles(prm, B, Pd, npix, use_zn && (prm->flags & BTBA_FLAG_COMPACTION)) : 1;
     const bool timing = (prm->flags & BTBA_FLAG_TIME_KERNELS) != 0;
+    const int timed_iteration = (prm->flags & BTBA_FLAG_TIME_SAMPLED) ? (int)(ws->solves_enqueued++ % (uint64_t)std::max(1, prm->n_gn_iters)) : -1;      // -1: all
 
     int rc;
     if ((rc = ws->x.ensure(sizeof(float) * 6 * (size_t)B * N))) return rc;
@@ -492,29 +496,48 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     }
     if (Z.frame_slot && B != 1) return BTBA_EINVAL;
     D.frame_slot = Z.frame_slot;
+    // block walk of the pinhole sweep: per-block depth ranges for its dead-block test, and the LDS it needs for the list of live blocks
+    size_t blist_bytes = 0;
+    if (D.walk_blocks && zn_layout == 1 && use_dense && !compaction) {
+        const int bw = Wd / 8, bh = Hd / 8;
+        blist_bytes = 32 + sizeof(uint32_t) * (size_t)((bh + tiles - 1) / tiles) * bw;
+        if (blist_bytes > 16384) { D.walk_blocks = 0; blist_bytes = 0; }        // very large caches: row strips
+        else if (!std::getenv("BTBA_NO_BLOCK_SKIP")) {                          // developer A/B: walk every block
+            if ((rc = ws->block_ranges.ensure(sizeof(float2) * (size_t)B * N * bw * bh))) return rc;
+            k_block_ranges<<<dim3((unsigned)((bw * bh + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)(B * N)), kBlock, 0, ws->stream>>>(Wd, Hd, prm->depth_min, prm->depth_max, reinterpret_cast<const float4 *>(Z.zn), Z.frame_slot, ws->block_ranges.as<float2>());
+            D.block_ranges = ws->block_ranges.as<float2>();
+        }
+    }
     // Software pipelining across instances: the batch is split in two halves on two streams, so one half's
     // latency-bound k_system_solve (B/2 workgroups on a 256-CU chip) and its sparse sweep overlap the other
     // half's dense sweep.  Halves never touch each other's data; fork/join events keep the caller's stream
     // ordering.  Small batches run as one piece.
-    const int n_halves = (B >= 8 && (prm->flags & BTBA_FLAG_OVERLAP)) ? 2 : 1;     // opt-in: measured gain only 4 % at c3 x 32
-    if (n_halves == 2 && !ws->aux_stream) {
-        // LOWEST priority: two equal-priority streams with identical kernel sequences just time-share the chip in
-        // lockstep (measured: no gain); with a priority gap the main half is never held up and the low-priority
-        // half fills the CUs the main half's k_system_solve / sparse sweep leave idle.
+    int n_halves = (B >= 8 && (prm->flags & BTBA_FLAG_OVERLAP)) ? 2 : 1;
+    if (n_halves == 2) if (const char *e = std::getenv("BTBA_GROUPS")) n_halves = std::max(1, std::min({ std::atoi(e), (int)btba_workspace::kMaxGroups, B / 2 }));
+    for (int g = 1; g < n_halves; g++) {
+        if (ws->aux_streams[g - 1]) continue;
+        // LOWEST priority by default: equal-priority streams with identical kernel sequences were measured to time-share the chip in
+        // lockstep; with a priority gap the main group is never held up and the others fill the CUs it leaves idle.
         int prio_least = 0, prio_greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        HIP_TRY(hipStreamCreateWithPriority(&ws->aux_stream, hipStreamNonBlocking, prio_least));
-        HIP_TRY(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming));
+        const char *pe = std::getenv("BTBA_GROUP_PRIO");
+        HIP_TRY(hipStreamCreateWithPriority(&ws->aux_streams[g - 1], hipStreamNonBlocking, (pe && pe[0] == 'e') ? 0 : prio_least));
+        HIP_TRY(hipEventCreateWithFlags(&ws->ev_join[g - 1], hipEventDisableTiming));
+        if (!ws->ev_fork) HIP_TRY(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
     }
-    struct Half { int b0, nb; hipStream_t st; } halves[2] = { { 0, n_halves == 2 ? B / 2 : B, ws->stream }, { B / 2, B - B / 2, ws->aux_stream } };
-    if (n_halves == 2) {
+    struct Half { int b0, nb; hipStream_t st; } halves[btba_workspace::kMaxGroups];
+    for (int g = 0; g < n_halves; g++) {
+        const int lo = (int)((long long)B * g / n_halves), hi = (int)((long long)B * (g + 1) / n_halves);
+        halves[g] = { lo, hi - lo, g == 0 ? ws->stream : ws->aux_streams[g - 1] };
+    }
+    if (n_halves > 1) {
         HIP_TRY(hipEventRecord(ws->ev_fork, ws->stream));
-        HIP_TRY(hipStreamWaitEvent(ws->aux_stream, ws->ev_fork, 0));
+        for (int g = 1; g < n_halves; g++) HIP_TRY(hipStreamWaitEvent(ws->aux_streams[g - 1], ws->ev_fork, 0));
     }
     const size_t pairsum_floats = lds_pairs / sizeof(float);
-    const size_t lut_bytes = sizeof(float) * (size_t)(Wd + Hd);         // coordinate look-up tables of the compact dense sweep
+    const size_t lut_bytes = sizeof(float) * (size_t)(Wd + Hd) + blist_bytes;         // coordinate look-up tables of the compact dense sweep (+ its list of live blocks)
     for (int it = 0; it < prm->n_gn_iters; it++) {
+        const bool timing_it = timing && (timed_iteration < 0 || timed_iteration == it);
         for (int h = 0; h < n_halves; h++) {
             const Half &H = halves[h];
             const size_t b0 = (size_t)H.b0;
@@ -530,6 +553,18 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             float *ps_h = ws->pairsum.p ? ws->pairsum.as<float>() + b0 * pairsum_floats : nullptr;
             float *tr_h = trace ? trace + b0 * (size_t)D.n_gn * D.trace_record : nullptr;
             size_t slot;
+            SolveDims Dh = D;                                   // the sweeps' view of this half
+            if (Dh.block_ranges) Dh.block_ranges += b0 * N * (size_t)((Wd / 8) * (Hd / 8));
+#ifdef BTBA_WG_TRACE
+            static DevBuf wg_trace_buf;
+            const char *wg_trace_file = std::getenv("BTBA_WG_TRACE_FILE");
+            const size_t wg_trace_n = (size_t)tiles * D.n_dense_pairs * H.nb + (size_t)chunks * P * H.nb;
+            if (wg_trace_file && it == prm->n_gn_iters - 1 && h == 0) {
+                if ((rc = wg_trace_buf.ensure(32 * wg_trace_n))) return rc;
+                HIP_TRY(hipMemsetAsync(wg_trace_buf.p, 0, 32 * wg_trace_n, H.st));
+                Dh.wg_trace = wg_trace_buf.as<unsigned long long>();
+            }
+#endif
             const unsigned n_d = (unsigned)tiles * D.n_dense_pairs * H.nb, n_s = (unsigned)chunks * P * H.nb;
             // one interleaved launch of both sweeps: the dense workgroups are VALU-bound, the sparse ones stream HBM, and the
             // two fill each other's idle pipes -- measured at c3 (scripts/ab_dense.py, fused vs separate step time):
@@ -537,8 +572,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             const bool fuse = use_sparse && use_dense && n_s >= 64 && n_d >= 64 && !(prm->flags & BTBA_FLAG_NO_FUSE);
             if (fuse) {
                 // one launch: HBM-streaming sparse workgroups interleaved with the VALU-bound dense ones
-                if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
-#define BTBA_FUSED_ARGS(CACHE) D, n_d, n_s, CACHE, reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, corr_h, off_h, sp_h, vl_h, vc_h
+                if ((rc = time_begin(ws, timing_it, 0, &slot, H.st))) return rc;
+#define BTBA_FUSED_ARGS(CACHE) Dh, n_d, n_s, CACHE, reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, corr_h, off_h, sp_h, vl_h, vc_h
                 const int lay = zn_layout ? zn_layout + (compaction ? 2 : 0) : 0;
                 if (lay == 0) k_fused_sweeps<0><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(reinterpret_cast<const float4 *>(campos_h)));
                 else if (lay == 1) k_fused_sweeps<1><<<dim3(n_d + n_s), kBlock, lut_bytes, H.st>>>(BTBA_FUSED_ARGS(zn_h));
@@ -549,24 +584,32 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                 if ((rc = time_end(ws, slot, H.st))) return rc;
             } else {
                 if (use_sparse) {
-                    if ((rc = time_begin(ws, timing, 1, &slot, H.st))) return rc;
+                    if ((rc = time_begin(ws, timing_it, 1, &slot, H.st))) return rc;
                     k_sparse_sweep<<<dim3(chunks, P, H.nb), kBlock, 0, H.st>>>(D, corr_h, off_h, T_h, sp_h);
                     if ((rc = time_end(ws, slot, H.st))) return rc;
                 }
                 if (use_dense) {
-                    if ((rc = time_begin(ws, timing, 0, &slot, H.st))) return rc;
+                    if ((rc = time_begin(ws, timing_it, 0, &slot, H.st))) return rc;
                     const dim3 dgrid(n_d);
 #define BTBA_DENSE_ARGS D, reinterpret_cast<const float4 *>(campos_h), reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h
-                    if (zn_layout == 1 && !compaction) k_dense_sweep_zn<true, false><<<dgrid, kBlock, lut_bytes, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
-                    else if (zn_layout == 2 && !compaction) k_dense_sweep_zn<false, false><<<dgrid, kBlock, lut_bytes, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
-                    else if (zn_layout == 1) k_dense_sweep_zn<true, true><<<dgrid, kBlock, lut_bytes, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
-                    else if (zn_layout == 2) k_dense_sweep_zn<false, true><<<dgrid, kBlock, lut_bytes, H.st>>>(D, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    if (zn_layout == 1 && !compaction) k_dense_sweep_zn<true, false><<<dgrid, kBlock, lut_bytes, H.st>>>(Dh, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    else if (zn_layout == 2 && !compaction) k_dense_sweep_zn<false, false><<<dgrid, kBlock, lut_bytes, H.st>>>(Dh, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    else if (zn_layout == 1) k_dense_sweep_zn<true, true><<<dgrid, kBlock, lut_bytes, H.st>>>(Dh, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
+                    else if (zn_layout == 2) k_dense_sweep_zn<false, true><<<dgrid, kBlock, lut_bytes, H.st>>>(Dh, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
                     else k_dense_sweep<<<dgrid, kBlock, 0, H.st>>>(BTBA_DENSE_ARGS);
 #undef BTBA_DENSE_ARGS
                     if ((rc = time_end(ws, slot, H.st))) return rc;
                 }
             }
-            if ((rc = time_begin(ws, timing, 2, &slot, H.st))) return rc;
+#ifdef BTBA_WG_TRACE
+            if (Dh.wg_trace) {                                   // dump the last iteration's workgroup timeline
+                std::vector<unsigned long long> host(4 * wg_trace_n);
+                HIP_TRY(hipStreamSynchronize(H.st));
+                HIP_TRY(hipMemcpy(host.data(), wg_trace_buf.p, 32 * wg_trace_n, hipMemcpyDeviceToHost));
+                if (FILE *f = std::fopen(wg_trace_file, "wb")) { std::fwrite(host.data(), 8, host.size(), f); std::fclose(f); }
+            }
+#endif
+            if ((rc = time_begin(ws, timing_it, 2, &slot, H.st))) return rc;
             float *A_h = a_global ? ws->big_A.as<float>() + b0 * n * ld : nullptr;
             float *out_h = (it == prm->n_gn_iters - 1) ? poses + 16 * b0 * N : nullptr;     // the last iterate's matrices go straight to the caller's buffer
 #define BTBA_SOLVE(LP, AG) k_system_solve<LP, AG><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h, A_h, out_h, ws->solve_tab.as<int>())
@@ -576,9 +619,9 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             if ((rc = time_end(ws, slot, H.st))) return rc;
         }
     }
-    if (n_halves == 2) {
-        HIP_TRY(hipEventRecord(ws->ev_join, ws->aux_stream));
-        HIP_TRY(hipStreamWaitEvent(ws->stream, ws->ev_join, 0));
+    for (int g = 1; g < n_halves; g++) {
+        HIP_TRY(hipEventRecord(ws->ev_join[g - 1], ws->aux_streams[g - 1]));
+        HIP_TRY(hipStreamWaitEvent(ws->stream, ws->ev_join[g - 1], 0));
     }
     if ((rc = time_end(ws, reg))) return rc;
     HIP_TRY(hipGetLastError());

@@ -70,6 +70,10 @@ struct SolveDims {
     int n_gn;
     int pairsum_in_lds;  // 1: stage reduced pair sums in LDS, 0: in global scratch
     int walk_blocks;     // pinhole sweep on the compact cache: waves walk 8 x 8 pixel blocks (width and height multiples of 8)
+#ifdef BTBA_WG_TRACE
+    unsigned long long *wg_trace; // developer build (scripts/wg_trace.py): per workgroup of the fused sweep (start, end) in 100 MHz ticks, hardware id, kind
+#endif
+    const float2 *block_ranges;   // per (frame of the solve, 8 x 8 block): [min, max] usable depth (k_block_ranges); nullptr: no block is skipped
     int tile_major;      // dense work order inside an instance: 1 = (tile, pair) -- all pairs' band t of the images together -- 0 = (pair, tile)
     int *order_flag;     // non-null: the sparse sweep ORs 1 into it when an entry does not belong to the pair of its segment
     // compact (z, nx, ny, nz) frame cache: how a cached pixel maps back to camera space -- the arithmetic of k_build_cache
@@ -471,12 +475,7 @@ __device__ __forceinline__ int tri21(int r, int c) { if (r > c) { const int t = 
 // off the single-workgroup critical path of k_system_solve (it was 8.4 k of its 55 k cycles).
 __device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *red, float *out, const float *__restrict__ T_target)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kDenseVals; k++) {
-        const float s = wave_sum_to_lane63(acc[k]);
-        if (lane == 63) red[wave * kDenseVals + k] = s;
-    }
+    wave_fold_store<kDenseVals>(acc, red + (threadIdx.x >> 6) * kDenseVals);
     __syncthreads();
     float *Sp = red + 4 * kDenseVals;                    // the workgroup's camera-frame sums (28) ...
     float *Mt = Sp + kDenseVals + 4;                     // ... and M (36)
@@ -568,6 +567,28 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
     dense_epilogue(acc, red, out, T + 16 * (fb + fi));
+}
+
+// ---- per-block depth ranges of the compact cache ------------------------------------------------------------------
+// [min, max] of the depths the dense sweep can use (depth_min < z < depth_max on the gated depth, the sweep's own bit-pattern
+// test) per 8 x 8 pixel block of every frame of the solve; an empty block gets (+inf, -inf).  Once per solve: the frames do
+// not change across Gauss-Newton iterations.  One wave per block, lane = pixel, butterfly min / max.
+__global__ void __launch_bounds__(kBlock) k_block_ranges(int width, int height, float depth_min, float depth_max, const float4 *__restrict__ zn,
+                                                         const int *__restrict__ frame_slot, float2 *__restrict__ ranges)
+{
+    // grid (blocks / 4, frames): one load per lane and no loop -- the kernel is a single memory round trip deep
+    const int f = (int)blockIdx.y, slot = frame_slot ? frame_slot[f] : f;
+    const int bw = width >> 3, nblk = bw * (height >> 3);
+    const int lane = (int)threadIdx.x & 63, blk = (int)blockIdx.x * (kBlock / 64) + ((int)threadIdx.x >> 6);
+    if (blk >= nblk) return;
+    const unsigned zmin_bits = __float_as_uint(depth_min) + 1u, zrange_bits = __float_as_uint(depth_max) - __float_as_uint(depth_min) - 1u;
+    const int by = blk / bw, bx = blk - by * bw;
+    const float d = zn[(size_t)slot * width * height + (size_t)((by * 8 + (lane >> 3)) * width + bx * 8 + (lane & 7))].x;
+    const bool ok = (__float_as_uint(d) - zmin_bits) < zrange_bits;
+    float lo = ok ? d : INFINITY, hi = ok ? d : -INFINITY;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { lo = fminf(lo, __shfl_xor(lo, m)); hi = fmaxf(hi, __shfl_xor(hi, m)); }
+    if (lane == 0) ranges[(size_t)f * nblk + blk] = make_float2(lo, hi);
 }
 
 // Ordered list of the pixels of every frame that carry a depth (>= 0.1 m, the cache builder's validity rule).
@@ -884,30 +905,90 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     };
 
     if (WALK == 2) {
-        // Wave w of the workgroup walks the 8 x 8 pixel blocks w, w + 4, ... of this band of block rows; lane = (row, column) inside
-        // the block.  The region of a source frame that projects into the target is a compact blob, so whole blocks fall outside it
-        // and are skipped (49 % of the wave trips carry a valid pixel at c3, against 69 % for 64 x 1 strips), and a block's taps land
-        // in a compact patch of the target.  Block coordinates are wave-uniform: they advance in scalar registers.
+        // Waves walk 8 x 8 pixel blocks of this band of block rows; lane = (row, column) inside the block.  The region of a source
+        // frame that projects into the target is a compact blob, so whole blocks fall outside it (51 % of them at c3; 64 x 1 strips:
+        // 31 %), and a block's taps land in a compact patch of the target.
+        //
+        // Dead blocks are removed BEFORE the walk where that can be PROVEN: a block's pixels with a usable depth lie in the frustum
+        // segment spanned by the block's extreme rays and its depth range [zlo, zhi] (k_block_ranges); the relative pose maps the
+        // segment to a convex polytope whose vertices are the 8 transformed corners, and while every corner has q.z > 0 the
+        // projection (u, v) of any point inside lies within the corners' [min, max] in u and in v (a ratio of affine functions is
+        // quasi-linear on a convex set where the denominator is positive).  If that range misses the image by more than a margin
+        // -- 0.01 pixel, three orders of magnitude above the rounding differences between this evaluation and the per-pixel one --
+        // no pixel of the block can pass the in-image test, and the block contributes exactly nothing, as in the reference
+        // (SolverBundlingDenseUtil.h:91-94).  Blocks without any usable depth go the same way.  90 % of the dead blocks are proven
+        // dead at c3; the live ones are compacted into an ordered list in LDS (deterministic) that the four waves share round-robin.
         const int bw = D.width >> 3, bh = D.height >> 3;
         const int rows_per = (bh + D.dense_tiles - 1) / D.dense_tiles;
         const int r0 = min(bh, rows_per * tile), r1 = min(bh, rows_per * (tile + 1));
         const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        int *hdr = reinterpret_cast<int *>(lut + D.width + D.height);       // [0 .. 4) wave totals, [4] running total
+        unsigned *blist = reinterpret_cast<unsigned *>(hdr + 8);
+        const int nb = (r1 - r0) * bw;
+        const float2 *rng = D.block_ranges ? D.block_ranges + (fb + fj) * (size_t)(bw * bh) : nullptr;
+        int n_live = 0;
+        for (int c0 = 0; c0 < nb; c0 += kBlock) {
+            const int idx = c0 + (int)threadIdx.x;
+            bool live = false;
+            unsigned code = 0;
+            if (idx < nb) {
+                const int byl = idx / bw, bxl = idx - byl * bw, byg = r0 + byl;
+                code = ((unsigned)byg << 16) | (unsigned)bxl;
+                live = true;
+                if (rng) {
+                    const float2 zr = rng[byg * bw + bxl];
+                    live = zr.x <= zr.y;
+                    if (live) {
+                        const float xa = lut[8 * bxl], xb = lut[8 * bxl + 7], ya = lut[D.width + 8 * byg], yb = lut[D.width + 8 * byg + 7];
+                        float ulo = INFINITY, uhi = -INFINITY, vlo = INFINITY, vhi = -INFINITY, zq = INFINITY;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const float x = (k & 1) ? xb : xa, y = (k & 2) ? yb : ya;
+                            const float rx = C.R[0] * x + C.R[1] * y + C.R[2], ry = C.R[3] * x + C.R[4] * y + C.R[5], rz = C.R[6] * x + C.R[7] * y + C.R[8];
+#pragma unroll
+                            for (int e = 0; e < 2; e++) {
+                                const float d = e ? zr.y : zr.x;
+                                const float qx = rx * d + C.t[0], qy = ry * d + C.t[1], qz = rz * d + C.t[2];
+                                const float rq = fast_rcp(qz);
+                                const float u = qx * D.fx * rq + D.cx, v = qy * D.fy * rq + D.cy;
+                                ulo = fminf(ulo, u); uhi = fmaxf(uhi, u); vlo = fminf(vlo, v); vhi = fmaxf(vhi, v); zq = fminf(zq, qz);
+                            }
+                        }
+                        const float m = 0.01f;
+                        const bool outside = (uhi < -0.5f - m) | (ulo > (float)D.width - 0.5f + m) | (vhi < -0.5f - m) | (vlo > (float)D.height - 0.5f + m);
+                        live = !(zq > 1e-3f && outside);          // NaN anywhere: comparisons false, the block stays
+                    }
+                }
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(live);
+            if (lane == 0) hdr[wave] = __popcll(bal);
+            __syncthreads();
+            int base = n_live, total = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) { const int t = hdr[w]; if (w < wave) base += t; total += t; }
+            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+            if (live) blist[base + before] = code;
+            n_live += total;
+            __syncthreads();
+        }
+        n_live = __builtin_amdgcn_readfirstlane(n_live);
         const unsigned lx = (unsigned)lane & 7u, ly = (unsigned)lane >> 3;
         const unsigned lane_px = ly * (unsigned)D.width + lx;          // pixel offset of the lane inside its block
         const unsigned ox_l = 4u * lx, oy_l = 4u * ly + 4u * (unsigned)D.width;
-        // (bx, by) of this wave's current and next block, advanced without divisions (scalar registers)
-        int bx = wave % bw, by = r0 + wave / bw;
-        auto advance = [&](int &x, int &y) { x += kBlock / 64; while (x >= bw) { x -= bw; y++; } };
-        int bxn = bx, byn = by;
-        advance(bxn, byn);
+        // this wave's current and next block (scalar registers), the next block's pixels in flight while the current one is worked on
+        int k = wave;
+        unsigned code_n = (k < n_live) ? (unsigned)__builtin_amdgcn_readfirstlane((int)blist[k]) : 0u;
         float4 zs_n = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (by < r1) zs_n = zn_s[(unsigned)(by * 8 * D.width + bx * 8) + lane_px];
-        while (by < r1) {
+        if (k < n_live) zs_n = zn_s[(unsigned)((int)(code_n >> 16) * 8 * D.width + (int)(code_n & 0xFFFFu) * 8) + lane_px];
+        while (k < n_live) {
             const float4 zs = zs_n;
-            if (byn < r1) zs_n = zn_s[(unsigned)(byn * 8 * D.width + bxn * 8) + lane_px];        // next block's stream loads
-            pixel(zs, ox_l + 32u * (unsigned)bx, oy_l + 32u * (unsigned)by);
-            bx = bxn; by = byn;
-            advance(bxn, byn);
+            const unsigned code = code_n;
+            k += kBlock / 64;
+            if (k < n_live) {
+                code_n = (unsigned)__builtin_amdgcn_readfirstlane((int)blist[k]);
+                zs_n = zn_s[(unsigned)((int)(code_n >> 16) * 8 * D.width + (int)(code_n & 0xFFFFu) * 8) + lane_px];
+            }
+            pixel(zs, ox_l + 32u * (code & 0xFFFFu), oy_l + 32u * (code >> 16));
         }
     } else {
         const int n_src = LISTS ? valid_counts[slot_s] : D.npix;
@@ -984,22 +1065,23 @@ __global__ void __launch_bounds__(kBlock, 3) k_dense_sweep(SolveDims D, const fl
 #define BTBA_FUSED_WAVES 3
 #endif
 template <int LAYOUT>   // 0: float4 camPos + float4 normals; compact cache: 1 zero-skew K, 2 general K, 3 / 4 the same walking valid-pixel lists
-__global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_fused_sweeps(SolveDims D, unsigned n_d, unsigned n_s,
-                                                           const float4 *__restrict__ campos, const float4 *__restrict__ normals,
-                                                           const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
-                                                           float *__restrict__ dense_partials,
-                                                           const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets, float *__restrict__ sparse_partials,
-                                                           const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts)
+__device__ __forceinline__ void fused_item(const SolveDims &D, unsigned n_d, unsigned n_s, unsigned g,
+                                           const float4 *__restrict__ campos, const float4 *__restrict__ normals,
+                                           const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
+                                           float *__restrict__ dense_partials,
+                                           const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets, float *__restrict__ sparse_partials,
+                                           const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts, float *red, float *zn_lut)
 {
-    __shared__ float red[kRedFloats];
-    extern __shared__ __attribute__((aligned(16))) float zn_lut[];        // (Wd + Hd) floats, compact layouts only
-    const unsigned G = n_d + n_s, g = blockIdx.x, xcd = g & 7u, slot = g >> 3;
+    const unsigned G = n_d + n_s, xcd = g & 7u, slot = g >> 3;
     const unsigned qd = n_d >> 3, rd = n_d & 7u;
     const unsigned Gx = (G - xcd + 7u) >> 3, ndx = qd + (xcd < rd ? 1u : 0u), nsx = Gx - ndx;
     unsigned sparse_base = 0;                                   // sparse items owned by lower XCDs
     for (unsigned y = 0; y < xcd; y++) sparse_base += ((G - y + 7u) >> 3) - (qd + (y < rd ? 1u : 0u));
     const unsigned Rx = nsx ? Gx / nsx : 0xFFFFFFFFu;
     const bool is_sparse = nsx && (slot % Rx == 0u) && (slot / Rx < nsx);
+#ifdef BTBA_WG_TRACE
+    const unsigned long long wg_t0 = wall_clock64();
+#endif
     if (is_sparse) {
         const unsigned i = sparse_base + slot / Rx;              // (chunk fastest, then pair, then instance)
         const int chunk = (int)(i % (unsigned)D.sparse_chunks);
@@ -1021,7 +1103,31 @@ __global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_fused_sweeps(Solve
         else if (LAYOUT == 3) dense_block_pinhole<1>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
         else dense_block_zn<false, true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
     }
+#ifdef BTBA_WG_TRACE
+    if (D.wg_trace && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n s_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        unsigned long long *q = D.wg_trace + 4 * (size_t)g;
+        q[0] = wg_t0; q[1] = wall_clock64(); q[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32); q[3] = is_sparse ? 1u : 0u;
+    }
+#endif
 }
+
+#define BTBA_FUSED_ITEM_ARGS D, n_d, n_s, g, campos, normals, dense_pairs, T, Tinv, dense_partials, corr, pair_offsets, sparse_partials, valid_lists, valid_counts, red, zn_lut
+template <int LAYOUT>
+__global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_fused_sweeps(SolveDims D, unsigned n_d, unsigned n_s,
+                                                           const float4 *__restrict__ campos, const float4 *__restrict__ normals,
+                                                           const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
+                                                           float *__restrict__ dense_partials,
+                                                           const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets, float *__restrict__ sparse_partials,
+                                                           const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts)
+{
+    __shared__ float red[kRedFloats];
+    extern __shared__ __attribute__((aligned(16))) float zn_lut[];        // (Wd + Hd) floats (+ the block walk's list), compact layouts only
+    const unsigned g = blockIdx.x;
+    fused_item<LAYOUT>(BTBA_FUSED_ITEM_ARGS);
+}
+#undef BTBA_FUSED_ITEM_ARGS
 
 // ---- system solve -------------------------------------------------------------------------------
 // symmetric 3x3 packed xx xy xz yy yz zz

@@ -73,6 +73,9 @@ enum {
 enum {
     BTBA_FLAG_TRACE         = 1,    /* record per-GN-iterate trace (btba_trace_layout)                            */
     BTBA_FLAG_TIME_KERNELS  = 2,    /* bracket every sweep / solve launch with hipEvents (btba_stats)             */
+    BTBA_FLAG_TIME_SAMPLED  = 2048, /* with TIME_KERNELS: bracket the launches of ONE Gauss-Newton iteration per solve only (the iteration
+                                       rotates from solve to solve): 28 event records per 7-iteration solve cost ~4 % of a c3 x 32 step,
+                                       4 do not; the per-launch averages in btba_stats are over the sampled launches              */
     BTBA_FLAG_OVERLAP       = 32,   /* split a batch over two streams (main + low-priority) so one half's k_system_solve
                                        overlaps the other half's sweeps; per-kernel timings then overlap too (+4 % at c3 x 32) */
     BTBA_FLAG_NO_FUSE       = 64,   /* launch the sparse and the dense sweep separately (default: ONE interleaved launch) */

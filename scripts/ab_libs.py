@@ -20,7 +20,7 @@ def child(lib):
         B = int(os.environ.get("AB_B", "32"))
         pick = [inst[b % len(inst)] for b in range(B)]
         bs = BatchSolver(ws)
-        bs.params.flags |= _lib.FLAG_TIME_KERNELS | (_lib.FLAG_COMPACTION if tag == "masked" else 0)
+        bs.params.flags |= (0 if os.environ.get("AB_NO_TIMING") else _lib.FLAG_TIME_KERNELS) | (_lib.FLAG_COMPACTION if tag == "masked" else 0) | int(os.environ.get("AB_FLAGS", "0"))
         bs.params.dense_tiles = int(os.environ.get("BTBA_BENCH_TILES", "0"))
         corr, offs, mx = bs.pack_correspondences([p["corr"] for p in pick], 15)
         zn_d = torch.from_numpy(np.stack([p["zn"] for p in pick])).to(dev)

@@ -92,7 +92,7 @@ def main():
     which = int(sys.argv[sys.argv.index("--loop") + 1]) if "--loop" in sys.argv else 0
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(kern) + r"\w*:", l))
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))        # a kernel can hold several s_endpgm
     body = [l.split(";")[0].rstrip() for l in lines[start:end]]
     cands = []
     for a, b in loops_of(body):

@@ -94,6 +94,33 @@ def test_c3_realistic_mask_matches_oracle(gpu, oracle):
             assert r < 1e-4 and t < 1e-4, (it, k, r, t)
 
 
+def test_dead_block_skip_is_exact(gpu, monkeypatch):
+    """The dense sweep drops 8 x 8 blocks whose frustum segment provably projects outside the target image before walking them
+    (k_block_ranges + the hull test in dense_block_pinhole).  It must never drop a block that holds an accepted pixel: with the
+    skip disabled (BTBA_NO_BLOCK_SKIP, every block walked) the accepted-pixel counts of every dense pair are IDENTICAL at the
+    first linearisation (same poses), the sums agree to fp32 grouping, and the solves stay within round-off of each other.
+    Eight windows, among them ones with poses far from the truth (large relative motion: most blocks dead) and a masked one."""
+    pbs = [S.make_problem(15, 2000, S.config_seed(5, 40 + b), background=(b != 7), full_res=False) for b in range(8)]
+    rng = np.random.default_rng(5)
+    for b in (4, 5, 6):                                  # poses far off: rotations up to ~0.5 rad, translations up to 0.2 m about the scene
+        for k in range(1, 15):
+            pbs[b].poses_init[k] = (S.se3_exp(rng.uniform(-0.5, 0.5, 3), rng.uniform(-0.2, 0.2, 3)) @ pbs[b].poses_init[k].astype(np.float64)).astype(np.float32)
+    out_a, tv_a, _ = run_gpu(gpu, pbs)
+    monkeypatch.setenv("BTBA_NO_BLOCK_SKIP", "1")
+    out_b, tv_b, _ = run_gpu(gpu, pbs)
+    monkeypatch.delenv("BTBA_NO_BLOCK_SKIP")
+    ca, cb = tv_a.dense_pair[:, 0, :, 27], tv_b.dense_pair[:, 0, :, 27]
+    assert np.array_equal(ca, cb)
+    assert ca.sum() > 0
+    print(f"accepted pixels per pair: min {ca.min():.0f} max {ca.max():.0f}; empty pairs {(ca == 0).sum()} of {ca.size}")
+    ref = np.abs(tv_b.dense_pair[:, 0]).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(tv_a.dense_pair[:, 0] - tv_b.dense_pair[:, 0]) <= 4e-6 * ref).all()
+    for b in range(4):                                   # well-posed windows: the whole solve within round-off
+        for k in range(15):
+            r, t = S.pose_error(out_a[b, k], out_b[b, k])
+            assert r < 5e-5 and t < 5e-5, (b, k, r, t)
+
+
 def test_c5_shape_batch_properties(gpu):
     """32 instances of the c3 shape (config 5's per-GPU share): run-to-run bit-identical, every instance equal
     to its own single-instance run up to fp32 noise, all finite, all improved."""
