@@ -67,6 +67,7 @@ struct btba_workspace {
     DevBuf block_ranges;                                    // per (frame, 8 x 8 block) usable depth range: dead-block test of the dense sweep
     std::vector<int32_t> dense_pairs_host;                  // what dense_pairs currently holds
     int dense_pairs_frames = -1;
+    size_t dense_work_offset = 0;                           // ints into dense_pairs: the fused sweep's work table
     int solve_tab_frames = -1;                              // window size solve_tab was built for
     std::vector<EventPair> events;                          // pending timed regions
     std::vector<hipEvent_t> event_pool;
@@ -388,6 +389,14 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         for (int q = 0; q < Pd; q++) { adj[cur[pairs[2 * q]]++] = (q << 1); adj[cur[pairs[2 * q + 1]]++] = (q << 1) | 1; }
         tab.insert(tab.end(), off.begin(), off.end());
         tab.insert(tab.end(), adj.begin(), adj.end());
+        // work order of the fused sweep's dense items: frames close in the window overlap most (keyframes are in temporal order), so
+        // pairs sorted by |i - j| put the long workgroups first and the short ones at the end of the launch, where they drain quickly
+        std::vector<int32_t> order(Pd);
+        for (int q = 0; q < Pd; q++) order[q] = q;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b2) { return std::abs(pairs[2 * a] - pairs[2 * a + 1]) < std::abs(pairs[2 * b2] - pairs[2 * b2 + 1]); });
+        while (tab.size() % 4) tab.push_back(0);           // 16-byte entries
+        ws->dense_work_offset = tab.size();
+        for (int q = 0; q < Pd; q++) { tab.push_back(pairs[2 * order[q]]); tab.push_back(pairs[2 * order[q] + 1]); tab.push_back(order[q]); tab.push_back(0); }
         if ((rc = ws->dense_pairs.ensure(sizeof(int32_t) * tab.size()))) return rc;
         HIP_TRY(hipMemcpyAsync(ws->dense_pairs.p, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice, ws->stream));
         HIP_TRY(hipStreamSynchronize(ws->stream));         // `tab` is a local; the copy must land before it dies
@@ -420,6 +429,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;
     D.order_flag = order_flag;
+    if (Pd > 0 && !std::getenv("BTBA_NO_DENSE_ORDER")) { D.dense_work = reinterpret_cast<const int4 *>(ws->dense_pairs.as<int32_t>() + ws->dense_work_offset); D.dense_work_stride = 0; }      // developer A/B: list order
     D.tile_major = std::getenv("BTBA_PAIR_MAJOR") ? 0 : 1;      // developer A/B only: (pair, band) instead of (band, pair) work order, same bits
     D.walk_blocks = (Wd % 8 == 0 && Hd % 8 == 0 && !std::getenv("BTBA_NO_BLOCK_WALK")) ? 1 : 0;
     D.n_gn = prm->n_gn_iters;
@@ -535,7 +545,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         for (int g = 1; g < n_halves; g++) HIP_TRY(hipStreamWaitEvent(ws->aux_streams[g - 1], ws->ev_fork, 0));
     }
     const size_t pairsum_floats = lds_pairs / sizeof(float);
-    const size_t lut_bytes = sizeof(float) * (size_t)(Wd + Hd) + blist_bytes;         // coordinate look-up tables of the compact dense sweep (+ its list of live blocks)
+    const size_t lut_bytes = sizeof(float) * (size_t)((Wd + Hd + 3) & ~3) + (zn_layout == 1 ? sizeof(float4) * (size_t)(Wd + Hd) : 0) + blist_bytes;         // coordinate look-up tables of the compact dense sweep (+ its list of live blocks)
     for (int it = 0; it < prm->n_gn_iters; it++) {
         const bool timing_it = timing && (timed_iteration < 0 || timed_iteration == it);
         for (int h = 0; h < n_halves; h++) {

@@ -26,6 +26,7 @@
 #define BTBA_PINHOLE_SGPR_POSE
 #define BTBA_PINHOLE_SGPR_CONST
 #define BTBA_PAIR_ACC
+#define BTBA_RAY_TABLES
 #define BTBA_FUSED_WAVES 6
 #endif
 #include <type_traits>
@@ -73,6 +74,8 @@ struct SolveDims {
 #ifdef BTBA_WG_TRACE
     unsigned long long *wg_trace; // developer build (scripts/wg_trace.py): per workgroup of the fused sweep (start, end) in 100 MHz ticks, hardware id, kind
 #endif
+    const int4 *dense_work;       // fused sweep: work position -> (target, source, dense pair, -), heaviest pairs first (nullptr: list order)
+    int dense_work_stride;        // entries per instance (0: one table for all)
     const float2 *block_ranges;   // per (frame of the solve, 8 x 8 block): [min, max] usable depth (k_block_ranges); nullptr: no block is skipped
     int tile_major;      // dense work order inside an instance: 1 = (tile, pair) -- all pairs' band t of the images together -- 0 = (pair, tile)
     int *order_flag;     // non-null: the sparse sweep ORs 1 into it when an entry does not belong to the pair of its segment
@@ -473,7 +476,24 @@ __device__ __forceinline__ int tri21(int r, int c) { if (r > c) { const int t = 
 // (see pixel_accumulate), then one 112-byte record per workgroup.  The congruence is linear, so applying it per tile and summing
 // the tiles in k_system_solve equals applying it to the sum; doing it here (27 lanes, ~40 FMAs each, once per workgroup) takes it
 // off the single-workgroup critical path of k_system_solve (it was 8.4 k of its 55 k cycles).
-__device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *red, float *out, const float *__restrict__ T_target)
+// M of the congruence (6 x 6, from the target frame's pose), staged in LDS by 36 threads at the START of a dense workgroup: its global
+// loads are then off the tail of the workgroup (the epilogue used to wait a memory round trip for them)
+__device__ __forceinline__ void dense_stage_M(float *red, const float *__restrict__ T_target)
+{
+    float *Mt = red + 4 * kDenseVals + kDenseVals + 4;
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 36) {
+        const int e = (int)threadIdx.x - 64, r = e / 6, c = e % 6;
+        float v;
+        if (r < 3) v = (c < 3) ? T_target[4 * r + c] : 0.0f;
+        else {
+            const int q = r - 3, qa = (q + 1) % 3, qb = (q + 2) % 3;     // ([t]x R)[q][c] = t[qa] R[qb][c] - t[qb] R[qa][c]
+            v = (c < 3) ? T_target[4 * qa + 3] * T_target[4 * qb + c] - T_target[4 * qb + 3] * T_target[4 * qa + c] : T_target[4 * q + (c - 3)];
+        }
+        Mt[e] = v;
+    }
+}
+
+__device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *red, float *out)
 {
     wave_fold_store<kDenseVals>(acc, red + (threadIdx.x >> 6) * kDenseVals);
     __syncthreads();
@@ -484,15 +504,6 @@ __device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *
 #pragma unroll
         for (int w = 1; w < 4; w++) s += red[w * kDenseVals + threadIdx.x];
         Sp[threadIdx.x] = s;
-    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + 36) {
-        const int e = (int)threadIdx.x - 64, r = e / 6, c = e % 6;
-        float v;
-        if (r < 3) v = (c < 3) ? T_target[4 * r + c] : 0.0f;
-        else {
-            const int q = r - 3, qa = (q + 1) % 3, qb = (q + 2) % 3;     // ([t]x R)[q][c] = t[qa] R[qb][c] - t[qb] R[qa][c]
-            v = (c < 3) ? T_target[4 * qa + 3] * T_target[4 * qb + c] - T_target[4 * qb + 3] * T_target[4 * qa + c] : T_target[4 * q + (c - 3)];
-        }
-        Mt[e] = v;
     }
     __syncthreads();
     const int idx = (int)threadIdx.x;
@@ -530,12 +541,12 @@ __device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *
 // float4 loads of the source camPos / normal); two pixels per lane per trip, sixteen target-tap gathers in
 // flight; the taps stay in L1/L2 because neighbouring source pixels project to neighbouring target pixels.
 __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__restrict__ campos, const float4 *__restrict__ normals,
-                                            const int2 *__restrict__ dense_pairs, const float *__restrict__ T, const float *__restrict__ Tinv,
+                                            const int2 ij, const float *__restrict__ T, const float *__restrict__ Tinv,
                                             float *__restrict__ partials, int tile, int p, int b, float *red)
 {
-    const int2 ij = dense_pairs[p];
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
+    dense_stage_M(red, T + 16 * (fb + fi));
     DenseCtx C;
     C.Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), load_mat4(T + 16 * (fb + fj)));      // source camera -> target camera
     C.cam_t = campos + (fb + fi) * (size_t)D.npix; C.nrm_t = normals + (fb + fi) * (size_t)D.npix;
@@ -566,7 +577,7 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
         }
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
-    dense_epilogue(acc, red, out, T + 16 * (fb + fi));
+    dense_epilogue(acc, red, out);
 }
 
 // ---- per-block depth ranges of the compact cache ------------------------------------------------------------------
@@ -658,7 +669,7 @@ __global__ void __launch_bounds__(1024) k_valid_lists(int npix, const float4 *__
 // The same sweep on the compact cache: ONE 16-byte load per source pixel and per tap (5 loads instead of 10),
 // camera-space points re-derived from z with the cache builder's exact arithmetic (zn_backproject).
 template <bool SIMPLE, bool LISTS>
-__device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
+__device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 *__restrict__ zn, const int2 ij,
                                                const float *__restrict__ T, const float *__restrict__ Tinv,
                                                float *__restrict__ partials, int tile, int p, int b, float *red,
                                                const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts, float *lut)
@@ -672,9 +683,9 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
     }
     __syncthreads();
     const float *lut_x = lut, *lut_y = lut + D.width;
-    const int2 ij = dense_pairs[p];
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
+    dense_stage_M(red, T + 16 * (fb + fi));
     DenseCtx C;
     C.Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), load_mat4(T + 16 * (fb + fj)));
     // the relative pose is the same in every lane: keep it in scalar registers (12 VGPRs back)
@@ -737,7 +748,7 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
                          make_float4(z00.y, z00.z, z00.w, 0.f), make_float4(z10.y, z10.z, z10.w, 0.f), make_float4(z01.y, z01.z, z01.w, 0.f), make_float4(z11.y, z11.z, z11.w, 0.f), acc);
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
-    dense_epilogue(acc, red, out, T + 16 * (fb + fi));
+    dense_epilogue(acc, red, out);
 }
 
 // ---- the dense sweep for pinhole intrinsics on the GATED compact cache --------------------------------------------
@@ -762,6 +773,9 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
 //   * depth-range tests are one unsigned compare of the bit patterns: for positive floats order is bit order, negative
 //     values, zeros and NaN fall outside after the subtraction wraps;
 //   * wave-uniform operands of 2-cycle operations (relative pose, intrinsics) live in VGPRs.
+#ifdef BTBA_WG_TRACE
+__shared__ unsigned long long wg_dbg[4];       // developer build: (end of prologue, end of pixel loop, live blocks) of the workgroup's dense item
+#endif
 struct PinholeCtx {
     float R[9], t[3];                 // relative pose source camera -> target camera
     float fx, fy, cx, cy, wm1, hm1, wm2, hm2, w16, normal_thresh, dist2_thresh, wdelta, w_dense, ybase4;
@@ -781,9 +795,12 @@ __device__ __forceinline__ float in_vgpr(float x) { asm volatile("" : "+v"(x)); 
 __device__ __forceinline__ unsigned in_vgpr(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 #endif
 __device__ __forceinline__ unsigned opaque_vgpr(unsigned x) { asm volatile("" : "+v"(x)); return x; }
+// v_min_f32 as the hardware does it: fminf() makes the compiler canonicalise its operands first (v_max_f32 x, x, x -- a half-rate
+// instruction per operand, repeated in the loop even for loop invariants); the operands here are never signalling NaNs
+__device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 template <int WALK>     // 0: 64-pixel row strips   1: the source frame's valid-pixel list   2: 8 x 8 pixel blocks per wave (cache width and height multiples of 8)
-__device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const float4 *__restrict__ zn, const int2 *__restrict__ dense_pairs,
+__device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const float4 *__restrict__ zn, const int2 ij,
                                                     const float *__restrict__ T, const float *__restrict__ Tinv,
                                                     float *__restrict__ partials, int tile, int p, int b, float *red,
                                                     const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts, float *lut)
@@ -795,9 +812,9 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         lut[e] = is_x ? D.zn_ki[0] * c + D.zn_ki[2] : D.zn_ki[5] * c + D.zn_ki[6];
     }
     __syncthreads();
-    const int2 ij = dense_pairs[p];
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
+    dense_stage_M(red, T + 16 * (fb + fi));
     const Mat4 Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), load_mat4(T + 16 * (fb + fj)));
     PinholeCtx C;
 #pragma unroll
@@ -825,17 +842,35 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     float acc[kDenseVals];
 #pragma unroll
     for (int k = 0; k < kDenseVals; k++) acc[k] = 0.0f;
+#ifdef BTBA_RAY_TABLES
+    // Rotated rays: the transformed point of source pixel (x, y) with depth d is q = d (R (lx, ly, 1)) + t = d (colA[x] + rowB[y]) + t with
+    // colA[x] = R[:, 0] lx(x), rowB[y] = R[:, 1] ly(y) + R[:, 2] -- two 16-byte LDS reads, 3 adds and 3 FMAs per pixel instead of 2 reads,
+    // 2 multiplies and 12 operations with a scalar-register operand (which issue at half rate, profiles/r02/valu_calibration.md).
+    float4 *colA = reinterpret_cast<float4 *>(lut + ((D.width + D.height + 3) & ~3));
+    float4 *rowB = colA + D.width;
+    for (int e = (int)threadIdx.x; e < D.width + D.height; e += kBlock) {
+        const float l = lut[e];
+        if (e < D.width) colA[e] = make_float4(C.R[0] * l, C.R[3] * l, C.R[6] * l, 0.0f);
+        else rowB[e - D.width] = make_float4(C.R[1] * l + C.R[2], C.R[4] * l + C.R[5], C.R[7] * l + C.R[8], 0.0f);
+    }
+    if (WALK != 2) __syncthreads();           // (the block walk's pre-pass has barriers of its own before the first pixel)
+#endif
 
-    // one source pixel: zs = its (gated depth, normal), ox / oy = LDS byte offsets of its column / row terms
+    // one source pixel: zs = its (gated depth, normal), ox / oy = LDS byte offsets of its column / row terms (ray tables: of its 16-byte entries, from colA)
     auto pixel = [&](const float4 &zs, unsigned ox, unsigned oy) {
         // source pixel -> camera space (gated depth: 0 where invalid), depth-range test on the bit pattern
         const float d = zs.x;
         const bool src_ok = (__float_as_uint(d) - C.zmin_bits) < C.zrange_bits;
-        const float sx = lds_f32_at(lut, ox) * d, sy = lds_f32_at(lut, oy) * d;
         // transform the point, project
+#ifdef BTBA_RAY_TABLES
+        const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(colA) + ox), rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(colA) + oy);
+        const float qx = (ra.x + rb.x) * d + C.t[0], qy = (ra.y + rb.y) * d + C.t[1], qz = (ra.z + rb.z) * d + C.t[2];
+#else
+        const float sx = lds_f32_at(lut, ox) * d, sy = lds_f32_at(lut, oy) * d;
         const float qx = C.R[0] * sx + C.R[1] * sy + C.R[2] * d + C.t[0];
         const float qy = C.R[3] * sx + C.R[4] * sy + C.R[5] * d + C.t[1];
         const float qz = C.R[6] * sx + C.R[7] * sy + C.R[8] * d + C.t[2];
+#endif
         const float rqz = fast_rcp(qz);
         const float u = qx * C.fx * rqz + C.cx, v = qy * C.fy * rqz + C.cy;
         const float uc = __builtin_amdgcn_fmed3f(u, 0.0f, C.wm1), vc = __builtin_amdgcn_fmed3f(v, 0.0f, C.hm1);      // NaN -> 0: addresses stay in the frame
@@ -847,7 +882,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const float nqz = C.R[6] * zs.y + C.R[7] * zs.z + C.R[8] * zs.w;
         // taps (x0, x0 + 1) x (y0, y0 + 1) with x0 = min(floor(uc), W - 2): at the right / bottom edge (uc = W - 1) the weights are (0, 1)
         // instead of (1, -) -- the same blend, and the four taps are always the 2 x 2 block at ONE computed address
-        const float fx0 = fminf(floorf(uc), C.wm2), fy0 = fminf(floorf(vc), C.hm2);
+        const float fx0 = min_raw(floorf(uc), C.wm2), fy0 = min_raw(floorf(vc), C.hm2);
         const float alpha = uc - fx0, beta = vc - fy0;
         const unsigned o00 = (unsigned)(fy0 * C.w16 + 16.0f * fx0), o01 = o00 + C.row16;      // byte offsets, fp32-exact below 2^24
         const float4 z00 = gather16(zn_t, o00), z10 = gather16(zn_t, o00 + 16u), z01 = gather16(zn_t, o01), z11 = gather16(zn_t, o01 + 16u);
@@ -872,7 +907,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         auto masked = [keep](float x) { return __uint_as_float(__float_as_uint(x) & keep); };
         const float res = masked(-(dx * nix + dy * niy + dz * niz));
         // Huber (SolverBundlingUtil.h:24-40) times the dense weight: rho' = 1 for e <= delta^2, delta / sqrt(e) above  <=>  min(1, delta rsq(e))
-        const float wgt = masked(fminf(C.w_dense, C.wdelta * fast_rsq(res * res)));
+        const float wgt = masked(min_raw(C.w_dense, C.wdelta * fast_rsq(res * res)));
         const float mx = masked(nix), my = masked(niy), mz = masked(niz);
         const float a[6] = { -mx, -my, -mz, my * qz - mz * qy, mz * qx - mx * qz, mx * qy - my * qx };
         int k = 0;
@@ -922,7 +957,11 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const int rows_per = (bh + D.dense_tiles - 1) / D.dense_tiles;
         const int r0 = min(bh, rows_per * tile), r1 = min(bh, rows_per * (tile + 1));
         const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#ifdef BTBA_RAY_TABLES
+        int *hdr = reinterpret_cast<int *>(rowB + D.height);                // [0 .. 4) wave totals, [4] running total
+#else
         int *hdr = reinterpret_cast<int *>(lut + D.width + D.height);       // [0 .. 4) wave totals, [4] running total
+#endif
         unsigned *blist = reinterpret_cast<unsigned *>(hdr + 8);
         const int nb = (r1 - r0) * bw;
         const float2 *rng = D.block_ranges ? D.block_ranges + (fb + fj) * (size_t)(bw * bh) : nullptr;
@@ -972,24 +1011,36 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
             __syncthreads();
         }
         n_live = __builtin_amdgcn_readfirstlane(n_live);
+#ifdef BTBA_WG_TRACE
+        if (threadIdx.x == 0) { wg_dbg[0] = wall_clock64(); wg_dbg[2] = (unsigned long long)n_live; }
+#endif
         const unsigned lx = (unsigned)lane & 7u, ly = (unsigned)lane >> 3;
         const unsigned lane_px = ly * (unsigned)D.width + lx;          // pixel offset of the lane inside its block
+#ifdef BTBA_RAY_TABLES
+        const unsigned ox_l = 16u * lx, oy_l = 16u * ly + 16u * (unsigned)D.width;
+        constexpr unsigned kBlockStep = 128u;            // 8 entries of 16 bytes
+#else
         const unsigned ox_l = 4u * lx, oy_l = 4u * ly + 4u * (unsigned)D.width;
+        constexpr unsigned kBlockStep = 32u;
+#endif
         // this wave's current and next block (scalar registers), the next block's pixels in flight while the current one is worked on
         int k = wave;
         unsigned code_n = (k < n_live) ? (unsigned)__builtin_amdgcn_readfirstlane((int)blist[k]) : 0u;
         float4 zs_n = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < n_live) zs_n = zn_s[(unsigned)((int)(code_n >> 16) * 8 * D.width + (int)(code_n & 0xFFFFu) * 8) + lane_px];
+        if (k < n_live) zs_n = gather16(zn_s, 16u * ((code_n >> 16) * 8u * (unsigned)D.width + (code_n & 0xFFFFu) * 8u + lane_px));
         while (k < n_live) {
             const float4 zs = zs_n;
             const unsigned code = code_n;
             k += kBlock / 64;
             if (k < n_live) {
                 code_n = (unsigned)__builtin_amdgcn_readfirstlane((int)blist[k]);
-                zs_n = zn_s[(unsigned)((int)(code_n >> 16) * 8 * D.width + (int)(code_n & 0xFFFFu) * 8) + lane_px];
+                zs_n = gather16(zn_s, 16u * ((code_n >> 16) * 8u * (unsigned)D.width + (code_n & 0xFFFFu) * 8u + lane_px));
             }
-            pixel(zs, ox_l + 32u * (code & 0xFFFFu), oy_l + 32u * (code >> 16));
+            pixel(zs, ox_l + kBlockStep * (code & 0xFFFFu), oy_l + kBlockStep * (code >> 16));
         }
+#ifdef BTBA_WG_TRACE
+        if (threadIdx.x == 0) wg_dbg[1] = wall_clock64();
+#endif
     } else {
         const int n_src = LISTS ? valid_counts[slot_s] : D.npix;
         const uint32_t *list = LISTS ? valid_lists + slot_s * (size_t)D.npix : nullptr;
@@ -1019,11 +1070,15 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
                 const float pyf = floorf((sf + 0.5f) * inv_w);              // exact: the margin 0.5 / W is far above the rounding of the product
                 ox = (unsigned)(4.0f * (sf - pyf * (float)D.width)); oy = (unsigned)(4.0f * pyf + C.ybase4);
             }
+#ifdef BTBA_RAY_TABLES
+            pixel(zs, 4u * ox, 4u * oy);                  // 4-byte table offsets -> 16-byte entries (rowB follows colA as the row table follows the column table)
+#else
             pixel(zs, ox, oy);
+#endif
         }
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
-    dense_epilogue(acc, red, out, T + 16 * (fb + fi));
+    dense_epilogue(acc, red, out);
 }
 
 template <bool SIMPLE, bool LISTS>
@@ -1038,10 +1093,10 @@ __global__ void __launch_bounds__(kBlock, 5) k_dense_sweep_zn(SolveDims D, const
     const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
     const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
     // pinhole intrinsics: the same block as in the fused launch (same partial sums, bit for bit)
-    if (SIMPLE && LISTS) dense_block_pinhole<1>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
-    else if (SIMPLE && D.walk_blocks) dense_block_pinhole<2>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
-    else if (SIMPLE) dense_block_pinhole<0>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
-    else dense_block_zn<false, LISTS>(D, zn, dense_pairs, T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+    if (SIMPLE && LISTS) dense_block_pinhole<1>(D, zn, dense_pairs[p], T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+    else if (SIMPLE && D.walk_blocks) dense_block_pinhole<2>(D, zn, dense_pairs[p], T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+    else if (SIMPLE) dense_block_pinhole<0>(D, zn, dense_pairs[p], T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+    else dense_block_zn<false, LISTS>(D, zn, dense_pairs[p], T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
 }
 
 // 1-D grid of dense_tiles * Pd * B workgroups (XCD-remapped).
@@ -1054,7 +1109,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_dense_sweep(SolveDims D, const fl
     const int tile = (int)(L % (unsigned)D.dense_tiles);
     const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
     const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
-    dense_block(D, campos, normals, dense_pairs, T, Tinv, partials, tile, p, b, red);
+    dense_block(D, campos, normals, dense_pairs[p], T, Tinv, partials, tile, p, b, red);
 }
 
 // Both sweeps of one Gauss-Newton iteration in ONE launch: n_d dense workgroups (VALU-bound) interleaved with
@@ -1095,20 +1150,26 @@ __device__ __forceinline__ void fused_item(const SolveDims &D, unsigned n_d, uns
         const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
         const unsigned Lb = L - (unsigned)b * (unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs;
         const int tile = D.tile_major ? (int)(Lb / (unsigned)D.n_dense_pairs) : (int)(Lb % (unsigned)D.dense_tiles);
-        const int p = D.tile_major ? (int)(Lb % (unsigned)D.n_dense_pairs) : (int)(Lb / (unsigned)D.dense_tiles);
-        if (LAYOUT == 0) dense_block(D, campos, normals, dense_pairs, T, Tinv, dense_partials, tile, p, b, red);
-        else if (LAYOUT == 1 && D.walk_blocks) dense_block_pinhole<2>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
-        else if (LAYOUT == 1) dense_block_pinhole<0>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);     // `campos` carries the compact cache
-        else if (LAYOUT == 2) dense_block_zn<false, false>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
-        else if (LAYOUT == 3) dense_block_pinhole<1>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
-        else dense_block_zn<false, true>(D, campos, dense_pairs, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+        int p = D.tile_major ? (int)(Lb % (unsigned)D.n_dense_pairs) : (int)(Lb / (unsigned)D.dense_tiles);
+        // work order: the pairs of a band heaviest first, so that the workgroups still running when the launch drains are short ones;
+        // a work-table entry is (target, source, pair, -): one load instead of order -> pair list
+        int2 ij;
+        if (D.dense_work) { const int4 w = D.dense_work[(size_t)b * D.dense_work_stride + p]; ij = make_int2(w.x, w.y); p = w.z; }
+        else ij = dense_pairs[p];
+        if (LAYOUT == 0) dense_block(D, campos, normals, ij, T, Tinv, dense_partials, tile, p, b, red);
+        else if (LAYOUT == 1 && D.walk_blocks) dense_block_pinhole<2>(D, campos, ij, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+        else if (LAYOUT == 1) dense_block_pinhole<0>(D, campos, ij, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);     // `campos` carries the compact cache
+        else if (LAYOUT == 2) dense_block_zn<false, false>(D, campos, ij, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+        else if (LAYOUT == 3) dense_block_pinhole<1>(D, campos, ij, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+        else dense_block_zn<false, true>(D, campos, ij, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
     }
 #ifdef BTBA_WG_TRACE
     if (D.wg_trace && threadIdx.x == 0) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n s_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
         unsigned long long *q = D.wg_trace + 4 * (size_t)g;
-        q[0] = wg_t0; q[1] = wall_clock64(); q[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32); q[3] = is_sparse ? 1u : 0u;
+        q[0] = wg_t0; q[1] = wall_clock64(); q[2] = (unsigned long long)(hw & 0xFFFFu) | ((unsigned long long)(xcc & 0xFu) << 16) | ((is_sparse ? 0ull : (wg_dbg[2] & 0xFFFFull)) << 32);
+        q[3] = is_sparse ? 1ull : (((wg_dbg[0] - wg_t0) & 0xFFFFFFull) << 8) | (((wg_dbg[1] - wg_t0) & 0xFFFFFFull) << 32);      // kind | prologue end | loop end (ticks from start)
     }
 #endif
 }

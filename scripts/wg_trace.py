@@ -32,18 +32,25 @@ def main():
         bs.solve_zn(zn_d, pick[0]["H"], pick[0]["W"], pick[0]["K"], corr_d, offs_d, mx, poses_d)
         ws.sync()
     q = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)
-    t0 = q[:, 0].astype(np.int64); t1 = q[:, 1].astype(np.int64); hw = q[:, 2]; kind = q[:, 3].astype(int)
+    t0 = q[:, 0].astype(np.int64); t1 = q[:, 1].astype(np.int64); hw = q[:, 2]; kind = (q[:, 3] & np.uint64(0xFF)).astype(int)
+    pro = ((q[:, 3] >> np.uint64(8)) & np.uint64(0xFFFFFF)).astype(np.int64) / 100.0          # dense items: end of prologue / end of pixel loop, us from start
+    loop_end = ((q[:, 3] >> np.uint64(32)) & np.uint64(0xFFFFFF)).astype(np.int64) / 100.0
+    n_live = ((hw >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64)
     ok = t1 > 0
     base = t0[ok].min()
     s = (t0 - base) / 100.0; e = (t1 - base) / 100.0          # microseconds
     dur = e - s
-    cu = ((hw >> 32) & 0xF) * 4096 + ((hw >> 8) & 0xFF)        # (xcc, se / sh / cu bits of HW_ID)
+    cu = ((hw >> np.uint64(16)) & np.uint64(0xF)) * np.uint64(4096) + ((hw >> np.uint64(8)) & np.uint64(0xFF))        # (xcc, se / sh / cu bits of HW_ID)
     span = float(e[ok].max())
     out = {"workgroups": int(ok.sum()), "missing": int((~ok).sum()), "span_us": round(span, 2), "distinct_cus": int(len(np.unique(cu[ok])))}
     for k, name in ((0, "dense"), (1, "sparse")):
         d = dur[ok & (kind == k)]
         out[name] = {"n": int(d.size), "mean_us": round(float(d.mean()), 2), "p10": round(float(np.percentile(d, 10)), 2), "p50": round(float(np.percentile(d, 50)), 2),
                      "p90": round(float(np.percentile(d, 90)), 2), "max": round(float(d.max()), 2), "sum_ms": round(float(d.sum()) / 1e3, 3)}
+    dn = ok & (kind == 0)
+    ph = {"prologue_us": pro[dn], "pixel_loop_us": (loop_end - pro)[dn], "epilogue_us": (dur - loop_end)[dn]}
+    out["dense_phases"] = {k: {"mean": round(float(v.mean()), 2), "p10": round(float(np.percentile(v, 10)), 2), "p90": round(float(np.percentile(v, 90)), 2)} for k, v in ph.items()}
+    out["dense_live_blocks"] = {"mean": round(float(n_live[dn].mean()), 1), "us_per_live_block_per_wave_trip": round(float((loop_end - pro)[dn].sum() / max(n_live[dn].sum(), 1) * 4), 3)}
     # running workgroups over time
     edges = np.linspace(0, span, 41)
     running = [(int(((s <= t) & (e > t) & ok).sum())) for t in edges[:-1] + (edges[1] - edges[0]) / 2]
