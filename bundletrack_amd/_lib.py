@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
     "btba_process_depth", "btba_depth_to_normals",
-    "btba_build_cache_zn", "btba_pack_zn", "btba_solve_batch_zn",
+    "btba_build_cache_zn", "btba_pack_zn", "btba_solve_batch_zn", "btba_zn_block_ranges", "btba_solve_batch_zn_ranges",
 ]
 
 
@@ -166,6 +166,9 @@ def lib() -> C.CDLL:
         L.btba_pack_zn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.btba_solve_batch_zn.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.btba_zn_block_ranges.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.btba_solve_batch_zn_ranges.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.btba_process_depth.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
         L.btba_depth_to_normals.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L

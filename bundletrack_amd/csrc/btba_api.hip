@@ -82,7 +82,7 @@ struct btba_workspace {
     // persistent frame cache (btba_optimize_frames_keyed): compact (z, n) frames, their valid-pixel lists and counts
     // live in pool slots that survive across calls; a keyframe is cached once, not once per BA call.
     struct FrameSlot { uint64_t key = 0; const float *depth = nullptr, *normal = nullptr; uint64_t stamp = 0; bool live = false; int32_t n_valid = 0; };
-    DevBuf pool_zn, pool_lists, pool_counts, pool_nvalid, pool_map;
+    DevBuf pool_zn, pool_lists, pool_counts, pool_nvalid, pool_map, pool_ranges;
     // keyed correspondence cache (BTBA_FLAG_KEYED_CORR): the EntryJ segment of a frame PAIR stays on the device under the pair's two
     // frame keys; a sliding window then uploads only the new frame's K - 1 segments
     struct CorrSeg { uint32_t off = 0, count = 0; };
@@ -177,7 +177,7 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A, &ws->solve_tab,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts, &ws->block_ranges,
-                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->ransac, &ws->corr_pool, &ws->corr_desc };
+                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->corr_pool, &ws->corr_desc };
     for (auto b : bufs) b->release();
     if (ws->corr_stage) (void)hipHostFree(ws->corr_stage);
     for (auto st : ws->aux_streams) if (st) (void)hipStreamDestroy(st);
@@ -339,6 +339,7 @@ struct ZnSpec {      // compact cache + the full-res geometry it encodes
     const float *zn = nullptr; int H = 0, W = 0; const float *K = nullptr;
     const int *frame_slot = nullptr;                       // persistent cache: device int[N], frame -> pool slot (B == 1 only)
     const uint32_t *lists = nullptr; const int *counts = nullptr;   // valid-pixel lists already built per slot
+    const float *block_ranges = nullptr;                   // per (slot, 8 x 8 block) depth ranges already built (btba_zn_block_ranges / the pool)
 };
 
 static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int N, int Hd, int Wd, const float *intr,
@@ -513,9 +514,12 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         blist_bytes = 32 + sizeof(uint32_t) * (size_t)((bh + tiles - 1) / tiles) * bw;
         if (blist_bytes > 16384) { D.walk_blocks = 0; blist_bytes = 0; }        // very large caches: row strips
         else if (!std::getenv("BTBA_NO_BLOCK_SKIP")) {                          // developer A/B: walk every block
-            if ((rc = ws->block_ranges.ensure(sizeof(float2) * (size_t)B * N * bw * bh))) return rc;
-            k_block_ranges<<<dim3((unsigned)((bw * bh + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)(B * N)), kBlock, 0, ws->stream>>>(Wd, Hd, prm->depth_min, prm->depth_max, reinterpret_cast<const float4 *>(Z.zn), Z.frame_slot, ws->block_ranges.as<float2>());
-            D.block_ranges = ws->block_ranges.as<float2>();
+            if (Z.block_ranges) D.block_ranges = reinterpret_cast<const float2 *>(Z.block_ranges);      // part of the caller's / the pool's frame cache
+            else if (!Z.frame_slot) {                                           // not given: one pass over the frames per solve
+                if ((rc = ws->block_ranges.ensure(sizeof(float2) * (size_t)B * N * bw * bh))) return rc;
+                k_block_ranges<<<dim3((unsigned)((bw * bh + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)(B * N)), kBlock, 0, ws->stream>>>(Wd, Hd, reinterpret_cast<const float4 *>(Z.zn), nullptr, ws->block_ranges.as<float2>());
+                D.block_ranges = ws->block_ranges.as<float2>();
+            }
         }
     }
     // Software pipelining across instances: the batch is split in two halves on two streams, so one half's
@@ -948,7 +952,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     ZnSpec Z;
     if (compact) {
         Z.zn = keyed ? ws->pool_zn.as<float>() : ws->campos.as<float>(); Z.H = H; Z.W = W; Z.K = K;
-        if (keyed) { Z.frame_slot = ws->pool_map.as<int>(); Z.lists = ws->pool_lists.as<uint32_t>(); Z.counts = ws->pool_counts.as<int>(); }
+        if (keyed) { Z.frame_slot = ws->pool_map.as<int>(); Z.lists = ws->pool_lists.as<uint32_t>(); Z.counts = ws->pool_counts.as<int>(); if (Wd % 8 == 0 && Hd % 8 == 0) Z.block_ranges = ws->pool_ranges.as<float>(); }
         if (!(prm.flags & (BTBA_FLAG_COMPACTION | BTBA_FLAG_NO_COMPACTION))) {
             // a tracker's frames are masked to the object: walk valid-pixel lists when under 60 % of the pixels carry a depth.
             // (the cache builder counted them; this call is synchronous anyway, so the 4*N-byte read-back costs nothing extra)
@@ -1060,6 +1064,7 @@ static int pool_resolve(btba_workspace *ws, int N, int H, int W, int Hd, int Wd,
         if ((rc = ws->pool_zn.ensure(sizeof(float) * 4 * cap * npix))) return rc;
         if ((rc = ws->pool_lists.ensure(sizeof(uint32_t) * cap * npix))) return rc;
         if ((rc = ws->pool_counts.ensure(sizeof(int) * cap))) return rc;
+        if ((rc = ws->pool_ranges.ensure(sizeof(float2) * cap * (size_t)((Wd / 8) * (Hd / 8) + 1)))) return rc;
         if ((rc = ws->pool_nvalid.ensure(sizeof(int32_t) * cap))) return rc;
         ws->pool_slots.assign(cap, btba_workspace::FrameSlot{});
         ws->pool_H = H; ws->pool_W = W; ws->pool_npix = npix; ws->pool_downscale = downscale;
@@ -1110,6 +1115,8 @@ static int pool_resolve(btba_workspace *ws, int N, int H, int W, int Hd, int Wd,
         k_build_cache_zn<<<dim3((npix + kBlock - 1) / kBlock, M), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, ws->ptrs.as<const float *>(), ws->ptrs.as<const float *>() + M,
                                                                                         ws->pool_zn.as<float4>(), ws->pool_nvalid.as<int32_t>(), slots_dev);
         k_valid_lists<<<M, 1024, 0, ws->stream>>>(npix, ws->pool_zn.as<const float4>(), ws->pool_lists.as<uint32_t>(), ws->pool_counts.as<int>(), slots_dev);
+        if (Wd % 8 == 0 && Hd % 8 == 0)          // the block walk's dead-block test: depth range of every 8 x 8 block of the new frames
+            k_block_ranges<<<dim3((unsigned)(((Wd / 8) * (Hd / 8) + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)M), kBlock, 0, ws->stream>>>(Wd, Hd, ws->pool_zn.as<const float4>(), slots_dev, ws->pool_ranges.as<float2>());
         if ((rc = time_end(ws, tslot))) return rc;
         HIP_TRY(hipGetLastError());
         std::vector<int32_t> nvh(cap);
@@ -1208,10 +1215,28 @@ int btba_pack_zn(btba_workspace *ws, int64_t n_pixels_total, const float *campos
     return BTBA_OK;
 }
 
+int btba_zn_block_ranges(btba_workspace *ws, int n_frames_total, int Hd, int Wd, const float *zn_dev, float *ranges_dev)
+{
+    if (!ws || n_frames_total < 1 || Hd < 8 || Wd < 8 || (Hd % 8) || (Wd % 8) || !zn_dev || !ranges_dev) return BTBA_EINVAL;
+    const int nblk = (Wd / 8) * (Hd / 8);
+    k_block_ranges<<<dim3((unsigned)((nblk + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)n_frames_total), kBlock, 0, ws->stream>>>(Wd, Hd, reinterpret_cast<const float4 *>(zn_dev), nullptr, reinterpret_cast<float2 *>(ranges_dev));
+    HIP_TRY(hipGetLastError());
+    return BTBA_OK;
+}
+
 int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames, int H, int W, const float *K,
                         const float *zn_dev, const btba_entryj *corr_dev, int64_t corr_stride,
                         const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
                         float *poses_dev, float *trace_dev)
+{
+    return btba_solve_batch_zn_ranges(ws, params, n_instances, n_frames, H, W, K, zn_dev, nullptr, corr_dev, corr_stride, pair_offsets_dev, max_corr_per_pair,
+                                      dense_pairs, n_dense_pairs, poses_dev, trace_dev);
+}
+
+int btba_solve_batch_zn_ranges(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames, int H, int W, const float *K,
+                               const float *zn_dev, const float *block_ranges_dev, const btba_entryj *corr_dev, int64_t corr_stride,
+                               const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
+                               float *poses_dev, float *trace_dev)
 {
     if (!ws || !params || !K || !zn_dev || H < 2 || W < 2 || !(params->image_downscale >= 1.0f)) return BTBA_EINVAL;
     const int Wd = (int)(W / params->image_downscale), Hd = (int)(H / params->image_downscale);
@@ -1224,7 +1249,7 @@ int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, int n_ins
         ws->events.clear();
     }
     ZnSpec Z;
-    Z.zn = zn_dev; Z.H = H; Z.W = W; Z.K = K;
+    Z.zn = zn_dev; Z.H = H; Z.W = W; Z.K = K; Z.block_ranges = block_ranges_dev;
     return solve_enqueue(ws, params, n_instances, n_frames, Hd, Wd, intr, nullptr, nullptr, Z, corr_dev, corr_stride,
                          pair_offsets_dev, max_corr_per_pair, dense_pairs, dense_pairs ? n_dense_pairs : -1, poses_dev, trace_dev);
 }

@@ -76,7 +76,7 @@ struct SolveDims {
 #endif
     const int4 *dense_work;       // fused sweep: work position -> (target, source, dense pair, -), heaviest pairs first (nullptr: list order)
     int dense_work_stride;        // entries per instance (0: one table for all)
-    const float2 *block_ranges;   // per (frame of the solve, 8 x 8 block): [min, max] usable depth (k_block_ranges); nullptr: no block is skipped
+    const float2 *block_ranges;   // per (cache slot, 8 x 8 block): [min, max] valid depth (k_block_ranges); nullptr: no block is skipped
     int tile_major;      // dense work order inside an instance: 1 = (tile, pair) -- all pairs' band t of the images together -- 0 = (pair, tile)
     int *order_flag;     // non-null: the sparse sweep ORs 1 into it when an entry does not belong to the pair of its segment
     // compact (z, nx, ny, nz) frame cache: how a cached pixel maps back to camera space -- the arithmetic of k_build_cache
@@ -581,25 +581,22 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
 }
 
 // ---- per-block depth ranges of the compact cache ------------------------------------------------------------------
-// [min, max] of the depths the dense sweep can use (depth_min < z < depth_max on the gated depth, the sweep's own bit-pattern
-// test) per 8 x 8 pixel block of every frame of the solve; an empty block gets (+inf, -inf).  Once per solve: the frames do
-// not change across Gauss-Newton iterations.  One wave per block, lane = pixel, butterfly min / max.
-__global__ void __launch_bounds__(kBlock) k_block_ranges(int width, int height, float depth_min, float depth_max, const float4 *__restrict__ zn,
-                                                         const int *__restrict__ frame_slot, float2 *__restrict__ ranges)
+// [min, max] of the valid (gated: non-zero) depths per 8 x 8 pixel block of a cached frame; an empty block gets (+inf, -inf).
+// Part of the frame cache: built once per frame (pool slot), not per solve.  One wave per block, lane = pixel, butterfly min / max;
+// grid (blocks / 4, frames): one load per lane and no loop -- a single memory round trip deep.
+__global__ void __launch_bounds__(kBlock) k_block_ranges(int width, int height, const float4 *__restrict__ zn, const int *__restrict__ slots, float2 *__restrict__ ranges)
 {
-    // grid (blocks / 4, frames): one load per lane and no loop -- the kernel is a single memory round trip deep
-    const int f = (int)blockIdx.y, slot = frame_slot ? frame_slot[f] : f;
+    const int slot = slots ? slots[blockIdx.y] : (int)blockIdx.y;
     const int bw = width >> 3, nblk = bw * (height >> 3);
     const int lane = (int)threadIdx.x & 63, blk = (int)blockIdx.x * (kBlock / 64) + ((int)threadIdx.x >> 6);
     if (blk >= nblk) return;
-    const unsigned zmin_bits = __float_as_uint(depth_min) + 1u, zrange_bits = __float_as_uint(depth_max) - __float_as_uint(depth_min) - 1u;
     const int by = blk / bw, bx = blk - by * bw;
     const float d = zn[(size_t)slot * width * height + (size_t)((by * 8 + (lane >> 3)) * width + bx * 8 + (lane & 7))].x;
-    const bool ok = (__float_as_uint(d) - zmin_bits) < zrange_bits;
+    const bool ok = d > 0.0f;                              // gated depth: 0 where invalid; NaN compares false
     float lo = ok ? d : INFINITY, hi = ok ? d : -INFINITY;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { lo = fminf(lo, __shfl_xor(lo, m)); hi = fmaxf(hi, __shfl_xor(hi, m)); }
-    if (lane == 0) ranges[(size_t)f * nblk + blk] = make_float2(lo, hi);
+    if (lane == 0) ranges[(size_t)slot * nblk + blk] = make_float2(lo, hi);
 }
 
 // Ordered list of the pixels of every frame that carry a depth (>= 0.1 m, the cache builder's validity rule).
@@ -964,7 +961,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
 #endif
         unsigned *blist = reinterpret_cast<unsigned *>(hdr + 8);
         const int nb = (r1 - r0) * bw;
-        const float2 *rng = D.block_ranges ? D.block_ranges + (fb + fj) * (size_t)(bw * bh) : nullptr;
+        const float2 *rng = D.block_ranges ? D.block_ranges + slot_s * (size_t)(bw * bh) : nullptr;
         int n_live = 0;
         for (int c0 = 0; c0 < nb; c0 += kBlock) {
             const int idx = c0 + (int)threadIdx.x;
@@ -975,7 +972,8 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
                 code = ((unsigned)byg << 16) | (unsigned)bxl;
                 live = true;
                 if (rng) {
-                    const float2 zr = rng[byg * bw + bxl];
+                    float2 zr = rng[byg * bw + bxl];
+                    zr.x = fmaxf(zr.x, D.depth_min); zr.y = fminf(zr.y, D.depth_max);      // usable depths: depth_min < z < depth_max
                     live = zr.x <= zr.y;
                     if (live) {
                         const float xa = lut[8 * bxl], xb = lut[8 * bxl + 7], ya = lut[D.width + 8 * byg], yb = lut[D.width + 8 * byg + 7];

@@ -319,6 +319,20 @@ BTBA_API int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, 
                                  const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair,
                                  const int32_t *dense_pairs, int n_dense_pairs, float *poses_dev, float *trace_dev);
 
+/* Depth range [min, max] of the valid pixels of every 8 x 8 block of compact caches (Hd, Wd multiples of 8): ranges_dev float2
+ * [n_frames_total][(Hd / 8) * (Wd / 8)], (+inf, -inf) for a block without a valid depth.  PART OF THE FRAME CACHE: it depends on the
+ * frames only (not on poses or parameters), so a caller that keeps its caches across solves builds it once per frame and hands it to
+ * btba_solve_batch_zn_ranges; the pinhole dense sweep uses it to drop 8 x 8 blocks that provably project outside the target image
+ * before touching their pixels (exact: DESIGN.md 4.2).  btba_solve_batch_zn computes it per solve (one pass over the frames);
+ * btba_optimize_frames / _keyed keep it with their frame cache.  Asynchronous on the workspace stream. */
+BTBA_API int btba_zn_block_ranges(btba_workspace *ws, int n_frames_total, int Hd, int Wd, const float *zn_dev, float *ranges_dev);
+/* btba_solve_batch_zn with the caches' block ranges supplied (block_ranges_dev NULL: as btba_solve_batch_zn). */
+BTBA_API int btba_solve_batch_zn_ranges(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames,
+                                        int H, int W, const float *K_rowmajor, const float *zn_dev, const float *block_ranges_dev,
+                                        const btba_entryj *corr_dev, int64_t corr_stride,
+                                        const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair,
+                                        const int32_t *dense_pairs, int n_dense_pairs, float *poses_dev, float *trace_dev);
+
 /* ---- correspondence RANSAC (the step before correspondences enter BA) ------------
  * Replaces ransacMultiPairGPU (src/cuda/cuda_ransac.cu:1228-1323) as called by SiftManager::runRansacMultiPairGPU
  * (FeatureManager.cpp:659-741): for every frame pair, n_trials 3-point rigid hypotheses ptsA -> ptsB, inlier vote with

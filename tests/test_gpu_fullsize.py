@@ -119,6 +119,21 @@ def test_dead_block_skip_is_exact(gpu, monkeypatch):
         for k in range(15):
             r, t = S.pose_error(out_a[b, k], out_b[b, k])
             assert r < 5e-5 and t < 5e-5, (b, k, r, t)
+    # block ranges built once with the cache (btba_zn_block_ranges) and handed to the solve: the same bits as computing them per solve
+    bs = gpu.BatchSolver(gpu.ws)
+    corr, offs, mx = bs.pack_correspondences([pb.corr for pb in pbs], 15)
+    zn_d = gpu.torch.from_numpy(np.stack([S.compact_cache(pb) for pb in pbs])).to(gpu.dev)
+    corr_d = gpu.torch.from_numpy(corr.view(np.uint8).reshape(len(pbs), -1, 32)).to(gpu.dev)
+    offs_d = gpu.torch.from_numpy(offs.astype(np.int32)).to(gpu.dev)
+    poses_d = gpu.torch.from_numpy(np.stack([pb.poses_init for pb in pbs])).to(gpu.dev)
+    rng_d = bs.block_ranges(zn_d)
+    bs.solve_zn(zn_d, pbs[0].H, pbs[0].W, pbs[0].K, corr_d, offs_d, mx, poses_d, block_ranges=rng_d)
+    assert np.array_equal(poses_d.cpu().numpy(), out_a)
+    rng = rng_d.cpu().numpy().reshape(len(pbs), 15, -1, 2)
+    z = np.stack([S.compact_cache(pb) for pb in pbs])[..., 0]
+    zb = z.reshape(len(pbs), 15, z.shape[2] // 8, 8, z.shape[3] // 8, 8).transpose(0, 1, 2, 4, 3, 5).reshape(len(pbs), 15, -1, 64)
+    lo = np.where(zb > 0, zb, np.inf).min(-1); hi = np.where(zb > 0, zb, -np.inf).max(-1)
+    assert np.array_equal(rng[..., 0], lo) and np.array_equal(rng[..., 1], hi)
 
 
 def test_c5_shape_batch_properties(gpu):
