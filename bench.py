@@ -254,15 +254,16 @@ def main():
     intr = pick[0]["intr"]
     n_corr = int(sum(len(p["corr"]) for p in pick))
 
-    # the caches' per-block depth ranges belong to the frame cache (they depend on the frames only): built here, with the cache, once
-    ranges_d = None if (args.float4_cache or cam_d.shape[2] % 8 or cam_d.shape[3] % 8) else bs.block_ranges(cam_d)
+    # what the solve derives from the caches alone (per-block depth ranges; the valid-pixel lists of masked frames) belongs to the frame
+    # cache: built here, with the caches, once
+    aux_d = None if args.float4_cache else bs.cache_aux(cam_d, valid_lists=bool(bs.params.flags & _lib.FLAG_COMPACTION))
 
     def step():
         poses_d.copy_(poses0)                               # pose in ...
         if args.float4_cache:
             bs.solve(cam_d, nrm_d, intr, corr_d, offs_d, mx, poses_d)   # ... pose out (7 GN iterations per instance)
         else:
-            bs.solve_zn(cam_d, pick[0]["H"], pick[0]["W"], pick[0]["K"], corr_d, offs_d, mx, poses_d, block_ranges=ranges_d)
+            bs.solve_zn(cam_d, pick[0]["H"], pick[0]["W"], pick[0]["K"], corr_d, offs_d, mx, poses_d, aux=aux_d)
 
     note("warm-up")
     for _ in range(args.warmup):
@@ -375,7 +376,7 @@ def main():
                 if args.float4_cache:
                     bs1.solve(cam_d[:1], nrm_d[:1], intr, c1d, o1d, m1, p)
                 else:
-                    bs1.solve_zn(cam_d[:1], pick[0]["H"], pick[0]["W"], pick[0]["K"], c1d, o1d, m1, p, block_ranges=None if ranges_d is None else ranges_d[:K])
+                    bs1.solve_zn(cam_d[:1], pick[0]["H"], pick[0]["W"], pick[0]["K"], c1d, o1d, m1, p, aux=None if aux_d is None else {k: v[:K] for k, v in aux_d.items()})
             for _ in range(5):
                 p1.copy_(poses0[:1]); one(p1)
             torch.cuda.synchronize()

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
     "btba_process_depth", "btba_depth_to_normals",
-    "btba_build_cache_zn", "btba_pack_zn", "btba_solve_batch_zn", "btba_zn_block_ranges", "btba_solve_batch_zn_ranges",
+    "btba_build_cache_zn", "btba_pack_zn", "btba_solve_batch_zn", "btba_zn_block_ranges", "btba_zn_valid_lists", "btba_solve_batch_zn_aux",
 ]
 
 
@@ -64,6 +64,11 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {f[0]: getattr(self, f[0]) for f in self._fields_}
+
+
+class ZnAux(C.Structure):
+    """btba_zn_aux (include/btba.h): device pointers to data derived from compact caches alone."""
+    _fields_ = [("block_ranges", C.c_void_p), ("valid_lists", C.c_void_p), ("valid_counts", C.c_void_p)]
 
 
 class TraceLayout(C.Structure):
@@ -167,8 +172,9 @@ def lib() -> C.CDLL:
         L.btba_solve_batch_zn.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.btba_zn_block_ranges.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        L.btba_solve_batch_zn_ranges.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.btba_zn_valid_lists.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.btba_solve_batch_zn_aux.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(ZnAux),
+                                              C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.btba_process_depth.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
         L.btba_depth_to_normals.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L

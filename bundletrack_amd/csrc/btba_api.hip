@@ -390,6 +390,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         for (int q = 0; q < Pd; q++) { adj[cur[pairs[2 * q]]++] = (q << 1); adj[cur[pairs[2 * q + 1]]++] = (q << 1) | 1; }
         tab.insert(tab.end(), off.begin(), off.end());
         tab.insert(tab.end(), adj.begin(), adj.end());
+        // canonical pair (i < j) -> the dense pair listed as (target i, source j), the one whose cross block the system keeps (-1: none)
+        std::vector<int32_t> first_listed((size_t)N * N, -1);
+        for (int q = Pd - 1; q >= 0; q--) first_listed[(size_t)pairs[2 * q] * N + pairs[2 * q + 1]] = q;
+        for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) tab.push_back(first_listed[(size_t)i * N + j]);
         // work order of the fused sweep's dense items: frames close in the window overlap most (keyframes are in temporal order), so
         // pairs sorted by |i - j| put the long workgroups first and the short ones at the end of the launch, where they drain quickly
         std::vector<int32_t> order(Pd);
@@ -456,7 +460,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     const size_t n = 6 * (size_t)N, ld = 4 * (((n + 3) / 4) | 1);
     // the 6N x 6N matrix lives in the CU's LDS when it fits (N <= BTBA_MAX_FRAMES_LDS with the default pair list); larger
     // windows (up to the reference's 85 frames) keep it in an L2-resident global scratch and run the multi-wave PCG
-    const size_t lds_rest = (6 * ld + 16 + 16 * (size_t)N + 4 * (size_t)D.n_dense_pairs + (size_t)N + 1 + (size_t)P + 288 + ((6 * (size_t)N + 3) & ~(size_t)3)) * sizeof(float);
+    const size_t lds_rest = (6 * ld + 16 + 16 * (size_t)N + 4 * (size_t)D.n_dense_pairs + (size_t)N + 1 + (size_t)P + 288 + (((size_t)P + 3) & ~(size_t)3) + ((6 * (size_t)N + 3) & ~(size_t)3)) * sizeof(float);
     const size_t lds_limit = 160 * 1024;
     const bool a_global = n * ld * sizeof(float) + lds_rest > lds_limit;
     const size_t lds_core = (a_global ? 0 : n * ld * sizeof(float)) + lds_rest;
@@ -1224,19 +1228,27 @@ int btba_zn_block_ranges(btba_workspace *ws, int n_frames_total, int Hd, int Wd,
     return BTBA_OK;
 }
 
+int btba_zn_valid_lists(btba_workspace *ws, int n_frames_total, int Hd, int Wd, const float *zn_dev, uint32_t *lists_dev, int32_t *counts_dev)
+{
+    if (!ws || n_frames_total < 1 || Hd < 2 || Wd < 2 || !zn_dev || !lists_dev || !counts_dev) return BTBA_EINVAL;
+    k_valid_lists<<<n_frames_total, 1024, 0, ws->stream>>>(Hd * Wd, reinterpret_cast<const float4 *>(zn_dev), lists_dev, counts_dev, nullptr);
+    HIP_TRY(hipGetLastError());
+    return BTBA_OK;
+}
+
 int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames, int H, int W, const float *K,
                         const float *zn_dev, const btba_entryj *corr_dev, int64_t corr_stride,
                         const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
                         float *poses_dev, float *trace_dev)
 {
-    return btba_solve_batch_zn_ranges(ws, params, n_instances, n_frames, H, W, K, zn_dev, nullptr, corr_dev, corr_stride, pair_offsets_dev, max_corr_per_pair,
-                                      dense_pairs, n_dense_pairs, poses_dev, trace_dev);
+    return btba_solve_batch_zn_aux(ws, params, n_instances, n_frames, H, W, K, zn_dev, nullptr, corr_dev, corr_stride, pair_offsets_dev, max_corr_per_pair,
+                                   dense_pairs, n_dense_pairs, poses_dev, trace_dev);
 }
 
-int btba_solve_batch_zn_ranges(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames, int H, int W, const float *K,
-                               const float *zn_dev, const float *block_ranges_dev, const btba_entryj *corr_dev, int64_t corr_stride,
-                               const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
-                               float *poses_dev, float *trace_dev)
+int btba_solve_batch_zn_aux(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames, int H, int W, const float *K,
+                            const float *zn_dev, const btba_zn_aux *aux, const btba_entryj *corr_dev, int64_t corr_stride,
+                            const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
+                            float *poses_dev, float *trace_dev)
 {
     if (!ws || !params || !K || !zn_dev || H < 2 || W < 2 || !(params->image_downscale >= 1.0f)) return BTBA_EINVAL;
     const int Wd = (int)(W / params->image_downscale), Hd = (int)(H / params->image_downscale);
@@ -1249,7 +1261,8 @@ int btba_solve_batch_zn_ranges(btba_workspace *ws, const btba_params *params, in
         ws->events.clear();
     }
     ZnSpec Z;
-    Z.zn = zn_dev; Z.H = H; Z.W = W; Z.K = K; Z.block_ranges = block_ranges_dev;
+    Z.zn = zn_dev; Z.H = H; Z.W = W; Z.K = K;
+    if (aux) { Z.block_ranges = aux->block_ranges; if (aux->valid_lists && aux->valid_counts) { Z.lists = aux->valid_lists; Z.counts = aux->valid_counts; } }
     return solve_enqueue(ws, params, n_instances, n_frames, Hd, Wd, intr, nullptr, nullptr, Z, corr_dev, corr_stride,
                          pair_offsets_dev, max_corr_per_pair, dense_pairs, dense_pairs ? n_dense_pairs : -1, poses_dev, trace_dev);
 }

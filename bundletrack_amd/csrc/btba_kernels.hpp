@@ -1307,7 +1307,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     // reduced pair sums: in LDS when they fit (address space known at compile time -> ds_* instructions, not flat_*),
     // otherwise in an L2-resident global scratch (K = 30)
     float *ps;
-    float *x_l = reinterpret_cast<float *>(entry_lut + 288);       // this iterate's x (6 N floats, padded to 16 bytes): phase D would otherwise start with a fabric-latency load
+    int *cross_l = entry_lut + 288;                                // canonical pair -> the dense pair whose cross block it carries (or -1): P ints, padded to 16 bytes
+    float *x_l = reinterpret_cast<float *>(cross_l + ((D.n_pairs + 3) & ~3));       // this iterate's x (6 N floats, padded to 16 bytes): phase D would otherwise start with a fabric-latency load
     if (LDS_PAIRS) ps = x_l + ((6 * N + 3) & ~3);
     else ps = pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals);
     float *pd = ps + (size_t)D.n_pairs * kSparseVals;          // model-frame dense pair sums (S, g, count)
@@ -1329,6 +1330,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     // canonical pair -> (i << 8 | j) and the 72 entry descriptors: constant per window size, tabulated by the host
     const int st_pij = tid < D.n_pairs ? solve_tab[tid] : 0;
     const int st_lut = tid < 288 ? solve_tab[D.n_pairs + tid] : 0;
+    const int *cross_tab = adj + n_adj;                            // behind the adjacency in the dense pair table (host: solve_enqueue)
+    const int st_cross = (D.use_dense && tid < D.n_pairs) ? cross_tab[tid] : -1;
     // Phase A: fixed-order reduction of the sweep partials
     BTBA_STAMP(6);
     // several items per lane per trip, up to eight partials of each in flight (24-40 loads issued before the first add): the
@@ -1381,48 +1384,47 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     if (tid < 6 * N) x_l[tid] = st_x;                    // 6 N <= 510 < 1 024: one trip
     if (tid < D.n_pairs) pair_ij_l[tid] = st_pij;
     if (tid < 288) entry_lut[tid] = st_lut;
-    for (int e = tid + nthr; e < D.n_pairs; e += nthr) pair_ij_l[e] = solve_tab[e];
+    if (tid < D.n_pairs) cross_l[tid] = st_cross;
+    for (int e = tid + nthr; e < D.n_pairs; e += nthr) { pair_ij_l[e] = solve_tab[e]; cross_l[e] = D.use_dense ? cross_tab[e] : -1; }
     if (tid < n_dp) { dense_pairs_lds[2 * tid] = st_dp.x; dense_pairs_lds[2 * tid + 1] = st_dp.y; }
     if (tid < n_ao) adj_off_l[tid] = st_ao;
     if (tid < n_adj) adj_l[tid] = st_adj;
     for (int e = tid + nthr; e < 16 * N; e += nthr) vT[e] = T[16 * (size_t)b * N + e];
     for (int e = tid + nthr; e < n_dp; e += nthr) { const int2 ij = dense_pairs[e]; dense_pairs_lds[2 * e] = ij.x; dense_pairs_lds[2 * e + 1] = ij.y; }
     for (int e = tid + nthr; e < n_adj; e += nthr) adj_l[e] = adj[e];
-    for (int e = tid; e < n * ld; e += nthr) A[e] = 0.0f;
+    // zero what the assembly below does not write: frame 0's rows and columns (it stays fixed) and the pad columns n .. ld-1 that the
+    // 16-byte mat-vec chunks read; every other entry is assigned by phase B (all canonical pairs with i >= 1, all diagonal blocks k >= 1)
+    for (int e = tid; e < 6 * ld; e += nthr) A[e] = 0.0f;
+    for (int e = tid; e < (n - 6) * (6 + ld - n); e += nthr) {
+        const int row = 6 + e / (6 + ld - n), q = e % (6 + ld - n);
+        A[row * ld + (q < 6 ? q : n + q - 6)] = 0.0f;
+    }
     __syncthreads();
     BTBA_STAMP(0);
     // (the camera-frame -> model-frame congruence of the dense pair sums is done by the sweep workgroups: dense_epilogue)
     if (tr && D.use_dense) for (int e = tid; e < D.n_dense_pairs * kDenseVals; e += nthr) tr[D.tr_dpair + e] = pd[e];
 
     BTBA_STAMP(1);
-    // Phase B1: off-diagonal 6x6 blocks, one canonical pair (i<j) each: A_ij = -(ws Ji^T Jj + S_dense)
+    // Phase B1: off-diagonal 6x6 blocks, one canonical pair (i<j) each: A_ij = -(ws Ji^T Jj + S_dense).  The dense part comes from the
+    // dense pair listed as (target i, source j) for this canonical pair, if any (cross_l; a pair listed the other way round is erased
+    // by the reference's FlipJtJ, duplicates of a pair in an explicit list are not supported -- documented): ONE pass, no
+    // read-modify-write, no barrier before the diagonal blocks.
     for (int e = tid; e < D.n_pairs * 36; e += nthr) {
-        const int p = e / 36, r = (e % 36) / 6, c = e % 6;
-        const int i = pair_ij_l[p] >> 8, j = pair_ij_l[p] & 255;
+        const int p = e / 36, rc = e - 36 * p, r = rc / 6, c = rc - 6 * r;
+        const int pij = pair_ij_l[p];
+        const int i = pij >> 8, j = pij & 255;
         if (i == 0) continue;
         float v = 0.0f;
         if (D.use_sparse) {
-            const int *dl = entry_lut + 4 * (36 + e % 36);
+            const int *dl = entry_lut + 4 * (36 + rc);
             const int4 d = make_int4(dl[0], dl[1], dl[2], dl[3]);
             const float *rec = ps + (size_t)p * kSparseVals;
             v = -D.w_sparse * (__int_as_float(d.z) * rec[d.x & 255] + __int_as_float(d.w) * rec[d.y & 255]);
         }
+        const int dp = cross_l[p];
+        if (dp >= 0) v -= pd[(size_t)dp * kDenseVals + tri21(r, c)];
         A[(6 * i + r) * ld + 6 * j + c] = v;
         A[(6 * j + c) * ld + 6 * i + r] = v;
-    }
-    __syncthreads();
-    if (D.use_dense) {
-        // dense cross blocks: several dense pairs may map onto one canonical block only through
-        // an explicit list; handle by serialising over dense pairs per block entry owner.
-        for (int e = tid; e < D.n_dense_pairs * 36; e += nthr) {
-            const int p = e / 36, r = (e % 36) / 6, c = e % 6;
-            const int2 ij = make_int2(dense_pairs_lds[2 * p], dense_pairs_lds[2 * p + 1]);
-            if (ij.x == 0 || ij.y == 0 || ij.x >= ij.y) continue;      // i>j: erased by FlipJtJ
-            // duplicates of the same (i,j) in an explicit list are not supported (documented)
-            const float s = pd[(size_t)p * kDenseVals + tri21(r, c)];
-            A[(6 * ij.x + r) * ld + 6 * ij.y + c] -= s;
-            A[(6 * ij.y + c) * ld + 6 * ij.x + r] -= s;
-        }
     }
     // Phase B2: diagonal blocks: TWO lanes per (frame k >= 1, entry), each sums half of the frame's pairs in fixed order
     for (int t = tid; t < 2 * (N - 1) * 36; t += nthr) {

@@ -318,21 +318,28 @@ class BatchSolver:
         self._last_layout = (L, N, npd if self.params.weight_dense_depth > 0 else 0)
         return tr
 
-    def block_ranges(self, zn):
-        """The caches' per-8x8-block depth ranges (btba_zn_block_ranges): part of the frame cache, built once per set of frames and
-        passed to solve_zn(block_ranges=...).  zn CUDA float32 [..., Hd, Wd, 4] with Hd, Wd multiples of 8; returns CUDA float32
-        [frames, (Hd/8)*(Wd/8), 2]."""
+    def cache_aux(self, zn, valid_lists=False):
+        """What the solve derives from the compact caches alone (btba_zn_aux): the per-8x8-block depth ranges (Hd, Wd multiples of 8)
+        and, on request, every frame's ordered list of valid pixels (for BTBA_FLAG_COMPACTION).  Part of the frame cache: built once
+        per set of frames and passed to solve_zn(aux=...).  zn CUDA float32 [..., Hd, Wd, 4]; returns a dict of CUDA tensors."""
         torch = _torch()
         Hd, Wd = int(zn.shape[-3]), int(zn.shape[-2])
         n = int(np.prod(zn.shape[:-3]))
-        out = torch.empty((n, (Hd // 8) * (Wd // 8), 2), dtype=torch.float32, device=zn.device)
-        check(lib().btba_zn_block_ranges(self.ws.handle, n, Hd, Wd, _dev_ptr(zn, "zn"), _dev_ptr(out, "out")), "btba_zn_block_ranges")
-        return out
+        aux = {}
+        if Hd % 8 == 0 and Wd % 8 == 0:
+            aux["block_ranges"] = torch.empty((n, (Hd // 8) * (Wd // 8), 2), dtype=torch.float32, device=zn.device)
+            check(lib().btba_zn_block_ranges(self.ws.handle, n, Hd, Wd, _dev_ptr(zn, "zn"), _dev_ptr(aux["block_ranges"], "block_ranges")), "btba_zn_block_ranges")
+        if valid_lists:
+            aux["valid_lists"] = torch.empty((n, Hd * Wd), dtype=torch.int32, device=zn.device)
+            aux["valid_counts"] = torch.empty((n,), dtype=torch.int32, device=zn.device)
+            check(lib().btba_zn_valid_lists(self.ws.handle, n, Hd, Wd, _dev_ptr(zn, "zn"), _dev_ptr(aux["valid_lists"], "valid_lists"), _dev_ptr(aux["valid_counts"], "valid_counts")),
+                  "btba_zn_valid_lists")
+        return aux
 
-    def solve_zn(self, zn, H, W, K, corr_dev, pair_offsets_dev, max_corr_per_pair, poses_dev, dense_pairs=None, trace=False, block_ranges=None):
+    def solve_zn(self, zn, H, W, K, corr_dev, pair_offsets_dev, max_corr_per_pair, poses_dev, dense_pairs=None, trace=False, aux=None):
         """Same as solve() on compact caches: zn CUDA float32 [B,N,Hd,Wd,4] = (z, nx, ny, nz); H, W, K = the FULL-resolution
-        frame geometry the caches were built from (Hd = H / image_downscale).  block_ranges: the result of block_ranges(zn) for
-        callers that keep their caches across solves (None: computed inside every solve)."""
+        frame geometry the caches were built from (Hd = H / image_downscale).  aux: the result of cache_aux(zn) for callers that
+        keep their caches across solves (None: derived inside every solve)."""
         torch = _torch()
         B, N = zn.shape[:2]
         Kf = np.ascontiguousarray(K, np.float32).reshape(9)
@@ -350,13 +357,16 @@ class BatchSolver:
             tr = torch.zeros((B, self.params.n_gn_iters, L.record_floats), dtype=torch.float32, device=zn.device)
         else:
             self.params.flags &= ~_lib.FLAG_TRACE
-        rc = lib().btba_solve_batch_zn_ranges(
-            self.ws.handle, C.byref(self.params), B, N, int(H), int(W), Kf.ctypes.data, _dev_ptr(zn, "zn"), _dev_ptr(block_ranges, "block_ranges"),
+        za = None
+        if aux:
+            za = _lib.ZnAux(_dev_ptr(aux.get("block_ranges"), "block_ranges"), _dev_ptr(aux.get("valid_lists"), "valid_lists"), _dev_ptr(aux.get("valid_counts"), "valid_counts"))
+        rc = lib().btba_solve_batch_zn_aux(
+            self.ws.handle, C.byref(self.params), B, N, int(H), int(W), Kf.ctypes.data, _dev_ptr(zn, "zn"), C.byref(za) if za is not None else None,
             _dev_ptr(corr_dev, "corr_dev"), stride,
             _dev_ptr(pair_offsets_dev, "pair_offsets_dev"), int(max_corr_per_pair),
             dp.ctypes.data if dp is not None else None, dp.shape[0] if dp is not None else 0,
             _dev_ptr(poses_dev, "poses_dev"), _dev_ptr(tr, "tr"))
-        check(rc, "btba_solve_batch_zn_ranges")
+        check(rc, "btba_solve_batch_zn_aux")
         self._last_layout = (L, N, npd if self.params.weight_dense_depth > 0 else 0)
         return tr
 

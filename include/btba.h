@@ -319,19 +319,29 @@ BTBA_API int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, 
                                  const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair,
                                  const int32_t *dense_pairs, int n_dense_pairs, float *poses_dev, float *trace_dev);
 
-/* Depth range [min, max] of the valid pixels of every 8 x 8 block of compact caches (Hd, Wd multiples of 8): ranges_dev float2
- * [n_frames_total][(Hd / 8) * (Wd / 8)], (+inf, -inf) for a block without a valid depth.  PART OF THE FRAME CACHE: it depends on the
- * frames only (not on poses or parameters), so a caller that keeps its caches across solves builds it once per frame and hands it to
- * btba_solve_batch_zn_ranges; the pinhole dense sweep uses it to drop 8 x 8 blocks that provably project outside the target image
- * before touching their pixels (exact: DESIGN.md 4.2).  btba_solve_batch_zn computes it per solve (one pass over the frames);
- * btba_optimize_frames / _keyed keep it with their frame cache.  Asynchronous on the workspace stream. */
+/* Data derived from compact caches ALONE (not from poses or parameters): a caller that keeps its caches across solves builds them
+ * once per set of frames and hands them to btba_solve_batch_zn_aux; btba_solve_batch_zn derives what it needs inside every solve
+ * (one pass over all frames each: 2 % of a c3 x 32 solve for the block ranges, 6 % of a masked one for the lists);
+ * btba_optimize_frames / _keyed keep both with their frame cache.  All pointers are device pointers and optional (NULL).
+ *   block_ranges : float2 [n_frames_total][(Hd / 8) * (Wd / 8)] -- depth range [min, max] of the valid pixels of every 8 x 8 block,
+ *                  (+inf, -inf) for a block without a valid depth (Hd, Wd multiples of 8).  The pinhole dense sweep uses it to
+ *                  drop blocks that provably project outside the target image before touching their pixels (exact: DESIGN.md 4.2).
+ *   valid_lists  : uint32 [n_frames_total][Hd * Wd] -- per frame, the ascending list of the pixels that carry a depth,
+ *   valid_counts : int32 [n_frames_total] -- and its length; walked instead of all pixels under BTBA_FLAG_COMPACTION. */
+typedef struct btba_zn_aux {
+    const float *block_ranges;
+    const uint32_t *valid_lists;
+    const int32_t *valid_counts;
+} btba_zn_aux;
+/* Builders (asynchronous on the workspace stream). */
 BTBA_API int btba_zn_block_ranges(btba_workspace *ws, int n_frames_total, int Hd, int Wd, const float *zn_dev, float *ranges_dev);
-/* btba_solve_batch_zn with the caches' block ranges supplied (block_ranges_dev NULL: as btba_solve_batch_zn). */
-BTBA_API int btba_solve_batch_zn_ranges(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames,
-                                        int H, int W, const float *K_rowmajor, const float *zn_dev, const float *block_ranges_dev,
-                                        const btba_entryj *corr_dev, int64_t corr_stride,
-                                        const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair,
-                                        const int32_t *dense_pairs, int n_dense_pairs, float *poses_dev, float *trace_dev);
+BTBA_API int btba_zn_valid_lists(btba_workspace *ws, int n_frames_total, int Hd, int Wd, const float *zn_dev, uint32_t *lists_dev, int32_t *counts_dev);
+/* btba_solve_batch_zn with the caches' derived data supplied (aux NULL, or any member NULL: as btba_solve_batch_zn). */
+BTBA_API int btba_solve_batch_zn_aux(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames,
+                                     int H, int W, const float *K_rowmajor, const float *zn_dev, const btba_zn_aux *aux,
+                                     const btba_entryj *corr_dev, int64_t corr_stride,
+                                     const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair,
+                                     const int32_t *dense_pairs, int n_dense_pairs, float *poses_dev, float *trace_dev);
 
 /* ---- correspondence RANSAC (the step before correspondences enter BA) ------------
  * Replaces ransacMultiPairGPU (src/cuda/cuda_ransac.cu:1228-1323) as called by SiftManager::runRansacMultiPairGPU

@@ -126,14 +126,26 @@ def test_dead_block_skip_is_exact(gpu, monkeypatch):
     corr_d = gpu.torch.from_numpy(corr.view(np.uint8).reshape(len(pbs), -1, 32)).to(gpu.dev)
     offs_d = gpu.torch.from_numpy(offs.astype(np.int32)).to(gpu.dev)
     poses_d = gpu.torch.from_numpy(np.stack([pb.poses_init for pb in pbs])).to(gpu.dev)
-    rng_d = bs.block_ranges(zn_d)
-    bs.solve_zn(zn_d, pbs[0].H, pbs[0].W, pbs[0].K, corr_d, offs_d, mx, poses_d, block_ranges=rng_d)
+    aux = bs.cache_aux(zn_d, valid_lists=True)
+    bs.solve_zn(zn_d, pbs[0].H, pbs[0].W, pbs[0].K, corr_d, offs_d, mx, poses_d, aux=aux)
     assert np.array_equal(poses_d.cpu().numpy(), out_a)
-    rng = rng_d.cpu().numpy().reshape(len(pbs), 15, -1, 2)
+    rng = aux["block_ranges"].cpu().numpy().reshape(len(pbs), 15, -1, 2)
     z = np.stack([S.compact_cache(pb) for pb in pbs])[..., 0]
     zb = z.reshape(len(pbs), 15, z.shape[2] // 8, 8, z.shape[3] // 8, 8).transpose(0, 1, 2, 4, 3, 5).reshape(len(pbs), 15, -1, 64)
     lo = np.where(zb > 0, zb, np.inf).min(-1); hi = np.where(zb > 0, zb, -np.inf).max(-1)
     assert np.array_equal(rng[..., 0], lo) and np.array_equal(rng[..., 1], hi)
+    # ... and the valid-pixel lists: supplied lists == lists built inside the solve, and they are the ascending valid pixels
+    from bundletrack_amd import _lib
+    bl = gpu.BatchSolver(gpu.ws, flags=_lib.FLAG_COMPACTION)
+    pa, pb_ = gpu.torch.from_numpy(np.stack([pb.poses_init for pb in pbs])).to(gpu.dev), gpu.torch.from_numpy(np.stack([pb.poses_init for pb in pbs])).to(gpu.dev)
+    bl.solve_zn(zn_d, pbs[0].H, pbs[0].W, pbs[0].K, corr_d, offs_d, mx, pa)
+    bl.solve_zn(zn_d, pbs[0].H, pbs[0].W, pbs[0].K, corr_d, offs_d, mx, pb_, aux=aux)
+    assert np.array_equal(pa.cpu().numpy(), pb_.cpu().numpy())
+    cnt = aux["valid_counts"].cpu().numpy(); lst = aux["valid_lists"].cpu().numpy()
+    zf = z.reshape(len(pbs) * 15, -1)
+    assert np.array_equal(cnt, (zf >= 0.1).sum(1))
+    for f in (0, 17, len(cnt) - 1):
+        assert np.array_equal(lst[f, :cnt[f]], np.nonzero(zf[f] >= 0.1)[0])
 
 
 def test_c5_shape_batch_properties(gpu):
