@@ -312,7 +312,7 @@ static int pick_chunks(const btba_params *prm, int B, int P, uint32_t max_corr_p
     if (want > 16) want = 16;
     return want;
 }
-static int pick_tiles(const btba_params *prm, int B, int Pd, int npix, bool lists)
+static int pick_tiles(const btba_params *prm, int B, int Pd, int npix, bool lists, int Wd, int Hd)
 {
     if (prm->dense_tiles > 0) return prm->dense_tiles;
     if (Pd == 0) return 1;
@@ -330,6 +330,14 @@ static int pick_tiles(const btba_params *prm, int B, int Pd, int npix, bool list
     if (want > cap) want = cap;
     if (want < 2) want = 2;
     if (want > 10) want = 10;          // more tiles = more partials for k_system_solve to reduce (latency mode)
+    // masked frames, small batches: a single instance measured 0.218 / 0.225 / 0.235 / 0.255 ms per solve for 5 / 8 / 10 / 15 tiles
+    if (lists && want > 5) want = 5;
+    // the block walk splits the image by rows of 8 x 8 blocks: tiles beyond ceil(rows / rows-per-tile) would be empty workgroups and
+    // empty partials (160 x 120: 15 block rows, 10 tiles -> 2 rows per tile -> 8 tiles; a single instance: 0.301 -> 0.269 ms per solve)
+    if (!lists && Wd % 8 == 0 && Hd % 8 == 0) {
+        const int bh = Hd / 8, rows_per = (bh + want - 1) / want;
+        want = (bh + rows_per - 1) / rows_per;
+    }
     return want;
 }
 
@@ -369,7 +377,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     }
     const int npix = Hd * Wd;
     const int chunks = use_sparse ? pick_chunks(prm, B, P, max_corr_per_pair) : 1;
-    const int tiles = use_dense ? pick_tiles(prm, B, Pd, npix, use_zn && (prm->flags & BTBA_FLAG_COMPACTION)) : 1;
+    const int tiles = use_dense ? pick_tiles(prm, B, Pd, npix, use_zn && (prm->flags & BTBA_FLAG_COMPACTION), Wd, Hd) : 1;
     const bool timing = (prm->flags & BTBA_FLAG_TIME_KERNELS) != 0;
     const int timed_iteration = (prm->flags & BTBA_FLAG_TIME_SAMPLED) ? (int)(ws->solves_enqueued++ % (uint64_t)std::max(1, prm->n_gn_iters)) : -1;      // -1: all
 
@@ -470,7 +478,11 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     const size_t lds_bytes = lds_core + (D.pairsum_in_lds ? lds_pairs : 0);
     if (lds_bytes > lds_limit) return BTBA_EINVAL;
     if (!D.pairsum_in_lds) { if ((rc = ws->pairsum.ensure((size_t)B * lds_pairs + 16))) return rc; }
-    if (a_global) { if ((rc = ws->big_A.ensure((size_t)B * n * ld * sizeof(float)))) return rc; }
+    if (a_global) { if ((rc = ws->big_A.ensure((size_t)B * (n + 2) * ld * sizeof(float)))) return rc; }      // per instance: A[n][ld], rhs[ld], prec[ld]
+    // large windows: reduce the partials and assemble the system on many workgroups (k_big_reduce, k_big_assemble); the traced solve
+    // keeps the single-workgroup path, whose trace records the system
+    D.pre_assembled = (a_global && !trace && !std::getenv("BTBA_NO_BIG_ASSEMBLY")) ? 1 : 0;
+    if (D.pre_assembled && D.pairsum_in_lds) { D.pairsum_in_lds = 0; if ((rc = ws->pairsum.ensure((size_t)B * lds_pairs + 16))) return rc; }
     if (lds_bytes > 64 * 1024 || !ws->lds_attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
@@ -628,8 +640,14 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             }
 #endif
             if ((rc = time_begin(ws, timing_it, 2, &slot, H.st))) return rc;
-            float *A_h = a_global ? ws->big_A.as<float>() + b0 * n * ld : nullptr;
+            float *A_h = a_global ? ws->big_A.as<float>() + b0 * (n + 2) * ld : nullptr;
             float *out_h = (it == prm->n_gn_iters - 1) ? poses + 16 * b0 * N : nullptr;     // the last iterate's matrices go straight to the caller's buffer
+            if (D.pre_assembled) {
+                const size_t n_sums = (size_t)P * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals;
+                k_big_reduce<<<dim3((unsigned)((n_sums + 255) / 256), (unsigned)H.nb), 256, 0, H.st>>>(D, sp_h, dp_h, ps_h);
+                const BigTasks bt = big_tasks(N, P, (int)ld);
+                k_big_assemble<<<dim3((bt.total + 255u) / 256u, (unsigned)H.nb), 256, 0, H.st>>>(D, ps_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, ws->solve_tab.as<int>(), A_h);
+            }
 #define BTBA_SOLVE(LP, AG) k_system_solve<LP, AG><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h, A_h, out_h, ws->solve_tab.as<int>())
             if (a_global) { if (D.pairsum_in_lds) BTBA_SOLVE(true, true); else BTBA_SOLVE(false, true); }
             else { if (D.pairsum_in_lds) BTBA_SOLVE(true, false); else BTBA_SOLVE(false, false); }

@@ -70,6 +70,7 @@ struct SolveDims {
     int64_t tr_x, tr_T, tr_rhs, tr_prec, tr_pcg, tr_delta, tr_dpair, tr_A, tr_clk;
     int n_gn;
     int pairsum_in_lds;  // 1: stage reduced pair sums in LDS, 0: in global scratch
+    int pre_assembled;   // large windows: k_big_reduce + k_big_assemble have built the system, k_system_solve only solves and updates
     int walk_blocks;     // pinhole sweep on the compact cache: waves walk 8 x 8 pixel blocks (width and height multiples of 8)
 #ifdef BTBA_WG_TRACE
     unsigned long long *wg_trace; // developer build (scripts/wg_trace.py): per workgroup of the fused sweep (start, end) in 100 MHz ticks, hardware id, kind
@@ -1278,6 +1279,171 @@ __device__ __forceinline__ float strided_sum(const float *__restrict__ q, int co
     return s;
 }
 
+// ---- large windows (matrix in a global scratch): reduction and assembly on MANY workgroups -------------------------------
+// Above BTBA_MAX_FRAMES_LDS frames k_system_solve used to do everything on one workgroup; at N = 85 (3 570 pairs, a 510 x 510
+// system) 118 k of its 989 k cycles went into reducing the sweep partials and 562 k into the assembly -- chains of dependent
+// global-memory reads walked by one CU (scripts/sys_clocks_big.py).  Both are embarrassingly parallel over pairs / matrix entries:
+//   k_big_reduce    one thread per reduced value: pair sums = sum over chunks / tiles of the sweep partials, in partial order
+//   k_big_assemble  one thread per off-diagonal entry, EIGHT lanes per diagonal entry / per unknown of the right-hand side (each sums an
+//                   eighth of the frame's pairs in fixed order, fixed shuffle tree), plus the zero-fill of what nobody writes
+// k_system_solve then starts at the PCG (D.pre_assembled).  Same formulas as phases A and B of k_system_solve; the sums over a
+// frame's pairs are grouped in eighths instead of halves / quarters.  System layout per instance: A[n][ld], rhs[ld], prec[ld].
+__global__ void __launch_bounds__(256) k_big_reduce(SolveDims D, const float *__restrict__ sparse_partials, const float *__restrict__ dense_partials,
+                                                    float *__restrict__ pairsum_global)
+{
+    const int b = blockIdx.y;
+    const size_t ns = (size_t)D.n_pairs * kSparseVals, nd = (size_t)D.n_dense_pairs * kDenseVals;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= ns + nd) return;
+    float *out = pairsum_global + (size_t)b * (ns + nd);
+    float s = 0.0f;
+    if (e < ns) {
+        if (D.use_sparse) {
+            const size_t p = e / kSparseVals, v = e - p * kSparseVals;
+            const float *q = sparse_partials + (((size_t)b * D.n_pairs + p) * D.sparse_chunks) * kSparseVals + v;
+            for (int c = 0; c < D.sparse_chunks; c++) s += q[(size_t)c * kSparseVals];
+        }
+    } else if (D.use_dense) {
+        const size_t ed = e - ns, p = ed / kDenseVals, v = ed - p * kDenseVals;
+        const float *q = dense_partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles) * kDenseVals + v;
+        for (int c = 0; c < D.dense_tiles; c++) s += q[(size_t)c * kDenseVals];
+    }
+    out[e] = s;
+}
+
+// task segments of k_big_assemble, each padded to a multiple of 64 threads
+struct BigTasks { unsigned off_diag, diag, rhs, zero, total; };
+__host__ __device__ inline BigTasks big_tasks(int N, int P, int ld)
+{
+    const unsigned n = 6u * (unsigned)N;
+    auto pad = [](unsigned x) { return (x + 63u) & ~63u; };
+    BigTasks t;
+    t.off_diag = pad((unsigned)P * 36u);
+    t.diag = pad((unsigned)(N - 1) * 36u * 8u);
+    t.rhs = pad(n * 8u);
+    t.zero = pad(6u * (unsigned)ld + (n - 6u) * (6u + (unsigned)ld - n));
+    t.total = t.off_diag + t.diag + t.rhs + t.zero;
+    return t;
+}
+
+__global__ void __launch_bounds__(256) k_big_assemble(SolveDims D, const float *__restrict__ pairsum_global, const int2 *__restrict__ dense_pairs,
+                                                      const int *__restrict__ adj_off, const int *__restrict__ adj, const int *__restrict__ solve_tab,
+                                                      float *__restrict__ A_scratch)
+{
+    const int b = blockIdx.y;
+    const int N = D.n_frames, n = 6 * N, ld = 4 * (((n + 3) / 4) | 1);
+    const BigTasks K = big_tasks(N, D.n_pairs, ld);
+    unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= K.total) return;
+    float *A = A_scratch + (size_t)b * (size_t)(n + 2) * ld, *rhs_out = A + (size_t)n * ld, *prec_out = rhs_out + ld;
+    const float *ps = pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals);
+    const float *pd = ps + (size_t)D.n_pairs * kSparseVals;
+    const int *pair_ij = solve_tab, *entry_lut = solve_tab + D.n_pairs;
+    const int n_adj = D.use_dense ? 2 * D.n_dense_pairs : 0;
+    const int *cross_tab = adj + n_adj;
+    if (t < K.off_diag) {                                  // ---- off-diagonal entries, one canonical pair (i < j) each
+        if (t >= (unsigned)D.n_pairs * 36u) return;
+        const int p = (int)(t / 36u), rc = (int)(t - 36u * (unsigned)p), r = rc / 6, c = rc - 6 * r;
+        const int pij = pair_ij[p], i = pij >> 8, j = pij & 255;
+        if (i == 0) return;
+        float v = 0.0f;
+        if (D.use_sparse) {
+            const int *dl = entry_lut + 4 * (36 + rc);
+            const float *rec = ps + (size_t)p * kSparseVals;
+            v = -D.w_sparse * (__int_as_float(dl[2]) * rec[dl[0] & 255] + __int_as_float(dl[3]) * rec[dl[1] & 255]);
+        }
+        const int dp = D.use_dense ? cross_tab[p] : -1;
+        if (dp >= 0) v -= pd[(size_t)dp * kDenseVals + tri21(r, c)];
+        A[(size_t)(6 * i + r) * ld + 6 * j + c] = v;
+        A[(size_t)(6 * j + c) * ld + 6 * i + r] = v;
+        return;
+    }
+    t -= K.off_diag;
+    if (t < K.diag) {                                      // ---- diagonal blocks: 8 lanes per (frame k >= 1, entry)
+        const unsigned e = t >> 3, sub = t & 7u;
+        const bool live = e < (unsigned)(N - 1) * 36u;
+        float v = 0.0f;
+        int k = 1, rc = 0;
+        if (live) {
+            k = 1 + (int)(e / 36u); rc = (int)(e % 36u);
+            const int r = rc / 6, c = rc - 6 * r;
+            if (D.use_sparse) {
+                const int *dl = entry_lut + 4 * rc;
+                const int d0 = dl[0], d1 = dl[1], es = d0 >> 8;
+                const float c1 = __int_as_float(dl[2]), c2 = __int_as_float(dl[3]);
+                float acc = 0.0f;
+                for (int m = (N * (int)sub) / 8; m < (N * ((int)sub + 1)) / 8; m++) {
+                    if (m == k) continue;
+                    const int i = m < k ? m : k, j = m < k ? k : m;
+                    const float *rec = ps + (size_t)pair_index(i, j, N) * kSparseVals + (k == i ? 0 : es);
+                    acc += c1 * rec[d0 & 255] + c2 * rec[d1 & 255];
+                }
+                v = D.w_sparse * acc;
+            }
+            if (D.use_dense) {
+                const int t21 = tri21(r, c);
+                const int q0 = adj_off[k], nq = adj_off[k + 1] - q0;
+                float acc = 0.0f;
+                for (int q = q0 + (nq * (int)sub) / 8; q < q0 + (nq * ((int)sub + 1)) / 8; q++) acc += pd[(size_t)(adj[q] >> 1) * kDenseVals + t21];
+                v += acc;
+            }
+        }
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        if (live && sub == 0) A[(size_t)(6 * k + rc / 6) * ld + 6 * k + rc % 6] = v;
+        return;
+    }
+    t -= K.diag;
+    if (t < K.rhs) {                                       // ---- right-hand side and Jacobi diagonal: 8 lanes per unknown
+        const unsigned e = t >> 3, sub = t & 7u;
+        const bool live = e < (unsigned)n;
+        const int k = live ? (int)e / 6 : 0, r = live ? (int)e % 6 : 0;
+        float rhs = 0.0f, md = 0.0f;
+        if (live && k > 0) {
+            if (D.use_sparse) {
+                const int o_i = (r < 3) ? 28 + r : 31 + r - 3, o_j = (r < 3) ? 28 + r : 34 + r - 3;
+                const int p_i = (r < 3) ? 37 : 38 + r - 3, p_j = (r < 3) ? 37 : 41 + r - 3;
+                for (int m = (N * (int)sub) / 8; m < (N * ((int)sub + 1)) / 8; m++) {
+                    if (m == k) continue;
+                    const int i = m < k ? m : k, j = m < k ? k : m;
+                    const float *rec = ps + (size_t)pair_index(i, j, N) * kSparseVals;
+                    const bool is_i = (k == i);
+                    const float g = rec[is_i ? o_i : o_j];
+                    rhs += is_i ? -g : g;
+                    md += rec[is_i ? p_i : p_j];
+                }
+                rhs *= D.w_sparse;
+            }
+            if (D.use_dense) {
+                const int q0 = adj_off[k], nq = adj_off[k + 1] - q0;
+                float jtr = 0.0f;
+                for (int q = q0 + (nq * (int)sub) / 8; q < q0 + (nq * ((int)sub + 1)) / 8; q++) {
+                    const int a = adj[q];
+                    const float g = pd[(size_t)(a >> 1) * kDenseVals + 21 + r];
+                    jtr += (a & 1) ? g : -g;
+                }
+                rhs -= jtr;
+            }
+        }
+        rhs += __shfl_xor(rhs, 1, 64); md += __shfl_xor(md, 1, 64);
+        rhs += __shfl_xor(rhs, 2, 64); md += __shfl_xor(md, 2, 64);
+        rhs += __shfl_xor(rhs, 4, 64); md += __shfl_xor(md, 4, 64);
+        if (live && sub == 0) {
+            rhs_out[e] = rhs;
+            prec_out[e] = (k > 0) ? ((md > kEps) ? 1.0f / md : 1.0f) : 0.0f;
+        }
+        return;
+    }
+    t -= K.rhs;
+    {                                                      // ---- what nobody writes: frame 0's rows and columns, the pad columns
+        const unsigned z0 = 6u * (unsigned)ld, w = 6u + (unsigned)ld - (unsigned)n;
+        if (t < z0) A[t] = 0.0f;
+        else if (t - z0 < (unsigned)(n - 6) * w) {
+            const unsigned q = t - z0, row = 6u + q / w, col = q % w;
+            A[(size_t)row * ld + (col < 6u ? col : (unsigned)n + col - 6u)] = 0.0f;
+        }
+    }
+}
+
 // grid (B); dynamic LDS: A[n*ld] + 7 vectors[n] + scratch + (optionally) reduced pair sums.
 // cross_ok[p] (dense) = 1 when the dense cross block survives FlipJtJ (target < source).
 template <bool LDS_PAIRS, bool A_GLOBAL = false>
@@ -1293,7 +1459,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     const int N = D.n_frames, n = 6 * N, ld = 4 * (((n + 3) / 4) | 1);   // odd multiple of 4: 16-B rows, conflict-free ds_read_b128
     // windows of more than BTBA_MAX_FRAMES_LDS frames: the matrix does not fit the CU's LDS and lives in an L2-resident
     // global scratch (A_GLOBAL); everything else keeps its place
-    float *A = A_GLOBAL ? A_scratch + (size_t)blockIdx.x * n * ld : lds;
+    float *A = A_GLOBAL ? A_scratch + (size_t)blockIdx.x * (size_t)(n + 2) * ld : lds;      // global layout per instance: A[n][ld], rhs[ld], prec[ld]
     float *vb = A_GLOBAL ? lds : A + (size_t)n * ld;       // rhs / residual r   (A's pad columns n..ld-1 stay 0)
     float *vM = vb + ld, *vz = vM + ld, *vp = vz + ld, *vAp = vp + ld, *vd = vAp + ld;     // vector stride ld (16-B aligned, zero padded)
     float *scratch = vd + ld;             // 16 floats
@@ -1316,6 +1482,15 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
 
     const long long clk0 = tr ? (long long)clock64() : 0;
 #define BTBA_STAMP(slot) do { if (tr && tid == 0) tr[D.tr_clk + (slot)] = (float)((long long)clock64() - clk0); } while (0)
+    if (A_GLOBAL && D.pre_assembled) {
+        // large windows: k_big_reduce + k_big_assemble have built A, the right-hand side and the Jacobi diagonal in the global scratch
+        const float *rhs_g = A + (size_t)n * ld, *prec_g = rhs_g + ld;
+        for (int e = tid; e < 16 * N; e += nthr) vT[e] = T[16 * (size_t)b * N + e];
+        for (int e = tid; e < 6 * N; e += nthr) x_l[e] = x[6 * (size_t)b * N + e];
+        for (int e = tid; e < n; e += nthr) { vb[e] = rhs_g[e]; vM[e] = prec_g[e]; vd[e] = 0.0f; }
+        for (int e = n + tid; e < ld; e += nthr) vp[e] = 0.0f;
+        __syncthreads();
+    } else {
     // Staging of this iterate's T and of the pair tables into LDS.  Every one of these global loads is a fabric-latency
     // miss (~2 k cycles; written by the previous launch / the host), and a load -> LDS-store loop per array serialises
     // them behind s_waitcnt (measured: 7.7 k cycles for four tiny arrays).  So: the first trip of all four arrays is
@@ -1498,6 +1673,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     }
     for (int e = n + tid; e < ld; e += nthr) vp[e] = 0.0f;      // pad of p: read by the 16-byte mat-vec chunks
     __syncthreads();
+    }
     BTBA_STAMP(2);
     if (tr) {
         for (int e = tid; e < n; e += nthr) {

@@ -557,9 +557,20 @@ def test_edge_shapes_through_the_boundary(gpu, oracle):
     # PCG to 16 waves; same arithmetic, same bar
     for N_big, seed in ((32, 93), (40, 94), (85, 95)):
         pbN = S.make_problem(N_big, 12, seed=seed, background=False, H=96, W=128, K=Ks, rot_step_deg=(5.0, 6.0))
-        worst, _, dB, nB = run(pbN)
+        worst, posesN, dB, nB = run(pbN)
         print(f"N={N_big}: worst pose diff {worst:.2e}")
         assert worst < 5e-4, (N_big, worst)
+        if N_big == 40:
+            # the same window with reduction and assembly on ONE workgroup (the path a traced solve takes) instead of k_big_reduce /
+            # k_big_assemble: the same sums in another grouping
+            os.environ["BTBA_NO_BIG_ASSEMBLY"] = "1"
+            try:
+                _, poses_one, _, _ = run(pbN)
+            finally:
+                del os.environ["BTBA_NO_BIG_ASSEMBLY"]
+            d_paths = max(max(S.pose_error(posesN[k], poses_one[k])) for k in range(N_big))
+            print(f"N=40: many-workgroup assembly vs one workgroup: worst pose diff {d_paths:.2e}")
+            assert 0 < d_paths < 5e-5 or np.array_equal(posesN, poses_one), d_paths
     with pytest.raises(_lib.BtbaError) as e:             # N = 86 is refused with a status, not `while(1);` (SolverBundling.cu:621-625)
         opt.optimizeFrames(pbN.corr[:0], None, 86, pbN.H, pbN.W, dB + dB[:1], None, nB + nB[:1], np.tile(np.eye(4, dtype=np.float32), (86, 1, 1)), pbN.K)
     assert e.value.status == _lib.BTBA_EINVAL
