@@ -478,10 +478,11 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     const size_t lds_bytes = lds_core + (D.pairsum_in_lds ? lds_pairs : 0);
     if (lds_bytes > lds_limit) return BTBA_EINVAL;
     if (!D.pairsum_in_lds) { if ((rc = ws->pairsum.ensure((size_t)B * lds_pairs + 16))) return rc; }
-    if (a_global) { if ((rc = ws->big_A.ensure((size_t)B * (n + 2) * ld * sizeof(float)))) return rc; }      // per instance: A[n][ld], rhs[ld], prec[ld]
-    // large windows: reduce the partials and assemble the system on many workgroups (k_big_reduce, k_big_assemble); the traced solve
-    // keeps the single-workgroup path, whose trace records the system
-    D.pre_assembled = (a_global && !trace && !std::getenv("BTBA_NO_BIG_ASSEMBLY")) ? 1 : 0;
+    // larger windows: reduce the partials and assemble the system on many workgroups (k_big_reduce, k_big_assemble); the traced solve
+    // keeps the single-workgroup path, whose trace records the system.  Worth two extra launches per iteration from ~24 frames on
+    // (one workgroup: 90 k of the 140 k cycles of a launch at N = 31 are reduction and assembly; at N = 15 19 k of 45 k, less than the launches)
+    D.pre_assembled = ((a_global || N >= 24) && !trace && !std::getenv("BTBA_NO_BIG_ASSEMBLY")) ? 1 : 0;
+    if (a_global || D.pre_assembled) { if ((rc = ws->big_A.ensure((size_t)B * (n + 2) * ld * sizeof(float)))) return rc; }      // per instance: A[n][ld], rhs[ld], prec[ld]
     if (D.pre_assembled && D.pairsum_in_lds) { D.pairsum_in_lds = 0; if ((rc = ws->pairsum.ensure((size_t)B * lds_pairs + 16))) return rc; }
     if (lds_bytes > 64 * 1024 || !ws->lds_attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_system_solve<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
@@ -640,7 +641,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             }
 #endif
             if ((rc = time_begin(ws, timing_it, 2, &slot, H.st))) return rc;
-            float *A_h = a_global ? ws->big_A.as<float>() + b0 * (n + 2) * ld : nullptr;
+            float *A_h = (a_global || D.pre_assembled) ? ws->big_A.as<float>() + b0 * (n + 2) * ld : nullptr;
             float *out_h = (it == prm->n_gn_iters - 1) ? poses + 16 * b0 * N : nullptr;     // the last iterate's matrices go straight to the caller's buffer
             if (D.pre_assembled) {
                 const size_t n_sums = (size_t)P * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals;

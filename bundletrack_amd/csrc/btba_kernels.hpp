@@ -1482,9 +1482,16 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
 
     const long long clk0 = tr ? (long long)clock64() : 0;
 #define BTBA_STAMP(slot) do { if (tr && tid == 0) tr[D.tr_clk + (slot)] = (float)((long long)clock64() - clk0); } while (0)
-    if (A_GLOBAL && D.pre_assembled) {
-        // large windows: k_big_reduce + k_big_assemble have built A, the right-hand side and the Jacobi diagonal in the global scratch
-        const float *rhs_g = A + (size_t)n * ld, *prec_g = rhs_g + ld;
+    if (D.pre_assembled) {
+        // larger windows: k_big_reduce + k_big_assemble have built A, the right-hand side and the Jacobi diagonal in the global scratch;
+        // a matrix that fits LDS is loaded back for the one-wave PCG (coalesced, once)
+        const float *Ag = A_scratch + (size_t)blockIdx.x * (size_t)(n + 2) * ld;
+        const float *rhs_g = Ag + (size_t)n * ld, *prec_g = rhs_g + ld;
+        if (!A_GLOBAL) {
+            const float4 *src = reinterpret_cast<const float4 *>(Ag);
+            float4 *dst = reinterpret_cast<float4 *>(A);
+            for (int e = tid; e < (n * ld) / 4; e += nthr) dst[e] = src[e];
+        }
         for (int e = tid; e < 16 * N; e += nthr) vT[e] = T[16 * (size_t)b * N + e];
         for (int e = tid; e < 6 * N; e += nthr) x_l[e] = x[6 * (size_t)b * N + e];
         for (int e = tid; e < n; e += nthr) { vb[e] = rhs_g[e]; vM[e] = prec_g[e]; vd[e] = 0.0f; }
