@@ -1758,26 +1758,32 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             const int nq = ld >> 2;                       // 16-byte chunks per row (pad columns hold zeros)
             // four independent partial sums per row (x, y, z, w lanes of the 16-byte chunks): the single wave has no other
             // work to hide FMA latency behind, so a 92-long dependent chain per row was the critical path of this phase
-            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0;
+            // ... as PACKED fp32 FMAs (v_pk_fma_f32, two lanes of a chunk per instruction): this wave is alone on its SIMD, so it is
+            // bound by the one-instruction-per-four-cycles issue rate, where a packed FMA costs what a plain one does
+            // (profiles/r02/valu_calibration.md) -- half the instructions for the same fused multiply-adds, bit for bit
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            auto lo = [](const float4 &v) { return (f2){ v.x, v.y }; };
+            auto hi = [](const float4 &v) { return (f2){ v.z, v.w }; };
+            f2 q0a = (f2){ 0.f, 0.f }, q0b = q0a, q1a = q0a, q1b = q0a, q2a = q0a, q2b = q0a, q3a = q0a, q3b = q0a;
             if (n <= 128) {
 _Pragma("unroll 8")
                 for (int c = 0; c < nq; c++) {
                     const float4 pc = p4[c], r0 = a0[c], r1 = a1[c];
-                    q0.x += r0.x * pc.x; q0.y += r0.y * pc.y; q0.z += r0.z * pc.z; q0.w += r0.w * pc.w;
-                    q1.x += r1.x * pc.x; q1.y += r1.y * pc.y; q1.z += r1.z * pc.z; q1.w += r1.w * pc.w;
+                    q0a = __builtin_elementwise_fma(lo(r0), lo(pc), q0a); q0b = __builtin_elementwise_fma(hi(r0), hi(pc), q0b);
+                    q1a = __builtin_elementwise_fma(lo(r1), lo(pc), q1a); q1b = __builtin_elementwise_fma(hi(r1), hi(pc), q1b);
                 }
             } else {
 _Pragma("unroll 4")
                 for (int c = 0; c < nq; c++) {
                     const float4 pc = p4[c], r0 = a0[c], r1 = a1[c], r2 = a2[c], r3 = a3[c];
-                    q0.x += r0.x * pc.x; q0.y += r0.y * pc.y; q0.z += r0.z * pc.z; q0.w += r0.w * pc.w;
-                    q1.x += r1.x * pc.x; q1.y += r1.y * pc.y; q1.z += r1.z * pc.z; q1.w += r1.w * pc.w;
-                    q2.x += r2.x * pc.x; q2.y += r2.y * pc.y; q2.z += r2.z * pc.z; q2.w += r2.w * pc.w;
-                    q3.x += r3.x * pc.x; q3.y += r3.y * pc.y; q3.z += r3.z * pc.z; q3.w += r3.w * pc.w;
+                    q0a = __builtin_elementwise_fma(lo(r0), lo(pc), q0a); q0b = __builtin_elementwise_fma(hi(r0), hi(pc), q0b);
+                    q1a = __builtin_elementwise_fma(lo(r1), lo(pc), q1a); q1b = __builtin_elementwise_fma(hi(r1), hi(pc), q1b);
+                    q2a = __builtin_elementwise_fma(lo(r2), lo(pc), q2a); q2b = __builtin_elementwise_fma(hi(r2), hi(pc), q2b);
+                    q3a = __builtin_elementwise_fma(lo(r3), lo(pc), q3a); q3b = __builtin_elementwise_fma(hi(r3), hi(pc), q3b);
                 }
             }
-            ap_[0] = (q0.x + q0.y) + (q0.z + q0.w); ap_[1] = (q1.x + q1.y) + (q1.z + q1.w);
-            ap_[2] = (q2.x + q2.y) + (q2.z + q2.w); ap_[3] = (q3.x + q3.y) + (q3.z + q3.w);
+            ap_[0] = (q0a.x + q0a.y) + (q0b.x + q0b.y); ap_[1] = (q1a.x + q1a.y) + (q1b.x + q1b.y);
+            ap_[2] = (q2a.x + q2a.y) + (q2b.x + q2b.y); ap_[3] = (q3a.x + q3a.y) + (q3b.x + q3b.y);
             part = 0.0f;
 #pragma unroll
             for (int j = 0; j < kMaxRows; j++) part += (lane + 64 * j < n) ? p_[j] * ap_[j] : 0.0f;
