@@ -21,6 +21,7 @@ BTBA_OK, BTBA_EINVAL, BTBA_EHIP, BTBA_ENUMERIC, BTBA_ENOMEM = 0, 1, 2, 3, 4
 PAIRS_TARGET_LOWER, PAIRS_TARGET_MORE_VALID, PAIRS_EXPLICIT, PAIRS_TARGET_HIGHER = 0, 1, 2, 3
 REDUCE_DETERMINISTIC, REDUCE_ATOMIC = 0, 1
 RANSAC_REFERENCE_SVD, RANSAC_HORN = 0, 1
+RANSAC_DRAW_HASH = 0x100      # ORed into `hypothesis`: counter-hash sample triples instead of the reference's cuRAND XORWOW stream
 FLAG_TRACE, FLAG_TIME_KERNELS = 1, 2
 FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_KEYED_CORR, FLAG_FLOAT4_CACHE, FLAG_NO_COMPACTION, FLAG_COMPACTION, FLAG_TIME_SAMPLED = 32, 64, 128, 256, 512, 1024, 2048
 
@@ -32,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "btba_params_default", "btba_strerror", "btba_last_hip_error", "btba_version",
     "btba_workspace_create", "btba_workspace_create_on_stream", "btba_workspace_destroy", "btba_workspace_sync",
     "btba_workspace_wait_stream", "btba_workspace_signal_stream",
-    "btba_optimize_frames", "btba_optimize_frames_keyed", "btba_frame_cache_clear", "btba_frame_cache_evict", "btba_ransac_pairs", "btba_ransac_pairs_ex", "btba_build_cache", "btba_solve_batch", "btba_solve_cached", "btba_collect_stats",
+    "btba_optimize_frames", "btba_optimize_frames_keyed", "btba_frame_cache_clear", "btba_frame_cache_evict", "btba_ransac_pairs", "btba_ransac_pairs_ex", "btba_ransac_reference_uniforms", "btba_build_cache", "btba_solve_batch", "btba_solve_cached", "btba_collect_stats",
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
     "btba_process_depth", "btba_depth_to_normals",

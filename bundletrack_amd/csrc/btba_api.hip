@@ -20,6 +20,7 @@
 #include "btba_kernels.hpp"
 #include "btba_image.hpp"
 #include "btba_ransac.hpp"
+#include "btba_xorwow.hpp"
 
 using namespace btba;
 
@@ -91,6 +92,9 @@ struct btba_workspace {
     size_t corr_pool_used = 0;                              // in EntryJ
     void *corr_stage = nullptr; size_t corr_stage_cap = 0;  // pinned host staging of the segments uploaded by one call
     DevBuf ransac;                                          // btba_ransac_pairs staging (points, samples, per-trial poses and counts, results)
+    DevBuf ransac_u;                                        // the reference's sample stream: n_trials x 3 uniforms (btba_xorwow.hpp), kept per (seed, n_trials)
+    std::vector<float> ransac_u_host;
+    uint64_t ransac_u_seed = 0;
     std::vector<FrameSlot> pool_slots;
     int pool_H = 0, pool_W = 0, pool_npix = 0;
     float pool_downscale = 0.0f, pool_K[9] = {0};
@@ -177,7 +181,7 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A, &ws->solve_tab,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts, &ws->block_ranges,
-                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->corr_pool, &ws->corr_desc };
+                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc };
     for (auto b : bufs) b->release();
     if (ws->corr_stage) (void)hipHostFree(ws->corr_stage);
     for (auto st : ws->aux_streams) if (st) (void)hipStreamDestroy(st);
@@ -1294,6 +1298,8 @@ int btba_ransac_pairs_ex(btba_workspace *ws, int hypothesis, int device_resident
                          int32_t *trial_counts_out, float *trial_poses_out)
 {
     if (!ws || n_pairs < 1 || !n_pts || n_trials < 1 || !(dist_thres >= 0.0f) || !inlier_ids_out || !n_inliers_out) return BTBA_EINVAL;
+    const bool draw_hash = (hypothesis & BTBA_RANSAC_DRAW_HASH) != 0;
+    hypothesis &= ~BTBA_RANSAC_DRAW_HASH;
     if (hypothesis != BTBA_RANSAC_REFERENCE_SVD && hypothesis != BTBA_RANSAC_HORN) return BTBA_EINVAL;
     std::vector<int32_t> offsets(n_pairs + 1, 0);
     for (int p = 0; p < n_pairs; p++) {
@@ -1327,8 +1333,21 @@ int btba_ransac_pairs_ex(btba_workspace *ws, int hypothesis, int device_resident
     HIP_TRY(hipStreamSynchronize(ws->stream));          // `offsets` is a local (16 B per pair: the only host wait of the device-resident form)
     if (samples && !dev) HIP_TRY(hipMemcpyAsync(base + o_smp, samples, 12 * NT, hipMemcpyHostToDevice, ws->stream));
     HIP_TRY(hipMemsetAsync(base + o_best, 0, 8 * (size_t)n_pairs, ws->stream));
+    if (!samples && !draw_hash) {
+        // the reference's per-trial cuRAND streams = one table of uniforms for all pairs; rebuilt only when the seed changes or
+        // more trials are asked for than the table holds (a longer table for the same seed starts with the shorter one)
+        if (ws->ransac_u_host.size() < 3 * (size_t)n_trials || ws->ransac_u_seed != seed) {
+            HIP_TRY(hipStreamSynchronize(ws->stream));      // an earlier call's kernels / upload may still be using the old table
+            ws->ransac_u_host.assign(3 * (size_t)n_trials, 0.0f);
+            xorwow::ransac_uniform_table(seed, n_trials, ws->ransac_u_host.data());
+            ws->ransac_u_seed = seed;
+            if ((rc = ws->ransac_u.ensure(12 * (size_t)n_trials))) return rc;
+            HIP_TRY(hipMemcpyAsync(ws->ransac_u.p, ws->ransac_u_host.data(), 12 * (size_t)n_trials, hipMemcpyHostToDevice, ws->stream));
+        }
+    }
     RansacDims D{};
-    D.n_pairs = n_pairs; D.n_trials = n_trials; D.dist_thres = dist_thres; D.seed = seed; D.has_samples = samples ? 1 : 0; D.hypothesis = hypothesis;
+    D.n_pairs = n_pairs; D.n_trials = n_trials; D.dist_thres = dist_thres; D.seed = seed; D.hypothesis = hypothesis;
+    D.draw = samples ? 1 : (draw_hash ? 0 : 2);
     const float4 *dA = dev ? reinterpret_cast<const float4 *>(ptsA) : reinterpret_cast<const float4 *>(base + o_a);
     const float4 *dB = dev ? reinterpret_cast<const float4 *>(ptsB) : reinterpret_cast<const float4 *>(base + o_b);
     const int *dS = (samples && dev) ? samples : reinterpret_cast<const int *>(base + o_smp);
@@ -1340,7 +1359,7 @@ int btba_ransac_pairs_ex(btba_workspace *ws, int hypothesis, int device_resident
     int *d_cnt = (dev && trial_counts_out) ? trial_counts_out : reinterpret_cast<int *>(base + o_cnt);
     float *d_pose = (dev && trial_poses_out) ? trial_poses_out : reinterpret_cast<float *>(base + o_pose);
     k_ransac_vote<<<dim3((n_trials + 255) / 256, n_pairs), 256, 0, ws->stream>>>(
-        D, dA, dB, reinterpret_cast<const int *>(base + o_off), dS, d_pose, d_cnt, reinterpret_cast<unsigned long long *>(base + o_best));
+        D, dA, dB, reinterpret_cast<const int *>(base + o_off), dS, ws->ransac_u.as<float>(), d_pose, d_cnt, reinterpret_cast<unsigned long long *>(base + o_best));
     k_ransac_extract<<<n_pairs, 256, 0, ws->stream>>>(
         D, dA, dB, reinterpret_cast<const int *>(base + o_off), d_pose, reinterpret_cast<const unsigned long long *>(base + o_best), d_ids, d_nin, d_bt, d_bp);
     HIP_TRY(hipGetLastError());
@@ -1363,6 +1382,13 @@ int btba_ransac_pairs(btba_workspace *ws, int n_pairs, const float *ptsA_host, c
 {
     return btba_ransac_pairs_ex(ws, BTBA_RANSAC_REFERENCE_SVD, 0, n_pairs, ptsA_host, ptsB_host, n_pts, n_trials, dist_thres, samples_host, seed,
                                 inlier_ids_out, n_inliers_out, best_trial_out, best_pose_out, trial_counts_out, trial_poses_out);
+}
+
+int btba_ransac_reference_uniforms(uint64_t seed, int n_trials, float *u_out)
+{
+    if (n_trials < 0 || (n_trials && !u_out)) return BTBA_EINVAL;
+    xorwow::ransac_uniform_table(seed, n_trials, u_out);
+    return BTBA_OK;
 }
 
 }  // extern "C"

@@ -14,7 +14,9 @@
 // case, no "R is not valid" failure; near-collinear samples rejected by the eigenvalue gap).  Points are staged through LDS in tiles
 // that every lane reads at the same index (broadcast reads; no flag matrix, no float atomics); the best trial is an
 // integer atomicMax on (count << 32 | ~trial): deterministic, lowest trial id among equals.  A second small
-// launch re-evaluates the winning pose and writes the ordered inlier list (ballot compaction).
+// launch re-evaluates the winning pose and writes the ordered inlier list (ballot compaction).  Sample triples: by default the
+// reference's own -- its per-trial cuRAND XORWOW streams are one constant table of n_trials x 3 uniforms (btba_xorwow.hpp), which
+// a lane turns into its pair's indices with a multiply and a round; or explicit; or a counter hash (distinct per pair).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,6 +38,13 @@ __host__ __device__ __forceinline__ int ransac_draw(uint64_t seed, int pair, int
     h = mix32(h ^ (0x85EBCA6Bu * (uint32_t)(trial + 1)));
     h = mix32(h + 0xC2B2AE35u * (uint32_t)(draw + 1));
     const float u = (float)((h >> 8) + 1u) * (1.0f / 16777216.0f);
+    return (int)roundf(u * (float)(n_pts - 1));
+}
+
+// round(curand_uniform(&state) * (n_pts - 1)), cuda_ransac.cu:1159-1161: int -> float, one fp32 multiply, round half away from zero
+__host__ __device__ __forceinline__ int ransac_index(float u, int n_pts)
+{
+#pragma clang fp contract(off)
     return (int)roundf(u * (float)(n_pts - 1));
 }
 
@@ -140,14 +149,15 @@ struct RansacDims {
     int n_pairs, n_trials;
     float dist_thres;
     uint64_t seed;
-    int has_samples;
+    int draw;            // where a trial's three indices come from: 0 counter hash of (seed, pair, trial, k); 1 explicit `samples`;
+                         // 2 the reference's cuRAND stream: round(u_table[trial][k] * (n - 1)) (btba_xorwow.hpp)
     int hypothesis;      // BTBA_RANSAC_REFERENCE_SVD (0): procrustesKernel with the reference's approximate 3x3 SVD, operation for operation; BTBA_RANSAC_HORN (1)
 };
 
 // grid (ceil(n_trials / 256), n_pairs) x 256.  offsets[pair] .. offsets[pair+1] delimit the pair's points.
 __global__ void __launch_bounds__(256) k_ransac_vote(RansacDims D, const float4 *__restrict__ ptsA, const float4 *__restrict__ ptsB, const int *__restrict__ offsets,
-                                                    const int *__restrict__ samples, float *__restrict__ poses, int *__restrict__ counts,
-                                                    unsigned long long *__restrict__ best)
+                                                    const int *__restrict__ samples, const float *__restrict__ u_table, float *__restrict__ poses,
+                                                    int *__restrict__ counts, unsigned long long *__restrict__ best)
 {
     const int pair = blockIdx.y, trial = blockIdx.x * 256 + (int)threadIdx.x;
     const int o = offsets[pair], n = offsets[pair + 1] - o;
@@ -159,7 +169,8 @@ __global__ void __launch_bounds__(256) k_ransac_vote(RansacDims D, const float4 
         int idx[3];
 #pragma unroll
         for (int k = 0; k < 3; k++)
-            idx[k] = D.has_samples ? samples[3 * ((size_t)pair * D.n_trials + trial) + k] : ransac_draw(D.seed, pair, trial, k, n);
+            idx[k] = D.draw == 1 ? samples[3 * ((size_t)pair * D.n_trials + trial) + k]
+                   : D.draw == 2 ? ransac_index(u_table[3 * trial + k], n) : ransac_draw(D.seed, pair, trial, k, n);
         const bool distinct = !(idx[0] == idx[1] || idx[1] == idx[2] || idx[0] == idx[2]);
         const bool in_range = idx[0] >= 0 && idx[1] >= 0 && idx[2] >= 0 && idx[0] < n && idx[1] < n && idx[2] < n;
         if (distinct && in_range) {

@@ -37,10 +37,28 @@ def pack_points(ptsA, ptsB):
     return a_all, b_all, n_pts
 
 
+def reference_uniforms(n_trials: int, seed: int = 0) -> np.ndarray:
+    """btba_ransac_reference_uniforms: the reference's sample stream as float32 [n_trials, 3] -- row t holds the three
+    curand_uniform() draws after curand_init(seed, t, 0) (cuda_ransac.cu:1154-1161).  Host-only, no GPU needed."""
+    u = np.zeros((max(int(n_trials), 0), 3), np.float32)
+    f = lib().btba_ransac_reference_uniforms
+    f.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
+    check(f(int(seed), int(n_trials), u.ctypes.data), "btba_ransac_reference_uniforms")
+    return u
+
+
+def reference_samples(n_trials: int, n_pts: int, seed: int = 0) -> np.ndarray:
+    """The triples the reference's trial t draws on a pair of n_pts points: round(u * (n_pts - 1)) in fp32, int32 [n_trials, 3]."""
+    prod = reference_uniforms(n_trials, seed) * np.float32(n_pts - 1)
+    return (np.sign(prod) * np.floor(np.abs(prod) + np.float32(0.5))).astype(np.int32)      # roundf: half away from zero
+
+
 def ransac_packed(ws, a_all, b_all, n_pts, n_trials: int = 2000, inlier_dist: float = 0.01, samples=None, seed: int = 0,
                   want_trials: bool = False, hypothesis: int = 0) -> list[dict]:
     """btba_ransac_pairs_ex on already packed points (see pack_points).  hypothesis: _lib.RANSAC_REFERENCE_SVD (0, default: the
-    reference's procrustesKernel with its approximate 3x3 SVD, operation for operation) or _lib.RANSAC_HORN (1: exact Kabsch)."""
+    reference's procrustesKernel with its approximate 3x3 SVD, operation for operation) or _lib.RANSAC_HORN (1: exact Kabsch),
+    optionally ORed with _lib.RANSAC_DRAW_HASH.  samples None: the reference's cuRAND XORWOW triples for curand_init(seed, trial, 0)
+    (the reference's seed is 0), or with RANSAC_DRAW_HASH a per-pair counter hash of the seed."""
     n_pairs, T = len(n_pts), int(np.sum(n_pts))
     smp = None
     if samples is not None:
@@ -101,9 +119,10 @@ def ransac_multi_pair(ws, ptsA, ptsB, n_trials: int = 2000, inlier_dist: float =
     return ransac_packed(ws, a_all, b_all, n_pts, n_trials, inlier_dist, samples, seed, want_trials, hypothesis)
 
 
-def run_ransac_multi_pair(ws, pairs, matches: dict, n_trials: int = 2000, inlier_dist: float = 0.01, seed: int = 0) -> None:
+def run_ransac_multi_pair(ws, pairs, matches: dict, n_trials: int = 2000, inlier_dist: float = 0.01, seed: int = 0, hypothesis: int = 0) -> None:
     """SiftManager::runRansacMultiPairGPU.  pairs: [(frameA, frameB)] (A newer); matches[(A.id, B.id)] = (ptA_cam,
-    ptB_cam) is replaced IN PLACE by its RANSAC inliers, or emptied when fewer than 5 survive (:733-737)."""
+    ptB_cam) is replaced IN PLACE by its RANSAC inliers, or emptied when fewer than 5 survive (:733-737).  Defaults = the
+    reference: procrustesKernel hypotheses on the cuRAND XORWOW triples of curand_init(0, trial, 0)."""
     keys, A, B = [], [], []
     for fa, fb in pairs:
         key = (fa.id, fb.id)
@@ -114,7 +133,7 @@ def run_ransac_multi_pair(ws, pairs, matches: dict, n_trials: int = 2000, inlier
         B.append(np.asarray(pb, np.float32) @ Tb[:3, :3].T + Tb[:3, 3])
     if not keys:
         return
-    res = ransac_multi_pair(ws, A, B, n_trials=n_trials, inlier_dist=inlier_dist, seed=seed)
+    res = ransac_multi_pair(ws, A, B, n_trials=n_trials, inlier_dist=inlier_dist, seed=seed, hypothesis=hypothesis)
     for key, r in zip(keys, res):
         pa, pb = matches.get(key, (np.zeros((0, 3), np.float32),) * 2)
         keep = r["inlier_ids"]

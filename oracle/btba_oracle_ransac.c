@@ -4,15 +4,20 @@
  * PARITY: procrustesKernel and evalPoseKernel of the reference are compiled for the CPU (oracle/Makefile target `ref`,
  * _ref/libbtba_ref_ransac.so) and compared with this file in tests/test_oracle_vs_reference.py.  Beyond that, unpinned:
  *   - the reference holds no golden vectors for this step either;
- *   - two ingredients live in third-party code that is absent from /root/reference and cannot be rebuilt here:
- *     cuRAND's XORWOW generator (curand_init(0, idx, 0) + curand_uniform, cuda_ransac.cu:1156-1163; CUDA toolkit,
- *     version unpinned by the reference) draws the sample triples, and the 3x3 SVD is McAdams et al., "Computing
- *     the SVD of 3x3 matrices with minimal branching and elementary floating point operations" (UW-Madison TR1690,
- *     2011), an APPROXIMATE Jacobi SVD (4 sweeps, rsqrt-based Givens angles) pasted into cuda_ransac.cu:48-975.
- *   What is restated is therefore the algorithm the reference implements around those two: sample triples are an
- *   INPUT (as they are for ransacMultiPairKernel's rand_list, cuda_ransac.cu:1105) or come from the documented
- *   counter hash below, and the rotation is the exact Kabsch optimum the approximate SVD converges to, computed
- *   with a double-precision one-sided Jacobi SVD.
+ *   - the sample triples come from cuRAND's XORWOW generator (curand_init(0, idx, 0) + curand_uniform,
+ *     cuda_ransac.cu:1154-1161) -- CUDA toolkit code, absent from /root/reference and from this image.  Its published
+ *     algorithm is restated in oracle/xorwow.h (see that header for what each part is anchored on: the recurrence and the
+ *     2^67 subsequence jump are checked against rocRAND's tables, the four seed-scrambling constants are unpinned) and
+ *     exported below (orc_ransac_reference_samples); sample triples can also be an INPUT (as they are for
+ *     ransacMultiPairKernel's rand_list, cuda_ransac.cu:1105) or come from the documented counter hash below;
+ *   - the 3x3 SVD is McAdams et al., "Computing the SVD of 3x3 matrices with minimal branching and elementary floating
+ *     point operations" (UW-Madison TR1690, 2011), an APPROXIMATE Jacobi SVD (4 sweeps, rsqrt-based Givens angles) pasted
+ *     into cuda_ransac.cu:48-975: restated operation for operation (mc_svd, orc_procrustes_reference: hypothesis 0) and
+ *     pinned bit for bit against the reference's own code; hypothesis 1 is the exact Kabsch optimum the approximate SVD
+ *     converges to, computed with a double-precision one-sided Jacobi SVD.
+ *   The reference's kernels and host launcher themselves (ransacEstimateModelKernel .. ransacMultiPairGPU) are compiled for
+ *   the CPU as well (oracle/Makefile, _ref/libbtba_ref_ransac.so: ref_ransac_multi_pair) with oracle/xorwow.h standing in
+ *   for <curand_kernel.h>, and compared end to end with orc_ransac_pair_ex on orc_ransac_reference_samples.
  *
  * Follows: procrustesKernel cuda_ransac.cu:999-1102, evalPoseKernel :978-997, ransacEstimateModelKernel :1145-1181,
  * ransacEvalModelKernel :1183-1200, findBestTrial :1202-1219, ransacMultiPairGPU :1228-1323,
@@ -23,7 +28,52 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "xorwow.h"
+
 #define ORC_API __attribute__((visibility("default")))
+
+/* ---- the reference's sample stream (cuda_ransac.cu:1154-1161): trial t draws three uniforms from its own XORWOW stream
+ * curand_init(seed = 0, subsequence = t, offset = 0) and turns each into round(u * (n_pts - 1)).  The stream does not
+ * depend on the frame pair, so the n_trials x 3 uniforms are one table for all pairs. */
+ORC_API void orc_curand_xorwow_state(uint64_t seed, uint64_t subsequence, uint64_t offset, uint32_t state_out[6] /* d, v[0..4] */)
+{
+    orc_xorwow_state s;
+    orc_curand_init(seed, subsequence, offset, &s);
+    state_out[0] = s.d;
+    memcpy(state_out + 1, s.v, sizeof s.v);
+}
+ORC_API void orc_curand_xorwow_draw(uint64_t seed, uint64_t subsequence, uint64_t offset, int n, uint32_t *raw_out /* may be NULL */, float *uniform_out /* may be NULL */)
+{
+    orc_xorwow_state s;
+    orc_curand_init(seed, subsequence, offset, &s);
+    for (int i = 0; i < n; i++) {
+        orc_xorwow_state c = s;
+        const uint32_t x = orc_xorwow_next(&s);
+        if (raw_out) raw_out[i] = x;
+        if (uniform_out) uniform_out[i] = orc_curand_uniform(&c);
+    }
+}
+ORC_API void orc_ransac_reference_uniforms(uint64_t seed, int n_trials, float *u_out /* [n_trials][3] */)
+{
+    for (int t = 0; t < n_trials; t++) {
+        orc_xorwow_state s;
+        orc_curand_init(seed, (uint64_t)t, 0, &s);
+        for (int k = 0; k < 3; k++) u_out[3 * t + k] = orc_curand_uniform(&s);
+    }
+}
+ORC_API void orc_ransac_reference_samples(uint64_t seed, int n_trials, int n_pts, int32_t *samples_out /* [n_trials][3] */)
+{
+    for (int t = 0; t < n_trials; t++) {
+        orc_xorwow_state s;
+        orc_curand_init(seed, (uint64_t)t, 0, &s);
+        for (int k = 0; k < 3; k++) samples_out[3 * t + k] = (int32_t)roundf(orc_curand_uniform(&s) * (float)(n_pts - 1));   /* :1159-1161 */
+    }
+}
+/* A^(2^k) (which = 0) or A^(2^(67 + k)) (which = 1), [160 input bits][5 output words] -- rocRAND's table layout */
+ORC_API void orc_xorwow_matrix(int which, int k, uint32_t *out /* 800 */)
+{
+    memcpy(out, orc_xorwow_power(which, k)->col, 800 * sizeof(uint32_t));
+}
 
 /* Sample index draw.  Reference: rand_idx = round(curand_uniform(&state) * (n_pts - 1)), u in (0, 1], one XORWOW
  * stream per trial (:1156-1163).  Here u = (h >> 8 + 1) * 2^-24 with h = a 32-bit mix of (seed, pair, trial, draw):

@@ -56,7 +56,7 @@ class OrcTrace(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
-    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("btba_oracle.c", "btba_oracle_ransac.c", "Makefile"))
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("btba_oracle.c", "btba_oracle_ransac.c", "xorwow.h", "Makefile"))
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
@@ -332,3 +332,55 @@ def ransac_pair(ptsA, ptsB, n_trials, dist_thres, samples=None, seed=0, pair_id=
       ids.ctypes.data, C.byref(n_in), C.byref(best), bp.ctypes.data, counts.ctypes.data, poses.ctypes.data)
     return dict(inlier_ids=ids[: n_in.value].copy(), best_trial=int(best.value), best_pose=bp.reshape(4, 4), counts=counts,
                 poses=poses.reshape(n_trials, 4, 4))
+
+
+# ---- cuRAND XORWOW as the reference's RANSAC draws from it (oracle/xorwow.h) -------------------------------------
+
+def curand_xorwow_state(seed: int, subsequence: int, offset: int = 0) -> np.ndarray:
+    """curand_init(seed, subsequence, offset): uint32 [6] = d, v[0..4]."""
+    out = np.zeros(6, np.uint32)
+    f = lib().orc_curand_xorwow_state
+    f.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    f.restype = None
+    f(seed, subsequence, offset, out.ctypes.data)
+    return out
+
+
+def curand_xorwow_draw(seed: int, subsequence: int, offset: int, n: int):
+    """n draws after curand_init(seed, subsequence, offset): (raw uint32 [n] = curand(), float32 [n] = curand_uniform())."""
+    raw, u = np.zeros(n, np.uint32), np.zeros(n, np.float32)
+    f = lib().orc_curand_xorwow_draw
+    f.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+    f.restype = None
+    f(seed, subsequence, offset, n, raw.ctypes.data, u.ctypes.data)
+    return raw, u
+
+
+def ransac_reference_uniforms(n_trials: int, seed: int = 0) -> np.ndarray:
+    """The reference's per-trial uniforms (curand_init(seed, trial, 0), three curand_uniform): float32 [n_trials, 3]."""
+    u = np.zeros((n_trials, 3), np.float32)
+    f = lib().orc_ransac_reference_uniforms
+    f.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
+    f.restype = None
+    f(seed, n_trials, u.ctypes.data)
+    return u
+
+
+def ransac_reference_samples(n_trials: int, n_pts: int, seed: int = 0) -> np.ndarray:
+    """round(curand_uniform * (n_pts - 1)) x 3 per trial (cuda_ransac.cu:1154-1161): int32 [n_trials, 3]."""
+    s = np.zeros((n_trials, 3), np.int32)
+    f = lib().orc_ransac_reference_samples
+    f.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+    f.restype = None
+    f(seed, n_trials, n_pts, s.ctypes.data)
+    return s
+
+
+def xorwow_matrix(which: int, k: int) -> np.ndarray:
+    """A^(2^k) (which 0) or A^(2^(67+k)) (which 1) of the XORWOW recurrence over GF(2): uint32 [160, 5], row c = image of unit bit c."""
+    m = np.zeros((160, 5), np.uint32)
+    f = lib().orc_xorwow_matrix
+    f.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    f.restype = None
+    f(which, k, m.ctypes.data)
+    return m

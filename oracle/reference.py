@@ -158,6 +158,24 @@ def eval_pose(ptsA, ptsB, pose, dist_thres):
     return ids[:n].copy()
 
 
+def ransac_multi_pair(ptsA, ptsB, n_trials, dist_thres):
+    """ransacMultiPairGPU (cuda_ransac.cu:1228-1323) end to end -- ransacEstimateModelKernel (cuRAND triples via oracle/xorwow.h,
+    procrustesKernel), ransacEvalModelKernel, findBestTrial, the host-side inlier gather -- on the sequential emulator.
+    ptsA[p], ptsB[p]: [n_p, 3|4] points of pair p.  Returns one ascending int32 inlier-id array per pair.  Among trials tied for
+    the most inliers the emulation keeps the LAST one (see oracle/ref_ransac_wrap.h)."""
+    A, B = [_pts4(a) for a in ptsA], [_pts4(b) for b in ptsB]
+    n_pts = np.array([len(a) for a in A], np.int32)
+    a_all, b_all = np.ascontiguousarray(np.concatenate(A)), np.ascontiguousarray(np.concatenate(B))
+    ids = np.zeros(max(int(n_pts.sum()), 1), np.int32); n_in = np.zeros(len(A), np.int32)
+    f = lib_ransac().ref_ransac_multi_pair
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    f(_p(a_all), _p(b_all), _p(n_pts), len(A), int(n_trials), float(dist_thres), _p(ids), _p(n_in))
+    out, o = [], 0
+    for p in range(len(A)):
+        out.append(ids[o:o + n_in[p]].copy()); o += int(n_pts[p])
+    return out
+
+
 # ---- the reference's WHOLE solver, emulated sequentially (oracle/_ref/libbtba_ref_solver.so) -----------------
 SO_SOLVER = os.path.join(_HERE, "_ref", "libbtba_ref_solver.so")
 _lib_s = None

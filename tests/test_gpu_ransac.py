@@ -49,12 +49,13 @@ def test_hypotheses_and_votes_match_oracle(ws, oracle):
 
 
 def test_device_sampling_matches_oracle_draws(ws, oracle):
-    """No explicit samples: both sides draw round(u (n-1)) from the same counter hash, so trial for trial they agree."""
+    """No explicit samples, BTBA_RANSAC_DRAW_HASH: both sides draw round(u (n-1)) from the same counter hash, so trial for trial they agree."""
     from bundletrack_amd.ransac import ransac_multi_pair
     rng = np.random.default_rng(6)
     sets = [planted(rng, n, f) for n, f in ((40, 0.25), (500, 0.45), (2000, 0.3))]
     from bundletrack_amd import _lib
-    res = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=99, want_trials=True, hypothesis=_lib.RANSAC_HORN)
+    hyp = _lib.RANSAC_HORN | _lib.RANSAC_DRAW_HASH
+    res = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=99, want_trials=True, hypothesis=hyp)
     for p, (P, Q, T, mask) in enumerate(sets):
         ref = oracle.ransac_pair(P, Q, 2000, 0.01, seed=99, pair_id=p)
         r = res[p]
@@ -63,7 +64,7 @@ def test_device_sampling_matches_oracle_draws(ws, oracle):
         assert np.array_equal(r["inlier_ids"], np.nonzero(mask)[0]) and np.array_equal(r["inlier_ids"], ref["inlier_ids"])
         e = S.pose_error(r["best_pose"], T)
         assert e[0] < 0.05 and e[1] < 0.005
-    again = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=99, want_trials=True, hypothesis=_lib.RANSAC_HORN)
+    again = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=99, want_trials=True, hypothesis=hyp)
     for a, b in zip(res, again):                                                 # deterministic, bit for bit
         assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["poses"], b["poses"]) and a["best_trial"] == b["best_trial"]
 
@@ -75,7 +76,7 @@ def test_edge_cases_and_caller_logic(ws):
     rng = np.random.default_rng(7)
     P, Q, T, mask = planted(rng, 50, 0.2)
     empty = np.zeros((0, 3), np.float32)
-    res = ransac_multi_pair(ws, [empty, P[:2], P], [empty, Q[:2], Q], n_trials=300, seed=1)
+    res = ransac_multi_pair(ws, [empty, P[:2], P], [empty, Q[:2], Q], n_trials=300, seed=1, hypothesis=_lib.RANSAC_DRAW_HASH)
     assert res[0]["best_trial"] == -1 and len(res[0]["inlier_ids"]) == 0        # empty pair
     assert res[1]["best_trial"] == -1 and len(res[1]["inlier_ids"]) == 0        # two points: nothing to fit
     assert np.array_equal(res[2]["inlier_ids"], np.nonzero(mask)[0])
@@ -171,7 +172,38 @@ def test_horn_and_reference_hypotheses_pick_the_same_inliers_on_tracker_size_pai
         P, Q, T, mask = planted(rng, 300, f)
         Q = (Q + rng.normal(size=Q.shape).astype(np.float32) * 0.001 * mask[:, None]).astype(np.float32)
         sets.append((P, Q, T, mask))
-    a = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=7)
-    b = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=7, hypothesis=_lib.RANSAC_HORN)
+    a = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=7, hypothesis=_lib.RANSAC_DRAW_HASH)
+    b = ransac_multi_pair(ws, [s[0] for s in sets], [s[1] for s in sets], n_trials=2000, inlier_dist=0.01, seed=7, hypothesis=_lib.RANSAC_HORN | _lib.RANSAC_DRAW_HASH)
     for (P, Q, T, mask), ra, rb in zip(sets, a, b):
         assert np.array_equal(ra["inlier_ids"], rb["inlier_ids"]) and np.array_equal(ra["inlier_ids"], np.nonzero(mask)[0])
+
+
+def test_default_draw_is_the_references_curand_stream(ws, oracle):
+    """samples = NULL, seed = 0 (the drop-in default): trial t of every pair samples round(u (n-1)) from cuRAND's XORWOW stream of
+    curand_init(0, t, 0) -- cuda_ransac.cu:1154-1161.  The product builds that stream on the host (btba_xorwow.hpp) and the vote
+    kernel reads it as a table; here the same call is repeated with the ORACLE's restatement of the stream (oracle/xorwow.h) passed
+    as explicit triples, and with the oracle's whole RANSAC on those triples.  Per-trial poses and counts, winner and inlier lists
+    must be identical -- for every pair, including pairs of different sizes in one launch, n_trials not a multiple of the
+    workgroup, a second seed, and a workspace whose cached table is first shorter, then for another seed."""
+    from bundletrack_amd import _lib
+    from bundletrack_amd.ransac import ransac_multi_pair
+    rng = np.random.default_rng(23)
+    sets = [planted(rng, n, f, noise=0.002) for n, f in ((3, 0.0), (7, 0.0), (40, 0.25), (300, 0.3), (301, 0.5), (2000, 0.3))]
+    A, B = [s[0] for s in sets], [s[1] for s in sets]
+    for n_trials, seed in ((100, 0), (777, 0), (2000, 0), (500, 12345), (2000, 0)):
+        dflt = ransac_multi_pair(ws, A, B, n_trials=n_trials, inlier_dist=0.01, seed=seed, want_trials=True)
+        smp = np.stack([oracle.ransac_reference_samples(n_trials, len(P), seed) for P in A])
+        expl = ransac_multi_pair(ws, A, B, n_trials=n_trials, inlier_dist=0.01, samples=smp, want_trials=True)
+        for p, (d, e) in enumerate(zip(dflt, expl)):
+            assert np.array_equal(d["counts"], e["counts"]) and np.array_equal(d["poses"].view(np.uint32), e["poses"].view(np.uint32)), (n_trials, seed, p)
+            assert d["best_trial"] == e["best_trial"] and np.array_equal(d["inlier_ids"], e["inlier_ids"])
+            ref = oracle.ransac_pair(A[p], B[p], n_trials, 0.01, samples=smp[p], hypothesis=0)
+            assert np.array_equal(d["counts"] > 0, ref["counts"] > 0)
+            assert (d["counts"] != ref["counts"]).mean() < 0.02                  # points within an ulp of the gate only
+            if np.array_equal(d["counts"], ref["counts"]):
+                assert d["best_trial"] == ref["best_trial"] and np.array_equal(d["inlier_ids"], ref["inlier_ids"])
+    # the stream is the same for every pair: two pairs with the same number of points draw the same triples
+    same = ransac_multi_pair(ws, [A[3], A[3]], [B[3], B[3]], n_trials=300, inlier_dist=0.01, want_trials=True)
+    assert np.array_equal(same[0]["counts"], same[1]["counts"]) and np.array_equal(same[0]["poses"], same[1]["poses"])
+    hashed = ransac_multi_pair(ws, [A[3], A[3]], [B[3], B[3]], n_trials=300, inlier_dist=0.01, want_trials=True, hypothesis=_lib.RANSAC_DRAW_HASH)
+    assert not np.array_equal(hashed[0]["counts"], hashed[1]["counts"])            # the counter hash gives every pair its own triples

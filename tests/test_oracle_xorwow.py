@@ -1,0 +1,166 @@
+"""The reference's RANSAC sample stream -- cuRAND XORWOW, curand_init(0, trial, 0) + 3 x curand_uniform, cuda_ransac.cu:1154-1161.
+
+cuRAND is CUDA-toolkit code that exists neither under /root/reference nor in this image, so its published algorithm is restated
+twice, independently: oracle/xorwow.h (test infrastructure; column-stored GF(2) matrices) and bundletrack_amd/csrc/btba_xorwow.hpp
+(product; row-stored matrices and parities, exported host-only as btba_ransac_reference_uniforms).  What pins them:
+  * the recurrence against Marsaglia's published xorwow code (restated here a third time in Python) and against rocRAND's A^1 table;
+  * the 2^67-step subsequence jump against rocRAND's precomputed h_xorwow_sequence_jump_matrices (same recurrence, same spacing),
+    and against plain stepping for small powers;
+  * the product against the oracle, bit for bit;
+  * the reference's own kernels + launcher (ransacMultiPairGPU, compiled for the CPU with oracle/xorwow.h behind curand_*)
+    against the oracle's RANSAC on the same stream, end to end.
+NOT pinned (no cuRAND here to run): the four seed-scrambling constants of curand_init and CURAND_2POW32_INV, restated from the
+published curand_kernel.h / curand_uniform.h.  DESIGN.md section 3 says the same."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROCRAND_TABLES = "/opt/rocm/include/rocrand/rocrand_xorwow_precomputed.h"
+M32 = 0xFFFFFFFF
+
+
+def py_xorwow(v, d, n):
+    """Marsaglia, "Xorshift RNGs" (2003) section 3.1, xorwow -- x, y, z, w, v and the Weyl counter d."""
+    v = list(v)
+    out = []
+    for _ in range(n):
+        t = v[0] ^ (v[0] >> 2)
+        v[0], v[1], v[2], v[3] = v[1], v[2], v[3], v[4]
+        v[4] = ((v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1))) & M32
+        d = (d + 362437) & M32
+        out.append((d + v[4]) & M32)
+    return out, v, d
+
+
+def py_seeded(seed):
+    s0, s1 = (seed & M32) ^ 0xAAD26B49, (seed >> 32) ^ 0xF7DCEFDD
+    t0, t1 = (1099087573 * s0) & M32, (2591861531 * s1) & M32
+    return [123456789 ^ t0, 362436069 ^ t0, 521288629 ^ t1, 88675123 ^ t1, (5783321 + t0) & M32], (6615241 + t1 + t0) & M32
+
+
+def rocrand_table(name):
+    txt = open(ROCRAND_TABLES).read()
+    i = txt.index(name)
+    body = txt[txt.index("{", txt.index("=", i)):txt.index("};", i)]
+    return np.array(re.findall(r"\d+", body), dtype=np.uint64).astype(np.uint32).reshape(32, 160, 5)
+
+
+def gf2_apply(M, v):
+    """M: uint32 [160, 5] (row c = image of unit bit c), v: 5 words."""
+    r = np.zeros(5, np.uint32)
+    for c in range(160):
+        if (int(v[c // 32]) >> (c % 32)) & 1:
+            r ^= M[c]
+    return r
+
+
+def test_recurrence_and_seeding_follow_the_published_algorithm(oracle):
+    # Marsaglia's own initial state is what curand_init leaves when the scrambled seed words cancel: check the raw recurrence on it
+    out, _, _ = py_xorwow([123456789, 362436069, 521288629, 88675123, 5783321], 6615241, 5)
+    assert out[0] == (6615241 + 362437 + (5783321 ^ (5783321 << 4) ^ (123456789 ^ (123456789 >> 2)) ^ ((123456789 ^ (123456789 >> 2)) << 1))) & M32
+    for seed in (0, 1, 1234, 2 ** 32 + 7, 2 ** 64 - 1):
+        v, d = py_seeded(seed)
+        st = oracle.curand_xorwow_state(seed, 0, 0)
+        assert int(st[0]) == d and [int(x) for x in st[1:]] == v
+        raw, u = oracle.curand_xorwow_draw(seed, 0, 0, 64)
+        want, _, _ = py_xorwow(v, d, 64)
+        assert [int(x) for x in raw] == want
+        # curand_uniform: x * 2^-32 + 2^-33 in fp32, (0, 1]
+        wu = (np.array(want, np.uint32).astype(np.float32) * np.float32(2.3283064e-10) + np.float32(2.3283064e-10) / np.float32(2)).astype(np.float32)
+        assert np.array_equal(u, wu) and u.min() > 0 and u.max() <= 1
+    assert np.float32(2.3283064e-10) == np.float32(2.0 ** -32)
+
+
+def test_offset_and_small_jumps_equal_plain_stepping(oracle):
+    for seed, off in ((0, 1), (0, 7), (5, 1000), (99, 4099)):
+        v, d = py_seeded(seed)
+        _, v2, d2 = py_xorwow(v, d, off)
+        st = oracle.curand_xorwow_state(seed, 0, off)
+        assert int(st[0]) == d2 and [int(x) for x in st[1:]] == v2
+    # A^(2^k) as a matrix = 2^k single steps
+    v, d = py_seeded(3)
+    for k in (0, 1, 5, 12):
+        _, vk, _ = py_xorwow(v, d, 2 ** k)
+        assert [int(x) for x in gf2_apply(oracle.xorwow_matrix(0, k), np.array(v, np.uint32))] == vk
+    # squaring chain: A^(2^(67+1)) applied once = A^(2^67) applied twice
+    x = np.array(py_seeded(11)[0], np.uint32)
+    J, J2 = oracle.xorwow_matrix(1, 0), oracle.xorwow_matrix(1, 1)
+    assert np.array_equal(gf2_apply(J2, x), gf2_apply(J, gf2_apply(J, x)))
+
+
+@pytest.mark.skipif(not os.path.exists(ROCRAND_TABLES), reason="rocRAND headers not installed")
+def test_jump_matrices_equal_rocrands_precomputed_tables(oracle):
+    """rocRAND's XORWOW has the same recurrence and the same 2^67 subsequence spacing as cuRAND's (only its seed scrambling
+    differs); its generated tables hold A^(4^i) and A^(4^i 2^67), i = 0..31, in the layout [input bit][output word]."""
+    steps, seqs = rocrand_table("h_xorwow_jump_matrices[XORWOW_JUMP_MATRICES][XORWOW_SIZE]"), rocrand_table("h_xorwow_sequence_jump_matrices[XORWOW_JUMP_MATRICES][XORWOW_SIZE]")
+    for i in (0, 1, 2, 9, 31):
+        assert np.array_equal(steps[i], oracle.xorwow_matrix(0, 2 * i)), i
+        assert np.array_equal(seqs[i], oracle.xorwow_matrix(1, 2 * i)), i
+    # subsequence t of curand_init = t applications of A^(2^67)
+    v, d = py_seeded(0)
+    x = np.array(v, np.uint32)
+    for t in range(1, 40):
+        x = gf2_apply(seqs[0], x)
+        st = oracle.curand_xorwow_state(0, t, 0)
+        assert int(st[0]) == d and np.array_equal(st[1:], x), t
+    st = oracle.curand_xorwow_state(0, 0xDEADBEEF12345, 0)          # a many-bit subsequence through rocRAND's base-4 digits
+    x, n, i = np.array(v, np.uint32), 0xDEADBEEF12345, 0
+    while n:
+        for _ in range(n & 3):
+            x = gf2_apply(seqs[i], x)
+        n >>= 2; i += 1
+    assert np.array_equal(st[1:], x)
+
+
+def test_product_stream_equals_the_oracles_bit_for_bit(oracle):
+    """btba_ransac_reference_uniforms (host-only entry of libbtba.so; bundletrack_amd/csrc/btba_xorwow.hpp) vs oracle/xorwow.h."""
+    from bundletrack_amd.ransac import reference_samples, reference_uniforms
+    for seed, n in ((0, 2000), (0, 1), (0, 0), (1, 500), (17, 500), (2 ** 40 + 5, 300), (2 ** 64 - 1, 300)):
+        got, want = reference_uniforms(n, seed), oracle.ransac_reference_uniforms(n, seed)
+        assert got.shape == (n, 3) and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, n)
+    assert np.array_equal(reference_uniforms(2000)[:100], reference_uniforms(100))          # trial t's draws do not depend on n_trials
+    for n_pts in (3, 4, 17, 300, 2000, 100000):
+        s = reference_samples(2000, n_pts)
+        assert np.array_equal(s, oracle.ransac_reference_samples(2000, n_pts)) and s.min() >= 0 and s.max() <= n_pts - 1
+    # round(u (n-1)): the two end points get half the weight of the others
+    s = oracle.ransac_reference_samples(20000, 11).ravel()
+    h = np.bincount(s, minlength=11)
+    assert h[0] < 0.7 * h[1:-1].mean() and h[-1] < 0.7 * h[1:-1].mean()
+    from bundletrack_amd import _lib
+    import ctypes as C
+    f = _lib.lib().btba_ransac_reference_uniforms
+    f.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
+    assert f(0, 5, None) == _lib.BTBA_EINVAL and f(0, -1, None) == _lib.BTBA_EINVAL
+
+
+def test_reference_ransac_end_to_end_matches_the_oracle_on_the_same_stream(oracle):
+    """ransacMultiPairGPU -- the reference's kernels and host launcher, run thread by thread on the CPU, drawing from oracle/xorwow.h
+    through its curand_* calls -- against the oracle's RANSAC (reference-exact hypotheses) fed the same triples explicitly.
+    Ties for the most inliers: the emulated findBestTrial keeps the last tied trial, the oracle the first; compare against that trial."""
+    from oracle import reference as R
+    if not R.available():
+        pytest.skip("oracle/_ref not built and /root/reference absent")
+    from test_oracle_ransac import planted
+    rng = np.random.default_rng(21)
+    n_trials = 600
+    sets = [planted(rng, n, frac, noise=0.002) for n, frac in ((5, 0.0), (40, 0.3), (300, 0.5), (301, 0.5), (700, 0.2))]
+    sets.append((sets[2][0][:3], sets[2][1][:3], None, None))                  # three points: every distinct triple is the whole set
+    got = R.ransac_multi_pair([s[0] for s in sets], [s[1] for s in sets], n_trials, 0.01)
+    n_ties = 0
+    for (P, Q, _, _), ids_ref in zip(sets, got):
+        smp = oracle.ransac_reference_samples(n_trials, len(P))
+        res = oracle.ransac_pair(P, Q, n_trials, 0.01, samples=smp, hypothesis=0)
+        counts = res["counts"]
+        if counts.max() == 0:
+            assert len(ids_ref) == 0 and res["best_trial"] == -1
+            continue
+        tied = np.nonzero(counts == counts.max())[0]
+        assert res["best_trial"] == tied[0] and len(ids_ref) == counts.max()
+        last = oracle.ransac_pair(P, Q, 1, 0.01, samples=smp[tied[-1]:tied[-1] + 1], hypothesis=0)
+        assert np.array_equal(ids_ref, last["inlier_ids"])
+        if len(tied) == 1:
+            assert np.array_equal(ids_ref, res["inlier_ids"])
+        n_ties += len(tied) > 1
+    print(f"pairs with tied best trials: {n_ties} of {len(sets)}")
