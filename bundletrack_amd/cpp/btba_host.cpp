@@ -232,6 +232,203 @@ std::vector<std::shared_ptr<Frame>> KeyframeMemory::selectKeyFramesForBA(const s
     return frames;
 }
 
+// ---- the slice of SiftManager that Bundler calls ----------------------------------------------------------------
+void FeatureManager::forgetFrame(const std::shared_ptr<Frame> &frame)
+{
+    for (auto it = _matches.begin(); it != _matches.end();)
+        it = (it->first.first == frame->_id || it->first.second == frame->_id) ? _matches.erase(it) : std::next(it);
+}
+
+int FeatureManager::countInlierCorres(const std::shared_ptr<Frame> &frameA, const std::shared_ptr<Frame> &frameB) const
+{
+    const auto it = _matches.find({ frameA->_id, frameB->_id });
+    return it == _matches.end() ? 0 : (int)(it->second.ptA_cam.size() / 3);      // every stored match is an inlier (pruned ones are removed, :717-738)
+}
+
+static void transform_points(const Matrix4f &T, const std::vector<float> &in, std::vector<float> &out)       // pcl::transformPointWithNormal, fp32
+{
+    out.resize(in.size());
+    for (size_t i = 0; i + 2 < in.size(); i += 3)
+        for (int r = 0; r < 3; r++) out[i + r] = T(r, 0) * in[i] + T(r, 1) * in[i + 1] + T(r, 2) * in[i + 2] + T(r, 3);
+}
+
+Matrix4f FeatureManager::procrustesByCorrespondence(const std::shared_ptr<Frame> &frameA, const std::shared_ptr<Frame> &frameB)
+{
+    Matrix4f pose = Matrix4f::Identity();
+    if (countInlierCorres(frameA, frameB) < 5) return pose;                      // :527
+    const Correspondences &m = _matches.at({ frameA->_id, frameB->_id });
+    std::vector<float> src, dst;
+    transform_points(frameA->_pose_in_model, m.ptA_cam, src);                    // :537-538
+    transform_points(frameB->_pose_in_model, m.ptB_cam, dst);
+    solveRigidTransformBetweenPoints(src, dst, pose);                            // :544 (the reference then aborts on a mean error > 1e-3 between neighbours)
+    return pose;
+}
+
+void FeatureManager::runRansacMultiPairGPU(btba_workspace *ws, const std::vector<std::pair<std::shared_ptr<Frame>, std::shared_ptr<Frame>>> &pairs,
+                                           int max_iter, float inlier_dist)
+{
+    if (pairs.empty()) return;
+    std::vector<float> A, B;                                                     // float4 (x, y, z, 1) of all pairs back to back (:680-705)
+    std::vector<int32_t> n_pts;
+    std::vector<float> pa, pb;
+    for (const auto &pr : pairs) {
+        const auto it = _matches.find({ pr.first->_id, pr.second->_id });
+        const size_t n = it == _matches.end() ? 0 : it->second.ptA_cam.size() / 3;
+        if (n) {
+            transform_points(pr.first->_pose_in_model, it->second.ptA_cam, pa);
+            transform_points(pr.second->_pose_in_model, it->second.ptB_cam, pb);
+            for (size_t i = 0; i < n; i++) {
+                A.insert(A.end(), { pa[3 * i], pa[3 * i + 1], pa[3 * i + 2], 1.0f });
+                B.insert(B.end(), { pb[3 * i], pb[3 * i + 1], pb[3 * i + 2], 1.0f });
+            }
+        }
+        n_pts.push_back((int32_t)n);
+    }
+    std::vector<int32_t> ids(std::max<size_t>(A.size() / 4, 1)), n_in(pairs.size()), best(pairs.size());
+    const int rc = btba_ransac_pairs(ws, (int)pairs.size(), A.data(), B.data(), n_pts.data(), max_iter, inlier_dist, /*samples=*/nullptr, /*seed=*/0,
+                                     ids.data(), n_in.data(), best.data(), nullptr, nullptr, nullptr);
+    if (rc != BTBA_OK) throw Error(rc, "btba_ransac_pairs");
+    size_t o = 0;
+    for (size_t p = 0; p < pairs.size(); p++) {                                  // :715-739
+        const auto it = _matches.find({ pairs[p].first->_id, pairs[p].second->_id });
+        if (it != _matches.end()) {
+            Correspondences kept;
+            if (n_in[p] >= 5)
+                for (int k = 0; k < n_in[p]; k++) {
+                    const int i = ids[o + k];
+                    kept.ptA_cam.insert(kept.ptA_cam.end(), it->second.ptA_cam.begin() + 3 * i, it->second.ptA_cam.begin() + 3 * i + 3);
+                    kept.ptB_cam.insert(kept.ptB_cam.end(), it->second.ptB_cam.begin() + 3 * i, it->second.ptB_cam.begin() + 3 * i + 3);
+                }
+            it->second = std::move(kept);                                        // fewer than 5 survivors: every match goes (:733-737)
+        }
+        o += (size_t)n_pts[p];
+    }
+}
+
+// ---- Bundler ---------------------------------------------------------------------------------------------------
+Bundler::Bundler(std::shared_ptr<Config> yml1, std::shared_ptr<FeatureManager> fm, const Matrix3f &K1, int H1, int W1, OptimizeFn optimize)
+    : yml(yml1 ? std::move(yml1) : std::make_shared<Config>()), _fm(std::move(fm)), memory(yml), K(K1), H(H1), W(W1), optimize_(std::move(optimize))
+{
+    if (!_fm) throw Error(BTBA_EINVAL, "Bundler: no feature manager");
+}
+
+void Bundler::processNewFrame(std::shared_ptr<Frame> frame)
+{
+    _newframe = frame;
+    std::shared_ptr<Frame> last_frame;
+    if (!_frames.empty()) {                                                      // :75-80
+        last_frame = _frames.back();
+        frame->_id = last_frame->_id + 1;
+        frame->_pose_in_model = last_frame->_pose_in_model;
+    }
+    if (frame->_status == Frame::FAIL) {                                         // :96-101 (an empty mask / cloud marked it)
+        _fm->forgetFrame(frame);
+        _need_reinit = true;
+        return;
+    }
+    try {
+        _fm->detectFeature(frame);                                               // :103-117
+    } catch (const std::exception &) {
+        frame->_status = Frame::FAIL;
+        _need_reinit = true;
+        _fm->forgetFrame(frame);
+        return;
+    }
+    if (last_frame) {
+        _fm->findCorres(frame, last_frame);                                      // :121
+        if (frame->_status == Frame::FAIL) {
+            _need_reinit = true;
+            _fm->forgetFrame(frame);
+            return;
+        }
+        const Matrix4f offset = _fm->procrustesByCorrespondence(frame, last_frame);      // :134-136: pose = offset * pose
+        Matrix4f moved;
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) {
+                float acc = 0.0f;
+                for (int k = 0; k < 4; k++) acc += offset(r, k) * frame->_pose_in_model(k, c);
+                moved(r, c) = acc;
+            }
+        frame->_pose_in_model = moved;
+    }
+    if ((int)_frames.size() >= yml->window_size + 3) {                           // :150-158
+        if (std::find(memory._keyframes.begin(), memory._keyframes.end(), _frames.front()) == memory._keyframes.end()) _fm->forgetFrame(_frames.front());
+        _frames.pop_front();
+    }
+    _frames.push_back(frame);
+    if (frame->_id == 0) {                                                       // :162-166
+        memory.checkAndAddKeyframe(frame);
+        return;
+    }
+    _local_frames = memory.selectKeyFramesForBA(frame);                          // :168-172
+    optimizeGPU();
+    if (frame->_status == Frame::FAIL) {                                         // :174-180
+        _fm->forgetFrame(frame);
+        _frames.pop_back();
+        if (own_opt_ && own_opt_->persistent_frame_cache) btba_frame_cache_evict(own_opt_->workspace(), (uint64_t)frame->_id);      // its id is handed out again
+        _need_reinit = true;
+        return;
+    }
+    memory.checkAndAddKeyframe(frame);                                           // :182
+    if (!yml->pose_dir.empty()) saveNewframeResult();
+}
+
+void Bundler::optimizeGPU()
+{
+    std::sort(_local_frames.begin(), _local_frames.end(), [](const std::shared_ptr<Frame> &a, const std::shared_ptr<Frame> &b) { return a->_id < b->_id; });   // :286
+    for (size_t i = 0; i < _local_frames.size(); i++)
+        for (size_t j = i + 1; j < _local_frames.size(); j++) _fm->findCorres(_local_frames[j], _local_frames[i]);                                       // :303
+    last_window = marshalWindow(_local_frames, _fm->_matches, _newframe, yml->min_fm_edges_newframe);          // :296-347 (sets NO_BA)
+    if (!last_window.run_ba) return;
+    const auto &fr = last_window.frames;
+    std::vector<float *> depths_gpu;
+    std::vector<uchar4 *> colors_gpu;
+    std::vector<float4 *> normals_gpu;
+    std::vector<Matrix4f> poses;
+    for (const auto &f : fr) { depths_gpu.push_back(f->_depth_gpu); colors_gpu.push_back(f->_color_gpu); normals_gpu.push_back(f->_normal_gpu); poses.push_back(f->_pose_in_model); }
+    if (optimize_) {
+        optimize_(last_window.global_corres, last_window.n_match_per_pair, (int)fr.size(), H, W, depths_gpu, colors_gpu, normals_gpu, poses, K);
+    } else {
+        if (!own_opt_) own_opt_ = std::make_unique<OptimizerGpu>(yml);
+        if (own_opt_->persistent_frame_cache) {
+            own_opt_->frame_ids.clear();
+            for (const auto &f : fr) own_opt_->frame_ids.push_back((uint64_t)f->_id);
+        }
+        own_opt_->optimizeFrames(last_window.global_corres, last_window.n_match_per_pair, (int)fr.size(), H, W, depths_gpu, colors_gpu, normals_gpu, poses, K);
+    }
+    n_ba_calls++;
+    for (size_t i = 0; i < fr.size(); i++) fr[i]->_pose_in_model = poses[i];     // :353-357
+}
+
+Matrix4f inverse(const Matrix4f &M)
+{
+    double a[4][8];                                                              // [M | I] -> [I | M^-1], Gauss-Jordan with partial pivoting
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { a[r][c] = M(r, c); a[r][4 + c] = r == c ? 1.0 : 0.0; }
+    for (int k = 0; k < 4; k++) {
+        int piv = k;
+        for (int r = k + 1; r < 4; r++) if (std::fabs(a[r][k]) > std::fabs(a[piv][k])) piv = r;
+        if (piv != k) for (int c = 0; c < 8; c++) std::swap(a[k][c], a[piv][c]);
+        const double d = a[k][k];                                                // 0 for a singular matrix: the result is inf / nan, as Eigen's
+        for (int c = 0; c < 8; c++) a[k][c] /= d;
+        for (int r = 0; r < 4; r++) {
+            if (r == k) continue;
+            const double f = a[r][k];
+            for (int c = 0; c < 8; c++) a[r][c] -= f * a[k][c];
+        }
+    }
+    Matrix4f R;
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) R(r, c) = (float)a[r][4 + c];
+    return R;
+}
+
+void Bundler::saveNewframeResult()
+{
+    if (yml->pose_dir.empty() || !_newframe) return;
+    const std::string name = _newframe->_id_str.empty() ? std::to_string(_newframe->_id) : _newframe->_id_str;
+    std::ofstream ff(yml->pose_dir + "/" + name + ".txt");                       // the caller creates the directory (the reference: system("mkdir -p"))
+    ff << formatPoseTxt(inverse(_newframe->_pose_in_model));                     // ob_in_cam = cur_in_model.inverse(), :371-375
+}
+
 // ---- problem dumps (bundletrack_amd/problem_io.py documents the layout) ---------------------------------------
 namespace {
 const char kProblemMagic[8] = { 'B', 'T', 'B', 'A', 'P', 'R', 'B', '1' };

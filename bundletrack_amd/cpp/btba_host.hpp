@@ -5,6 +5,9 @@
 //   OptimizerGpu::optimizeFrames                        src/cuda/LossGPU.h:40-52, LossGPU.cu:53-139
 //   Bundler::optimizeGPU's marshalling                  src/Bundler.cpp:286-347   (marshalWindow)
 //   Bundler::checkAndAddKeyframe / selectKeyFramesForBA src/Bundler.cpp:185-274   (KeyframeMemory)
+//   Bundler::processNewFrame / optimizeGPU / saveNewframeResult   src/Bundler.cpp:56-183, 279-359, 362-377   (Bundler)
+//   SiftManager::forgetFrame / procrustesByCorrespondence / runRansacMultiPairGPU   src/FeatureManager.cpp:142-170, 523-556, 659-741
+//                                                        (FeatureManager: the slice of SiftManager that Bundler calls)
 //   Utils::rotationGeodesicDistance                     src/Utils.cpp:42-47
 //   Utils::solveRigidTransformBetweenPoints             src/Utils.cpp:180-214     (Kabsch; a 3x3 one-sided Jacobi SVD stands in
 //                                                        for Eigen::JacobiSVD)
@@ -15,6 +18,8 @@
 // device code, no torch; HIP contributes the float4 / uchar4 pixel types only.
 #pragma once
 #include <cstdint>
+#include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -50,6 +55,10 @@ struct Config {
     int max_BA_frames = 15, min_fm_edges_newframe = 5;
     float keyframe_min_rot = 10.0f;
     int keyframe_min_feat_num = 0;
+    int window_size = 2;                          // bundle.window_size :26 ("exclude keyframes, include new frame")
+    int ransac_max_iter = 2000;                   // ransac.* :53-56
+    float ransac_inlier_dist = 0.01f;
+    std::string pose_dir;                         // debug_dir + "/poses/" (:5; Bundler.cpp:366); empty = do not write pose files
 };
 
 class Error : public std::runtime_error {       // the reference exits / spins instead (cutil_inline_runtime.h:261-269)
@@ -88,6 +97,7 @@ private:
 struct Frame {                                   // the fields of Frame (src/Frame.h:45-96) the BA caller touches
     enum Status { FAIL, NO_BA, OTHER };
     int _id = 0;
+    std::string _id_str;                         // names the pose file (Bundler.cpp:374)
     Status _status = OTHER;
     Matrix4f _pose_in_model = Matrix4f::Identity();
     int _n_keypts = 0;
@@ -128,6 +138,60 @@ public:
 private:
     std::shared_ptr<Config> yml;
 };
+
+// The slice of SiftManager (src/FeatureManager.h:86-130) that Bundler calls.  Feature detection and matching themselves are out of
+// scope (LF-Net over zmq, OpenCV): findCorres is the hook a tracker fills in; what the reference does with
+// the matches afterwards is implemented here.
+class FeatureManager {
+public:
+    std::map<std::pair<int, int>, Correspondences> _matches;        // _matches[{frameA, frameB}], keyed (newer id, older id)
+    virtual ~FeatureManager() = default;
+    virtual void detectFeature(const std::shared_ptr<Frame> & /*frame*/) {}
+    // fills _matches[{frameA->_id, frameB->_id}] unless present (:176); may mark frameA FAIL
+    virtual void findCorres(const std::shared_ptr<Frame> &frameA, const std::shared_ptr<Frame> &frameB) = 0;
+    virtual void forgetFrame(const std::shared_ptr<Frame> &frame);                                                   // :142-170
+    int countInlierCorres(const std::shared_ptr<Frame> &frameA, const std::shared_ptr<Frame> &frameB) const;          // :746-758
+    // :523-556: Kabsch of the matches moved into the model frame with the frames' current poses; identity below 5 matches
+    virtual Matrix4f procrustesByCorrespondence(const std::shared_ptr<Frame> &frameA, const std::shared_ptr<Frame> &frameB);
+    // :659-741 on btba_ransac_pairs (one call for all pairs; the reference's cuRAND triples and procrustesKernel hypotheses):
+    // every pair's matches are replaced by their RANSAC inliers, or emptied when fewer than 5 survive.  Needs the GPU.
+    void runRansacMultiPairGPU(btba_workspace *ws, const std::vector<std::pair<std::shared_ptr<Frame>, std::shared_ptr<Frame>>> &pairs,
+                               int max_iter, float inlier_dist);
+};
+
+// Bundler (src/Bundler.h, Bundler.cpp:56-377) from the point where a frame has its mask, depth and normals on the device:
+// pose initialisation from the previous frame, the sliding window, the keyframe subset, bundle adjustment, keyframe insertion,
+// the pose file.  `optimize` defaults to one persistent OptimizerGpu (the reference constructs a new one per call, :349);
+// tests inject a CPU stand-in with the same signature.
+class Bundler {
+public:
+    using OptimizeFn = std::function<void(const std::vector<EntryJ> &, const std::vector<int> &, int, int, int, const std::vector<float *> &,
+                                          const std::vector<uchar4 *> &, const std::vector<float4 *> &, std::vector<Matrix4f> &, const Matrix3f &)>;
+    std::shared_ptr<Config> yml;
+    std::shared_ptr<FeatureManager> _fm;
+    std::deque<std::shared_ptr<Frame>> _frames;
+    std::vector<std::shared_ptr<Frame>> _local_frames;
+    std::shared_ptr<Frame> _newframe;
+    bool _need_reinit = false;
+    KeyframeMemory memory;                                          // _keyframes + checkAndAddKeyframe + selectKeyFramesForBA
+    Matrix3f K{};
+    int H = 0, W = 0;
+    int n_ba_calls = 0;
+    Window last_window;                                             // what the last optimizeGPU marshalled
+
+    Bundler(std::shared_ptr<Config> yml1, std::shared_ptr<FeatureManager> fm, const Matrix3f &K1, int H1, int W1, OptimizeFn optimize = {});
+    void processNewFrame(std::shared_ptr<Frame> frame);             // :56-183
+    void optimizeGPU();                                             // :279-359
+    void saveNewframeResult();                                      // :362-377: <pose_dir>/<_id_str>.txt = inverse(pose_in_model), 10 digits
+    const std::vector<std::shared_ptr<Frame>> &keyframes() const { return memory._keyframes; }
+
+private:
+    OptimizeFn optimize_;
+    std::unique_ptr<OptimizerGpu> own_opt_;                         // created at the first BA call when no OptimizeFn was given
+};
+
+// Eigen's inverse() for a general 4x4, computed in double (used for the pose files)
+Matrix4f inverse(const Matrix4f &M);
 
 // One bundle-adjustment call as a file (the layout is documented in bundletrack_amd/problem_io.py, which writes and reads
 // the same bytes): what Bundler::optimizeGPU hands to OptimizerGpu::optimizeFrames, with the frames on the HOST -- the
