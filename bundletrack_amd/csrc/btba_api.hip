@@ -110,6 +110,21 @@ struct btba_workspace {
     }
 };
 
+// A workspace belongs to the device that was current when it was created.  A process that drives several GPUs from one thread
+// ("one process looping hipSetDevice") may call in with another device current: every entry point that takes a
+// workspace switches to the workspace's device for the duration of the call and back afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(const btba_workspace *ws)
+    {
+        int cur = -1;
+        if (ws && hipGetDevice(&cur) == hipSuccess && cur != ws->device && hipSetDevice(ws->device) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 extern "C" {
 
 void btba_params_default(btba_params *p)
@@ -175,6 +190,7 @@ static int workspace_create(btba_workspace **out, void *stream, bool use_given)
 
 void btba_workspace_destroy(btba_workspace *ws)
 {
+    DeviceGuard device_guard(ws);
     if (!ws) return;
     (void)hipStreamSynchronize(ws->stream);
     for (auto &ep : ws->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -194,6 +210,7 @@ void btba_workspace_destroy(btba_workspace *ws)
 
 int btba_workspace_sync(btba_workspace *ws)
 {
+    DeviceGuard device_guard(ws);
     if (!ws) return BTBA_EINVAL;
     HIP_TRY(hipStreamSynchronize(ws->stream));
     return BTBA_OK;
@@ -210,12 +227,14 @@ static int order_streams(btba_workspace *ws, hipStream_t from, hipStream_t to)
 
 int btba_workspace_wait_stream(btba_workspace *ws, void *stream)
 {
+    DeviceGuard device_guard(ws);
     if (!ws) return BTBA_EINVAL;
     return order_streams(ws, static_cast<hipStream_t>(stream), ws->stream);
 }
 
 int btba_workspace_signal_stream(btba_workspace *ws, void *stream)
 {
+    DeviceGuard device_guard(ws);
     if (!ws) return BTBA_EINVAL;
     return order_streams(ws, ws->stream, static_cast<hipStream_t>(stream));
 }
@@ -673,6 +692,7 @@ extern "C" {
 
 int btba_collect_stats(btba_workspace *ws, btba_stats *stats)
 {
+    DeviceGuard device_guard(ws);
     if (!ws) return BTBA_EINVAL;
     HIP_TRY(hipStreamSynchronize(ws->stream));
     btba_stats &S = ws->stats;
@@ -704,6 +724,7 @@ int btba_solve_batch(btba_workspace *ws, const btba_params *params, int n_instan
                      const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
                      float *poses_dev, float *trace_dev)
 {
+    DeviceGuard device_guard(ws);
     if (!ws) return BTBA_EINVAL;
     // Timed regions accumulate over calls until btba_collect_stats(); without BTBA_FLAG_TIME_KERNELS nothing
     // is recorded, so an un-collected caller does not grow the list.  A runaway list is recycled.
@@ -720,6 +741,7 @@ int btba_solve_cached(btba_workspace *ws, const btba_params *params, int n_frame
                       const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
                       float *poses_dev, float *trace_dev)
 {
+    DeviceGuard device_guard(ws);
     return btba_solve_batch(ws, params, 1, n_frames, Hd, Wd, intr, campos_dev, normals_dev, corr_dev, (int64_t)(n_corr ? n_corr : 1), pair_offsets_dev,
                             max_corr_per_pair, dense_pairs, n_dense_pairs, poses_dev, trace_dev);
 }
@@ -755,6 +777,7 @@ int btba_build_cache(btba_workspace *ws, int n_frames, int H, int W, const float
                      const float *const *depth_dev, const float *const *normal_dev,
                      float *campos_dev, float *normals_dev, int32_t *n_valid_dev, float *intr_out)
 {
+    DeviceGuard device_guard(ws);
     if (!ws || n_frames < 1 || H < 2 || W < 2 || !K || !depth_dev || !normal_dev || !campos_dev || !normals_dev || !(image_downscale >= 1.0f)) return BTBA_EINVAL;
     const int Wd = (int)(W / image_downscale), Hd = (int)(H / image_downscale);     // LossGPU.cu:56-57
     if (Wd < 2 || Hd < 2) return BTBA_EINVAL;
@@ -800,7 +823,8 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     btba_workspace *ws = ws_in;
     int rc = BTBA_OK;
     if (!ws) { if ((rc = btba_workspace_create_on_stream(&ws, nullptr))) return rc; }       // the reference's stream: the legacy NULL stream
-    auto finish = [&](int code) { if (!ws_in) btba_workspace_destroy(ws); return code; };
+    // an error return may leave asynchronous copies out of this function's locals (offsets, poses, descriptors) in flight: drain them
+    auto finish = [&](int code) { if (code != BTBA_OK && ws_in) (void)hipStreamSynchronize(ws->stream); if (!ws_in) btba_workspace_destroy(ws); return code; };
     for (auto &ep : ws->events) { ws->event_pool.push_back(ep.a); ws->event_pool.push_back(ep.b); }
     ws->events.clear();
 
@@ -1042,6 +1066,7 @@ int btba_optimize_frames(btba_workspace *ws, const btba_params *params, int n_fr
                          const float *const *depth_dev, const float *const *normal_dev,
                          const int32_t *dense_pairs, int n_dense_pairs, float *poses, btba_stats *stats)
 {
+    DeviceGuard device_guard(ws);
     return optimize_frames_impl(ws, params, n_frames, H, W, K, corres_host, n_corres, n_match_per_pair, depth_dev, normal_dev, nullptr,
                                 dense_pairs, n_dense_pairs, poses, stats);
 }
@@ -1051,6 +1076,7 @@ int btba_optimize_frames_keyed(btba_workspace *ws, const btba_params *params, in
                                const float *const *depth_dev, const float *const *normal_dev, const uint64_t *frame_keys,
                                const int32_t *dense_pairs, int n_dense_pairs, float *poses, btba_stats *stats)
 {
+    DeviceGuard device_guard(ws);
     if (!ws || !frame_keys) return BTBA_EINVAL;
     return optimize_frames_impl(ws, params, n_frames, H, W, K, corres_host, n_corres, n_match_per_pair, depth_dev, normal_dev, frame_keys,
                                 dense_pairs, n_dense_pairs, poses, stats);
@@ -1058,6 +1084,7 @@ int btba_optimize_frames_keyed(btba_workspace *ws, const btba_params *params, in
 
 int btba_frame_cache_clear(btba_workspace *ws)
 {
+    DeviceGuard device_guard(ws);
     if (!ws) return BTBA_EINVAL;
     for (auto &sl : ws->pool_slots) sl = btba_workspace::FrameSlot{};
     ws->corr_index.clear();
@@ -1067,6 +1094,7 @@ int btba_frame_cache_clear(btba_workspace *ws)
 
 int btba_frame_cache_evict(btba_workspace *ws, uint64_t frame_key)
 {
+    DeviceGuard device_guard(ws);
     if (!ws) return BTBA_EINVAL;
     for (auto &sl : ws->pool_slots) if (sl.live && sl.key == frame_key) sl = btba_workspace::FrameSlot{};
     for (auto it = ws->corr_index.begin(); it != ws->corr_index.end();)          // its correspondence segments go with it (the pool space is reclaimed at the next reset)
@@ -1164,6 +1192,7 @@ static int pool_resolve(btba_workspace *ws, int N, int H, int W, int Hd, int Wd,
 
 int btba_matrices_to_poses(btba_workspace *ws, int n, const float *T_dev, float *x_dev)
 {
+    DeviceGuard device_guard(ws);
     if (!ws || n < 1 || !T_dev || !x_dev) return BTBA_EINVAL;
     k_prepare<<<(n + 63) / 64, 64, 0, ws->stream>>>(n, T_dev, x_dev, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
@@ -1172,6 +1201,7 @@ int btba_matrices_to_poses(btba_workspace *ws, int n, const float *T_dev, float 
 
 int btba_poses_to_matrices(btba_workspace *ws, int n, const float *x_dev, float *T_dev, float *Tinv_dev)
 {
+    DeviceGuard device_guard(ws);
     if (!ws || n < 1 || !x_dev || (!T_dev && !Tinv_dev)) return BTBA_EINVAL;
     k_poses_to_matrices<<<(n + 63) / 64, 64, 0, ws->stream>>>(n, x_dev, T_dev, Tinv_dev);
     HIP_TRY(hipGetLastError());
@@ -1181,6 +1211,7 @@ int btba_poses_to_matrices(btba_workspace *ws, int n, const float *x_dev, float 
 int btba_process_depth(btba_workspace *ws, int H, int W, const float *depth_in_dev, float *depth_out_dev,
                        int erode_radius, float erode_diff, float erode_ratio, int bf_radius, float sigma_d, float sigma_r)
 {
+    DeviceGuard device_guard(ws);
     if (!ws || H < 1 || W < 1 || !depth_in_dev || !depth_out_dev || depth_in_dev == depth_out_dev) return BTBA_EINVAL;
     if (erode_radius < 0 || bf_radius < 0 || erode_radius + 2 * bf_radius > 16 || !(sigma_d > 0.0f) || !(sigma_r > 0.0f)) return BTBA_EINVAL;
     DepthFilterParams P{ W, H, erode_radius, erode_diff, erode_ratio, bf_radius, sigma_d, sigma_r };
@@ -1193,6 +1224,7 @@ int btba_process_depth(btba_workspace *ws, int H, int W, const float *depth_in_d
 
 int btba_depth_to_normals(btba_workspace *ws, int H, int W, const float *K, const float *depth_dev, float *normals_dev, float *xyz_dev)
 {
+    DeviceGuard device_guard(ws);
     if (!ws || H < 1 || W < 1 || !K || !depth_dev || !normals_dev) return BTBA_EINVAL;
     float intr[4];
     Mat4 Kinv;
@@ -1205,6 +1237,7 @@ int btba_depth_to_normals(btba_workspace *ws, int H, int W, const float *K, cons
 int btba_build_cache_zn(btba_workspace *ws, int n_frames, int H, int W, const float *K, float image_downscale,
                         const float *const *depth_dev, const float *const *normal_dev, float *zn_dev, int32_t *n_valid_dev, float *intr_out)
 {
+    DeviceGuard device_guard(ws);
     if (!ws || n_frames < 1 || H < 2 || W < 2 || !K || !depth_dev || !normal_dev || !zn_dev || !(image_downscale >= 1.0f)) return BTBA_EINVAL;
     const int Wd = (int)(W / image_downscale), Hd = (int)(H / image_downscale);
     if (Wd < 2 || Hd < 2) return BTBA_EINVAL;
@@ -1235,6 +1268,7 @@ int btba_build_cache_zn(btba_workspace *ws, int n_frames, int H, int W, const fl
 
 int btba_pack_zn(btba_workspace *ws, int64_t n_pixels_total, const float *campos_dev, const float *normals_dev, float *zn_dev)
 {
+    DeviceGuard device_guard(ws);
     if (!ws || n_pixels_total < 1 || !campos_dev || !normals_dev || !zn_dev) return BTBA_EINVAL;
     k_pack_zn<<<(unsigned)((n_pixels_total + kBlock - 1) / kBlock), kBlock, 0, ws->stream>>>((size_t)n_pixels_total, reinterpret_cast<const float4 *>(campos_dev),
                                                                                             reinterpret_cast<const float4 *>(normals_dev), reinterpret_cast<float4 *>(zn_dev));
@@ -1244,6 +1278,7 @@ int btba_pack_zn(btba_workspace *ws, int64_t n_pixels_total, const float *campos
 
 int btba_zn_block_ranges(btba_workspace *ws, int n_frames_total, int Hd, int Wd, const float *zn_dev, float *ranges_dev)
 {
+    DeviceGuard device_guard(ws);
     if (!ws || n_frames_total < 1 || Hd < 8 || Wd < 8 || (Hd % 8) || (Wd % 8) || !zn_dev || !ranges_dev) return BTBA_EINVAL;
     const int nblk = (Wd / 8) * (Hd / 8);
     k_block_ranges<<<dim3((unsigned)((nblk + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)n_frames_total), kBlock, 0, ws->stream>>>(Wd, Hd, reinterpret_cast<const float4 *>(zn_dev), nullptr, reinterpret_cast<float2 *>(ranges_dev));
@@ -1253,6 +1288,7 @@ int btba_zn_block_ranges(btba_workspace *ws, int n_frames_total, int Hd, int Wd,
 
 int btba_zn_valid_lists(btba_workspace *ws, int n_frames_total, int Hd, int Wd, const float *zn_dev, uint32_t *lists_dev, int32_t *counts_dev)
 {
+    DeviceGuard device_guard(ws);
     if (!ws || n_frames_total < 1 || Hd < 2 || Wd < 2 || !zn_dev || !lists_dev || !counts_dev) return BTBA_EINVAL;
     k_valid_lists<<<n_frames_total, 1024, 0, ws->stream>>>(Hd * Wd, reinterpret_cast<const float4 *>(zn_dev), lists_dev, counts_dev, nullptr);
     HIP_TRY(hipGetLastError());
@@ -1264,6 +1300,7 @@ int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, int n_ins
                         const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
                         float *poses_dev, float *trace_dev)
 {
+    DeviceGuard device_guard(ws);
     return btba_solve_batch_zn_aux(ws, params, n_instances, n_frames, H, W, K, zn_dev, nullptr, corr_dev, corr_stride, pair_offsets_dev, max_corr_per_pair,
                                    dense_pairs, n_dense_pairs, poses_dev, trace_dev);
 }
@@ -1273,6 +1310,7 @@ int btba_solve_batch_zn_aux(btba_workspace *ws, const btba_params *params, int n
                             const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
                             float *poses_dev, float *trace_dev)
 {
+    DeviceGuard device_guard(ws);
     if (!ws || !params || !K || !zn_dev || H < 2 || W < 2 || !(params->image_downscale >= 1.0f)) return BTBA_EINVAL;
     const int Wd = (int)(W / params->image_downscale), Hd = (int)(H / params->image_downscale);
     if (Wd < 2 || Hd < 2) return BTBA_EINVAL;
@@ -1297,6 +1335,7 @@ int btba_ransac_pairs_ex(btba_workspace *ws, int hypothesis, int device_resident
                          int32_t *inlier_ids_out, int32_t *n_inliers_out, int32_t *best_trial_out, float *best_pose_out,
                          int32_t *trial_counts_out, float *trial_poses_out)
 {
+    DeviceGuard device_guard(ws);
     if (!ws || n_pairs < 1 || !n_pts || n_trials < 1 || !(dist_thres >= 0.0f) || !inlier_ids_out || !n_inliers_out) return BTBA_EINVAL;
     const bool draw_hash = (hypothesis & BTBA_RANSAC_DRAW_HASH) != 0;
     hypothesis &= ~BTBA_RANSAC_DRAW_HASH;
@@ -1380,6 +1419,7 @@ int btba_ransac_pairs(btba_workspace *ws, int n_pairs, const float *ptsA_host, c
                       int32_t *inlier_ids_out, int32_t *n_inliers_out, int32_t *best_trial_out, float *best_pose_out,
                       int32_t *trial_counts_out, float *trial_poses_out)
 {
+    DeviceGuard device_guard(ws);
     return btba_ransac_pairs_ex(ws, BTBA_RANSAC_REFERENCE_SVD, 0, n_pairs, ptsA_host, ptsB_host, n_pts, n_trials, dist_thres, samples_host, seed,
                                 inlier_ids_out, n_inliers_out, best_trial_out, best_pose_out, trial_counts_out, trial_poses_out);
 }

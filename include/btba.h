@@ -169,7 +169,9 @@ BTBA_API int btba_version(void);
 
 /* One workspace = one HIP stream + reusable device scratch.  `stream` may be NULL (the
  * workspace then creates and owns a non-blocking stream: the caller orders it against its own streams with
- * btba_workspace_wait_stream / _signal_stream).  Re-entrant across workspaces. */
+ * btba_workspace_wait_stream / _signal_stream).  Re-entrant across workspaces.  A workspace lives on the device that is
+ * current when it is created; every call that takes it switches to that device for its duration and restores the caller's
+ * (one thread may drive several GPUs, one workspace each; buffers handed to a call must live on the workspace's device). */
 BTBA_API int btba_workspace_create(btba_workspace **out, void *stream);
 /* Same, but `stream` is used as given even when it is the NULL (legacy default) stream -- what a framework whose
  * "current stream" is the default stream (PyTorch) needs so that its own copies and kernels order with the solver. */
