@@ -49,8 +49,8 @@ def reference_uniforms(n_trials: int, seed: int = 0) -> np.ndarray:
 
 def reference_samples(n_trials: int, n_pts: int, seed: int = 0) -> np.ndarray:
     """The triples the reference's trial t draws on a pair of n_pts points: round(u * (n_pts - 1)) in fp32, int32 [n_trials, 3]."""
-    prod = reference_uniforms(n_trials, seed) * np.float32(n_pts - 1)
-    return (np.sign(prod) * np.floor(np.abs(prod) + np.float32(0.5))).astype(np.int32)      # roundf: half away from zero
+    prod = (reference_uniforms(n_trials, seed) * np.float32(n_pts - 1)).astype(np.float64)       # the fp32 product, then exactly:
+    return (np.sign(prod) * np.floor(np.abs(prod) + 0.5)).astype(np.int32)                        # roundf, half away from zero
 
 
 def ransac_packed(ws, a_all, b_all, n_pts, n_trials: int = 2000, inlier_dist: float = 0.01, samples=None, seed: int = 0,

@@ -207,3 +207,37 @@ def test_default_draw_is_the_references_curand_stream(ws, oracle):
     assert np.array_equal(same[0]["counts"], same[1]["counts"]) and np.array_equal(same[0]["poses"], same[1]["poses"])
     hashed = ransac_multi_pair(ws, [A[3], A[3]], [B[3], B[3]], n_trials=300, inlier_dist=0.01, want_trials=True, hypothesis=_lib.RANSAC_DRAW_HASH)
     assert not np.array_equal(hashed[0]["counts"], hashed[1]["counts"])            # the counter hash gives every pair its own triples
+
+
+def test_default_call_against_the_references_whole_ransac(ws, oracle):
+    """btba_ransac_pairs' default (samples NULL, seed 0) against ransacMultiPairGPU itself -- the reference's three kernels and host
+    launcher compiled from /root/reference for the CPU (oracle/_ref/libbtba_ref_ransac.so; cuRAND behind it is oracle/xorwow.h) -- end to
+    end, several pairs in one call on both sides: the same inlier lists.  Where several trials tie for the most inliers the emulated
+    findBestTrial keeps the last of them (a race on a real GPU), the product the first; the product's per-trial counts name the tied
+    trials and the reference's list must then be the product's list for the last one."""
+    from oracle import reference as R
+    if not os.path.exists(R.SO_RANSAC) or not hasattr(R.lib_ransac(), "ref_ransac_multi_pair"):
+        pytest.skip("oracle/_ref/libbtba_ref_ransac.so (with ransacMultiPairGPU) not built")
+    from bundletrack_amd.ransac import ransac_multi_pair, reference_samples
+    rng = np.random.default_rng(29)
+    sets = [planted(rng, n, f, noise=0.002) for n, f in ((5, 0.0), (40, 0.3), (300, 0.5), (301, 0.5), (700, 0.2), (1500, 0.4))]
+    A, B = [s[0] for s in sets], [s[1] for s in sets]
+    n_trials = 600
+    want = R.ransac_multi_pair(A, B, n_trials, 0.01)
+    got = ransac_multi_pair(ws, A, B, n_trials=n_trials, inlier_dist=0.01, seed=0, want_trials=True)
+    ties = 0
+    for p, (g, w) in enumerate(zip(got, want)):
+        counts = g["counts"]
+        if counts.max() == 0:
+            assert len(w) == 0 and g["best_trial"] == -1
+            continue
+        tied = np.nonzero(counts == counts.max())[0]
+        assert g["best_trial"] == tied[0] and len(w) == counts.max(), p
+        if len(tied) == 1:
+            assert np.array_equal(g["inlier_ids"], w), p
+        else:
+            ties += 1
+            smp = reference_samples(n_trials, len(A[p]))[tied[-1]][None, None, :]
+            last = ransac_multi_pair(ws, [A[p]], [B[p]], n_trials=1, inlier_dist=0.01, samples=smp)[0]
+            assert np.array_equal(last["inlier_ids"], w), p
+    print(f"HIP default call vs the reference's ransacMultiPairGPU: {len(sets)} pairs identical ({ties} through the tie rule)")
