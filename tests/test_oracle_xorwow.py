@@ -164,3 +164,15 @@ def test_reference_ransac_end_to_end_matches_the_oracle_on_the_same_stream(oracl
             assert np.array_equal(ids_ref, res["inlier_ids"])
         n_ties += len(tied) > 1
     print(f"pairs with tied best trials: {n_ties} of {len(sets)}")
+
+
+def test_stream_matches_the_committed_table(oracle):
+    """tests/golden/xorwow_seed0_first64.npz (self-derived, tests/golden/make_golden.py): the stream does not drift, in the oracle or
+    in the product -- and it is the table a CUDA machine's curand output is to be held against."""
+    from bundletrack_amd.ransac import reference_uniforms
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xorwow_seed0_first64.npz"))
+    assert np.array_equal(oracle.ransac_reference_uniforms(64).view(np.uint32), g["uniforms"].view(np.uint32))
+    assert np.array_equal(reference_uniforms(64).view(np.uint32), g["uniforms"].view(np.uint32))
+    for t in (0, 1, 63):
+        assert np.array_equal(oracle.curand_xorwow_draw(0, t, 0, 3)[0], g["raw"][t])
+    assert np.allclose(g["uniforms"][0], [0.6916408, 0.28643104, 0.10144828], rtol=0, atol=1e-7)
