@@ -41,13 +41,13 @@ def make(name):
 
 
 def make_xorwow():
-    """xorwow_seed0_first64.npz -- SELF-DERIVED (oracle/xorwow.h): the first three curand() / curand_uniform() draws of
+    """tables/xorwow_seed0_first64.npz -- SELF-DERIVED (oracle/xorwow.h): the first three curand() / curand_uniform() draws of
     curand_init(0, t, 0) for t = 0 .. 63, as this repository computes them.  It pins the product and the oracle against change,
     and it is the table to hold a CUDA machine's output against ("checking the cuRAND constants")."""
     from oracle import oracle
     u = oracle.ransac_reference_uniforms(64)
     raw = np.stack([oracle.curand_xorwow_draw(0, t, 0, 3)[0] for t in range(64)])
-    np.savez(os.path.join(os.path.dirname(os.path.abspath(__file__)), "xorwow_seed0_first64.npz"), uniforms=u, raw=raw)
+    np.savez(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tables", "xorwow_seed0_first64.npz"), uniforms=u, raw=raw)
 
 
 if __name__ == "__main__":

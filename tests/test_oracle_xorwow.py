@@ -167,10 +167,10 @@ def test_reference_ransac_end_to_end_matches_the_oracle_on_the_same_stream(oracl
 
 
 def test_stream_matches_the_committed_table(oracle):
-    """tests/golden/xorwow_seed0_first64.npz (self-derived, tests/golden/make_golden.py): the stream does not drift, in the oracle or
+    """tests/golden/tables/xorwow_seed0_first64.npz (self-derived, tests/golden/make_golden.py): the stream does not drift, in the oracle or
     in the product -- and it is the table a CUDA machine's curand output is to be held against."""
     from bundletrack_amd.ransac import reference_uniforms
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xorwow_seed0_first64.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tables", "xorwow_seed0_first64.npz"))
     assert np.array_equal(oracle.ransac_reference_uniforms(64).view(np.uint32), g["uniforms"].view(np.uint32))
     assert np.array_equal(reference_uniforms(64).view(np.uint32), g["uniforms"].view(np.uint32))
     for t in (0, 1, 63):
