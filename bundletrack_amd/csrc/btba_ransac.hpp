@@ -150,7 +150,7 @@ struct RansacDims {
     float dist_thres;
     uint64_t seed;
     int draw;            // where a trial's three indices come from: 0 counter hash of (seed, pair, trial, k); 1 explicit `samples`;
-                         // 2 the reference's cuRAND stream: round(u_table[trial][k] * (n - 1)) (btba_xorwow.hpp)
+                         // 2 the restated cuRAND stream (unverified against a CUDA run, btba_xorwow.hpp): round(u_table[trial][k] * (n - 1)) (btba_xorwow.hpp)
     int hypothesis;      // BTBA_RANSAC_REFERENCE_SVD (0): procrustesKernel with the reference's approximate 3x3 SVD, operation for operation; BTBA_RANSAC_HORN (1)
 };
 

@@ -11,7 +11,7 @@
 // cuRAND is CUDA-toolkit code (absent here); what follows implements its published XORWOW algorithm:
 //   recurrence  -- Marsaglia, "Xorshift RNGs" (2003), xorwow: t = v0 ^ (v0 >> 2); v0..v3 = v1..v4;
 //                  v4 = (v4 ^ (v4 << 4)) ^ (t ^ (t << 1)); d += 362437; output d + v4;
-//   curand_init -- scramble (seed) into (v, d) as curand_kernel.h does, then advance by subsequence * 2^67 steps (+ offset steps);
+//   curand_init -- scramble (seed) into (v, d) as curand_kernel.h does (restated from the published header, UNVERIFIED: see seeded()), then advance by subsequence * 2^67 steps (+ offset steps);
 //                  the five xorshift words evolve linearly over GF(2), so n steps are the 160 x 160 bit matrix A^n; the Weyl
 //                  counter d moves by 362437 * n, which is 0 mod 2^32 for n = k 2^67;
 //   uniform     -- x * 2^-32 + 2^-33 in fp32, in (0, 1].
@@ -107,13 +107,22 @@ inline uint32_t next(State &s)                               // curand(&state)
     s.d += 362437u;
     return s.d + s.v[4];
 }
-inline State seeded(uint64_t seed)                           // curand_init(seed, 0, 0)
+// Seed scrambling of curand_init, as published in curand_kernel.h (_curand_init_scratch): two salts XORed into the halves of the seed,
+// two odd multipliers, then Marsaglia's five initial words and his d combined with the products as  +, ^, +, ^, +  and  d + t1 + t0.
+// rocRAND's xorwow_engine (/opt/rocm/include/rocrand/rocrand_xorwow.h:113-122) is the same construction with four other constants, which
+// is what lets a third-party implementation pin the operators here (tests/test_oracle_xorwow.py builds rocRAND's engine on the host and
+// compares it with seeded(seed, kRocrandSeeding)).  The four cuRAND constants themselves rest on the published header alone:
+// RESTATED, UNVERIFIED until a CUDA machine prints the rows INTEGRATION.md names.
+struct SeedConstants { uint32_t salt_lo, salt_hi, mul_lo, mul_hi; };
+constexpr SeedConstants kCurandSeeding = { 0xaad26b49u, 0xf7dcefddu, 1099087573u, 2591861531u };
+constexpr SeedConstants kRocrandSeeding = { 0x2c7f967fu, 0xa03697cbu, 1228688033u, 2073658381u };
+inline State seeded(uint64_t seed, const SeedConstants &k = kCurandSeeding)          // curand_init(seed, 0, 0)
 {
     State s;
-    const uint32_t lo = (uint32_t)seed ^ 0xaad26b49u, hi = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
-    const uint32_t a = 1099087573u * lo, b = 2591861531u * hi;
-    s.d = 6615241u + b + a;
-    s.v[0] = 123456789u ^ a; s.v[1] = 362436069u ^ a; s.v[2] = 521288629u ^ b; s.v[3] = 88675123u ^ b; s.v[4] = 5783321u + a;
+    const uint32_t s0 = (uint32_t)seed ^ k.salt_lo, s1 = (uint32_t)(seed >> 32) ^ k.salt_hi;
+    const uint32_t t0 = k.mul_lo * s0, t1 = k.mul_hi * s1;
+    s.d = 6615241u + t1 + t0;
+    s.v[0] = 123456789u + t0; s.v[1] = 362436069u ^ t0; s.v[2] = 521288629u + t1; s.v[3] = 88675123u ^ t1; s.v[4] = 5783321u + t0;
     return s;
 }
 inline float uniform(State &s)                               // curand_uniform(&state)
@@ -122,17 +131,20 @@ inline float uniform(State &s)                               // curand_uniform(&
     return (float)next(s) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);      // CURAND_2POW32_INV; the product is exact
 }
 
-// u_out[3 t + k] = the k-th curand_uniform after curand_init(seed, t, 0), t = 0 .. n_trials-1
-inline void ransac_uniform_table(uint64_t seed, int n_trials, float *u_out)
+// u_out[3 t + k] = the k-th curand_uniform after curand_init(seed, t, 0), t = 0 .. n_trials-1 (raw_out, optional: the curand() words)
+inline void ransac_uniform_table(uint64_t seed, int n_trials, float *u_out, const SeedConstants &k = kCurandSeeding, uint32_t *raw_out = nullptr)
 {
     const Matrix &J = subsequence_jump();
-    const State s0 = seeded(seed);
+    const State s0 = seeded(seed, k);
     Bits160 x = pack(s0.v);
     for (int t = 0; t < n_trials; t++) {
         State s;
         s.d = s0.d;                                          // a subsequence jump leaves the Weyl counter where it is
         unpack(x, s.v);
-        for (int k = 0; k < 3; k++) u_out[3 * t + k] = uniform(s);
+        for (int q = 0; q < 3; q++) {
+            if (raw_out) { State c = s; raw_out[3 * t + q] = next(c); }
+            u_out[3 * t + q] = uniform(s);
+        }
         x = apply(J, x);
     }
 }

@@ -352,12 +352,14 @@ BTBA_API int btba_solve_batch_zn_aux(btba_workspace *ws, const btba_params *para
  *   ptsA_host / ptsB_host : float4 (x, y, z, 1) points of ALL pairs back to back (model frame, as the reference uploads
  *                           them); pair p owns n_pts[p] consecutive points.
  *   samples_host          : NULL, or int32 [n_pairs][n_trials][3] explicit sample indices (the rand_list of
- *                           ransacMultiPairKernel, :1105).  NULL: the reference's own stream -- trial t draws
+ *                           ransacMultiPairKernel, :1105).  NULL: the reference's generator, RESTATED AND UNVERIFIED -- trial t draws
  *                           round(u (n_pts-1)) three times from cuRAND's XORWOW generator after curand_init(seed, t, 0)
  *                           (ransacEstimateModelKernel, :1154-1161; the reference's literal seed is 0 -- pass seed = 0 for its
  *                           triples).  That stream does not depend on the pair, so it is one table of n_trials x 3 uniforms,
  *                           computed on the host from cuRAND's published algorithm (btba_ransac_reference_uniforms below),
- *                           kept in the workspace and read by the vote kernel.  With BTBA_RANSAC_DRAW_HASH (btba_ransac_pairs_ex)
+ *                           kept in the workspace and read by the vote kernel.  No cuRAND exists on this side: operators, jumps
+ *                           and recurrence are pinned against rocRAND's engine, the four seed constants and the uniform
+ *                           conversion rest on the published headers (INTEGRATION.md gives the CUDA snippet that settles it).  With BTBA_RANSAC_DRAW_HASH (btba_ransac_pairs_ex)
  *                           the triples come from a counter hash of (seed, pair, trial, draw) instead: same round(u (n-1))
  *                           shape, but every pair gets its own triples.  Trials with repeated / negative / out-of-range
  *                           indices are skipped (:1164-1165).
@@ -377,7 +379,7 @@ BTBA_API int btba_solve_batch_zn_aux(btba_workspace *ws, const btba_params *para
  * on the host), nothing but the 4 (n_pairs + 1)-byte offset table crosses PCIe, and the call is asynchronous on the workspace
  * stream (the host-buffer form spends ~60 % of a tracker-size call in its copies). */
 enum { BTBA_RANSAC_REFERENCE_SVD = 0, BTBA_RANSAC_HORN = 1,
-       BTBA_RANSAC_DRAW_HASH = 0x100 /* ORed into `hypothesis`: counter-hash triples instead of the reference's cuRAND stream */ };
+       BTBA_RANSAC_DRAW_HASH = 0x100 /* ORed into `hypothesis`: counter-hash triples instead of the restated cuRAND stream */ };
 BTBA_API int btba_ransac_pairs_ex(btba_workspace *ws, int hypothesis, int device_resident, int n_pairs, const float *ptsA, const float *ptsB,
                                   const int32_t *n_pts, int n_trials, float dist_thres, const int32_t *samples, uint64_t seed,
                                   int32_t *inlier_ids_out, int32_t *n_inliers_out, int32_t *best_trial_out, float *best_pose_out,
@@ -387,7 +389,7 @@ BTBA_API int btba_ransac_pairs(btba_workspace *ws, int n_pairs, const float *pts
                                int32_t *inlier_ids_out, int32_t *n_inliers_out, int32_t *best_trial_out, float *best_pose_out,
                                int32_t *trial_counts_out, float *trial_poses_out);
 
-/* The reference's RANSAC sample stream as numbers: u_out[3 t + k] = the k-th curand_uniform() after curand_init(seed, t, 0) of
+/* The reference's RANSAC sample stream as numbers (restated from cuRAND's published headers; unverified against a CUDA run): u_out[3 t + k] = the k-th curand_uniform() after curand_init(seed, t, 0) of
  * cuRAND's XORWOW generator, t = 0 .. n_trials-1 (cuda_ransac.cu:1154-1161); trial t of a pair with n points samples
  * round(u * (n - 1)).  Host-only (no GPU, no workspace): Marsaglia's xorwow recurrence, cuRAND's seed scrambling and its
  * 2^67-step subsequence jump as a GF(2) matrix power (bundletrack_amd/csrc/btba_xorwow.hpp).  BTBA_EINVAL on bad arguments. */

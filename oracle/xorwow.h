@@ -15,8 +15,9 @@
  *     (/opt/rocm/include/rocrand/rocrand_xorwow.h), and tests/test_oracle_xorwow.py checks this file's one-step matrix
  *     against rocRAND's precomputed A^1;
  *   - curand_init(seed, subsequence, offset): seed scrambling as in curand_kernel.h's _curand_init_scratch (constants
- *     0xaad26b49, 0xf7dcefdd, 1099087573, 2591861531 -- restated from the published header, NOT verifiable here: PARITY
- *     UNPINNED for these four constants), then a jump of subsequence * 2^67 steps and of `offset` steps.  The 2^67 jump is
+ *     0xaad26b49, 0xf7dcefdd, 1099087573, 2591861531, combined with Marsaglia's initial words as +, ^, +, ^, + -- restated from
+ *     the published header, NOT verifiable here: PARITY UNPINNED for the four constants; the operator pattern is the one
+ *     rocRAND's cuRAND-derived engine uses and is checked against that engine with rocRAND's constants), then a jump of subsequence * 2^67 steps and of `offset` steps.  The 2^67 jump is
  *     the 160x160 GF(2) matrix A^(2^67) obtained here by 67 squarings; tests check it against rocRAND's precomputed
  *     h_xorwow_sequence_jump_matrices[0] (rocRAND documents the same 2^67 spacing).  d is unchanged by a subsequence jump
  *     (362437 * k * 2^67 = 0 mod 2^32) and advanced by 362437 * offset;
@@ -91,20 +92,31 @@ static inline void orc_xorwow_jump(orc_xorwow_state *s, uint64_t n, int which)
         if (n & 1u) orc_xorwow_matvec(orc_xorwow_power(which, k), s->v, s->v);
 }
 
-/* curand_init(seed, subsequence, offset, &state) for curandStateXORWOW_t */
-static inline void orc_curand_init(uint64_t seed, uint64_t subsequence, uint64_t offset, orc_xorwow_state *s)
+/* curand_init(seed, subsequence, offset, &state) for curandStateXORWOW_t, with the four seed-scrambling constants as a parameter:
+ * consts = { salt of the low seed word, salt of the high word, multiplier of the low word, multiplier of the high word }.
+ * Published curand_kernel.h (_curand_init_scratch): v[0] = 123456789 + t0, v[1] = 362436069 ^ t0, v[2] = 521288629 + t1,
+ * v[3] = 88675123 ^ t1, v[4] = 5783321 + t0, d = 6615241 + t1 + t0.  rocRAND's xorwow_engine constructor
+ * (/opt/rocm/include/rocrand/rocrand_xorwow.h:113-122) is the same construction with other constants -- with ITS constants this
+ * function must reproduce rocRAND's engine bit for bit, which tests/test_oracle_xorwow.py checks against the engine itself. */
+static const uint32_t orc_curand_seed_consts[4] = { 0xaad26b49u, 0xf7dcefddu, 1099087573u, 2591861531u };
+static const uint32_t orc_rocrand_seed_consts[4] = { 0x2c7f967fu, 0xa03697cbu, 1228688033u, 2073658381u };
+static inline void orc_xorwow_init_consts(const uint32_t consts[4], uint64_t seed, uint64_t subsequence, uint64_t offset, orc_xorwow_state *s)
 {
-    const uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u, s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
-    const uint32_t t0 = 1099087573u * s0, t1 = 2591861531u * s1;
+    const uint32_t s0 = (uint32_t)seed ^ consts[0], s1 = (uint32_t)(seed >> 32) ^ consts[1];
+    const uint32_t t0 = consts[2] * s0, t1 = consts[3] * s1;
     s->d = 6615241u + t1 + t0;
-    s->v[0] = 123456789u ^ t0;
+    s->v[0] = 123456789u + t0;
     s->v[1] = 362436069u ^ t0;
-    s->v[2] = 521288629u ^ t1;
+    s->v[2] = 521288629u + t1;
     s->v[3] = 88675123u ^ t1;
     s->v[4] = 5783321u + t0;
     orc_xorwow_jump(s, subsequence, 1);                  /* d: + 362437 * subsequence * 2^67 = + 0 (mod 2^32) */
     orc_xorwow_jump(s, offset, 0);
     s->d += 362437u * (uint32_t)offset;
+}
+static inline void orc_curand_init(uint64_t seed, uint64_t subsequence, uint64_t offset, orc_xorwow_state *s)
+{
+    orc_xorwow_init_consts(orc_curand_seed_consts, seed, subsequence, offset, s);
 }
 /* curand_uniform(&state): (0, 1] */
 static inline float orc_curand_uniform(orc_xorwow_state *s)

@@ -178,7 +178,7 @@ def test_horn_and_reference_hypotheses_pick_the_same_inliers_on_tracker_size_pai
         assert np.array_equal(ra["inlier_ids"], rb["inlier_ids"]) and np.array_equal(ra["inlier_ids"], np.nonzero(mask)[0])
 
 
-def test_default_draw_is_the_references_curand_stream(ws, oracle):
+def test_default_draw_is_the_restated_curand_stream(ws, oracle):
     """samples = NULL, seed = 0 (the drop-in default): trial t of every pair samples round(u (n-1)) from cuRAND's XORWOW stream of
     curand_init(0, t, 0) -- cuda_ransac.cu:1154-1161.  The product builds that stream on the host (btba_xorwow.hpp) and the vote
     kernel reads it as a table; here the same call is repeated with the ORACLE's restatement of the stream (oracle/xorwow.h) passed
