@@ -23,7 +23,8 @@ REDUCE_DETERMINISTIC, REDUCE_ATOMIC = 0, 1
 RANSAC_REFERENCE_SVD, RANSAC_HORN = 0, 1
 RANSAC_DRAW_HASH = 0x100      # ORed into `hypothesis`: counter-hash sample triples instead of the reference's cuRAND XORWOW stream
 FLAG_TRACE, FLAG_TIME_KERNELS = 1, 2
-FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_KEYED_CORR, FLAG_FLOAT4_CACHE, FLAG_NO_COMPACTION, FLAG_COMPACTION, FLAG_TIME_SAMPLED = 32, 64, 128, 256, 512, 1024, 2048
+FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_KEYED_CORR, FLAG_FLOAT4_CACHE, FLAG_NO_COMPACTION, FLAG_COMPACTION, FLAG_TIME_SAMPLED = 32, 64, 4096, 256, 512, 1024, 2048
+OPT_DENSE_ORDER, OPT_TILE_MAJOR, OPT_BLOCK_WALK, OPT_BLOCK_SKIP, OPT_BIG_ASSEMBLY, OPT_OVERLAP_GROUPS, OPT_OVERLAP_EQUAL_PRIO, OPT_KEYED_CORR_MIN_BYTES, OPT_PERSISTENT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 ENTRYJ_DTYPE = np.dtype(
     [("imgIdx_i", "<u4"), ("imgIdx_j", "<u4"), ("pos_i", "<f4", (3,)), ("pos_j", "<f4", (3,))]
@@ -32,7 +33,7 @@ ENTRYJ_DTYPE = np.dtype(
 EXPORTED_SYMBOLS = [
     "btba_params_default", "btba_strerror", "btba_last_hip_error", "btba_version",
     "btba_workspace_create", "btba_workspace_create_on_stream", "btba_workspace_destroy", "btba_workspace_sync",
-    "btba_workspace_wait_stream", "btba_workspace_signal_stream",
+    "btba_workspace_wait_stream", "btba_workspace_signal_stream", "btba_workspace_set_option",
     "btba_optimize_frames", "btba_optimize_frames_keyed", "btba_frame_cache_clear", "btba_frame_cache_evict", "btba_ransac_pairs", "btba_ransac_pairs_ex", "btba_ransac_reference_uniforms", "btba_build_cache", "btba_solve_batch", "btba_solve_cached", "btba_collect_stats",
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
@@ -61,6 +62,7 @@ class Stats(C.Structure):
         ("n_dense_launches", C.c_int32), ("n_sparse_launches", C.c_int32), ("n_solve_launches", C.c_int32),
         ("bytes_dense_alg", C.c_int64), ("bytes_sparse_alg", C.c_int64),
         ("fused_sweeps", C.c_int32), ("cache_frames_built", C.c_int32), ("corr_pairs_uploaded", C.c_int32),
+        ("ms_pair_setup", C.c_float), ("n_setup_launches", C.c_int32),
     ]
 
     def as_dict(self):
@@ -138,12 +140,16 @@ def lib() -> C.CDLL:
         L.btba_strerror.restype = C.c_char_p
         L.btba_strerror.argtypes = [C.c_int]
         for name in EXPORTED_SYMBOLS:
+            if "BTBA_LIB_PATH" in os.environ and name == "btba_workspace_set_option" and not hasattr(L, name):
+                continue               # developer A/B against a build from before version 103
             getattr(L, name)           # AttributeError if the ABI and the header drift apart
         L.btba_workspace_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p]
         L.btba_workspace_create_on_stream.argtypes = [C.POINTER(C.c_void_p), C.c_void_p]
         L.btba_workspace_destroy.argtypes = [C.c_void_p]
         L.btba_workspace_destroy.restype = None
         L.btba_workspace_sync.argtypes = [C.c_void_p]
+        if hasattr(L, "btba_workspace_set_option"):
+            L.btba_workspace_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
         L.btba_workspace_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.btba_workspace_signal_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.btba_collect_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]

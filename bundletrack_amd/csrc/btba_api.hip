@@ -54,7 +54,7 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
-struct EventPair { hipEvent_t a, b; int kind; };   // kind 0 dense, 1 sparse, 2 system, 3 solve region, 4 cache
+struct EventPair { hipEvent_t a, b; int kind; };   // kind 0 dense, 1 sparse, 2 system, 3 solve region, 4 cache, 5 pair set-up
 
 }  // namespace
 
@@ -66,6 +66,20 @@ struct btba_workspace {
     DevBuf corr, offsets, poses, campos, normals, nvalid;   // optimize_frames staging
     DevBuf valid_lists, valid_counts;                       // per-frame lists of pixels with a depth (compact cache)
     DevBuf block_ranges;                                    // per (frame, 8 x 8 block) usable depth range: dead-block test of the dense sweep
+    DevBuf dense_desc, live_counts, live_lists, item_queue;             // k_pair_setup's output per (instance, work position): descriptor, live-block counts and lists
+    // Developer / tuning switches.  Read from the environment ONCE, when the workspace is created (never on the solve path), and settable
+    // per workspace through btba_workspace_set_option (include/btba.h: BTBA_OPT_*).  None of them changes what is computed.
+    struct Tuning {
+        bool dense_order = true;       // BTBA_OPT_DENSE_ORDER   (env BTBA_NO_DENSE_ORDER=1 turns it off): dense pairs worked off heaviest first
+        bool tile_major = true;        // BTBA_OPT_TILE_MAJOR    (env BTBA_PAIR_MAJOR=1 turns it off): (band, pair) instead of (pair, band) work order
+        bool block_walk = true;        // BTBA_OPT_BLOCK_WALK    (env BTBA_NO_BLOCK_WALK=1): waves walk 8 x 8 blocks instead of 64 x 1 strips
+        bool block_skip = true;        // BTBA_OPT_BLOCK_SKIP    (env BTBA_NO_BLOCK_SKIP=1): provably dead blocks are not walked
+        bool persistent = true;        // BTBA_OPT_PERSISTENT    (env BTBA_NO_PERSISTENT=1): the fused sweep as persistent workgroups pulling items from per-XCD cursors
+        bool big_assembly = true;      // BTBA_OPT_BIG_ASSEMBLY  (env BTBA_NO_BIG_ASSEMBLY=1): many-workgroup reduction / assembly from 24 frames on
+        int overlap_groups = 2;        // BTBA_OPT_OVERLAP_GROUPS (env BTBA_GROUPS): instance groups of BTBA_FLAG_OVERLAP
+        bool overlap_equal_prio = false;   // BTBA_OPT_OVERLAP_EQUAL_PRIO (env BTBA_GROUP_PRIO=e...)
+        size_t keyed_corr_min_bytes = (size_t)1 << 20;   // BTBA_OPT_KEYED_CORR_MIN_BYTES (env of the same name): below it the keyed correspondence cache is not used
+    } tune;
     std::vector<int32_t> dense_pairs_host;                  // what dense_pairs currently holds
     int dense_pairs_frames = -1;
     size_t dense_work_offset = 0;                           // ints into dense_pairs: the fused sweep's work table
@@ -177,6 +191,19 @@ static int workspace_create(btba_workspace **out, void *stream, bool use_given)
     btba_workspace *ws = new (std::nothrow) btba_workspace();
     if (!ws) return BTBA_ENOMEM;
     if (hipGetDevice(&ws->device) != hipSuccess) { delete ws; return BTBA_EHIP; }
+    {   // developer switches from the environment: here and nowhere else
+        auto on = [](const char *name) { const char *e = std::getenv(name); return e && e[0] && e[0] != '0'; };
+        btba_workspace::Tuning &t = ws->tune;
+        t.dense_order = !on("BTBA_NO_DENSE_ORDER");
+        t.tile_major = !on("BTBA_PAIR_MAJOR");
+        t.block_walk = !on("BTBA_NO_BLOCK_WALK");
+        t.block_skip = !on("BTBA_NO_BLOCK_SKIP");
+        t.big_assembly = !on("BTBA_NO_BIG_ASSEMBLY");
+        t.persistent = !on("BTBA_NO_PERSISTENT");
+        if (const char *e = std::getenv("BTBA_GROUPS")) t.overlap_groups = std::atoi(e);
+        if (const char *e = std::getenv("BTBA_GROUP_PRIO")) t.overlap_equal_prio = e[0] == 'e';
+        if (const char *e = std::getenv("BTBA_KEYED_CORR_MIN_BYTES")) t.keyed_corr_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
+    }
     if (use_given) {
         ws->stream = reinterpret_cast<hipStream_t>(stream);       // may be the NULL stream
     } else {
@@ -197,7 +224,7 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A, &ws->solve_tab,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts, &ws->block_ranges,
-                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc };
+                       &ws->dense_desc, &ws->live_counts, &ws->live_lists, &ws->item_queue, &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc };
     for (auto b : bufs) b->release();
     if (ws->corr_stage) (void)hipHostFree(ws->corr_stage);
     for (auto st : ws->aux_streams) if (st) (void)hipStreamDestroy(st);
@@ -206,6 +233,25 @@ void btba_workspace_destroy(btba_workspace *ws)
     if (ws->ev_order) (void)hipEventDestroy(ws->ev_order);
     if (ws->owns_stream) (void)hipStreamDestroy(ws->stream);
     delete ws;
+}
+
+int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
+{
+    if (!ws) return BTBA_EINVAL;
+    btba_workspace::Tuning &t = ws->tune;
+    switch (option) {
+    case BTBA_OPT_DENSE_ORDER: t.dense_order = value != 0; ws->dense_pairs_frames = -1; break;      // the work table is rebuilt
+    case BTBA_OPT_TILE_MAJOR: t.tile_major = value != 0; break;
+    case BTBA_OPT_BLOCK_WALK: t.block_walk = value != 0; break;
+    case BTBA_OPT_BLOCK_SKIP: t.block_skip = value != 0; break;
+    case BTBA_OPT_BIG_ASSEMBLY: t.big_assembly = value != 0; break;
+    case BTBA_OPT_PERSISTENT: t.persistent = value != 0; break;
+    case BTBA_OPT_OVERLAP_GROUPS: if (value < 1 || value > btba_workspace::kMaxGroups) return BTBA_EINVAL; t.overlap_groups = (int)value; break;
+    case BTBA_OPT_OVERLAP_EQUAL_PRIO: t.overlap_equal_prio = value != 0; break;
+    case BTBA_OPT_KEYED_CORR_MIN_BYTES: if (value < 0) return BTBA_EINVAL; t.keyed_corr_min_bytes = (size_t)value; break;
+    default: return BTBA_EINVAL;
+    }
+    return BTBA_OK;
 }
 
 int btba_workspace_sync(btba_workspace *ws)
@@ -391,6 +437,16 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         else for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) { pairs.push_back(i); pairs.push_back(j); }
         for (size_t k = 0; k < pairs.size(); k += 2)
             if (pairs[k] < 0 || pairs[k] >= N || pairs[k + 1] < 0 || pairs[k + 1] >= N || pairs[k] == pairs[k + 1]) return BTBA_EINVAL;
+        if (dense_pairs && Pd_in >= 0) {
+            // an explicit list may name a pair in both directions, but not the same (target, source) twice: the system's diagonal blocks would
+            // count it twice and the one-pass off-diagonal assembly once (the reference's own list never repeats a pair, SolverBundling.cu:17-47)
+            std::vector<char> seen((size_t)N * N, 0);
+            for (size_t k = 0; k < pairs.size(); k += 2) {
+                char &c = seen[(size_t)pairs[k] * N + pairs[k + 1]];
+                if (c) return BTBA_EINVAL;
+                c = 1;
+            }
+        }
     }
     const int Pd = (int)(pairs.size() / 2);
     const bool use_zn = Z.zn != nullptr;
@@ -429,7 +485,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         // pairs sorted by |i - j| put the long workgroups first and the short ones at the end of the launch, where they drain quickly
         std::vector<int32_t> order(Pd);
         for (int q = 0; q < Pd; q++) order[q] = q;
-        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b2) { return std::abs(pairs[2 * a] - pairs[2 * a + 1]) < std::abs(pairs[2 * b2] - pairs[2 * b2 + 1]); });
+        if (ws->tune.dense_order) std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b2) { return std::abs(pairs[2 * a] - pairs[2 * a + 1]) < std::abs(pairs[2 * b2] - pairs[2 * b2 + 1]); });
         while (tab.size() % 4) tab.push_back(0);           // 16-byte entries
         ws->dense_work_offset = tab.size();
         for (int q = 0; q < Pd; q++) { tab.push_back(pairs[2 * order[q]]); tab.push_back(pairs[2 * order[q] + 1]); tab.push_back(order[q]); tab.push_back(0); }
@@ -465,9 +521,9 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;
     D.order_flag = order_flag;
-    if (Pd > 0 && !std::getenv("BTBA_NO_DENSE_ORDER")) { D.dense_work = reinterpret_cast<const int4 *>(ws->dense_pairs.as<int32_t>() + ws->dense_work_offset); D.dense_work_stride = 0; }      // developer A/B: list order
-    D.tile_major = std::getenv("BTBA_PAIR_MAJOR") ? 0 : 1;      // developer A/B only: (pair, band) instead of (band, pair) work order, same bits
-    D.walk_blocks = (Wd % 8 == 0 && Hd % 8 == 0 && !std::getenv("BTBA_NO_BLOCK_WALK")) ? 1 : 0;
+    if (Pd > 0) D.dense_work = reinterpret_cast<const int4 *>(ws->dense_pairs.as<int32_t>() + ws->dense_work_offset);      // work position -> (target, source, pair, -)
+    D.tile_major = ws->tune.tile_major ? 1 : 0;
+    D.walk_blocks = (Wd % 8 == 0 && Hd % 8 == 0 && Wd + Hd <= 1024 && ws->tune.block_walk) ? 1 : 0;
     D.n_gn = prm->n_gn_iters;
     int zn_layout = 0;
     if (use_zn) {
@@ -504,7 +560,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // larger windows: reduce the partials and assemble the system on many workgroups (k_big_reduce, k_big_assemble); the traced solve
     // keeps the single-workgroup path, whose trace records the system.  Worth two extra launches per iteration from ~24 frames on
     // (one workgroup: 90 k of the 140 k cycles of a launch at N = 31 are reduction and assembly; at N = 15 19 k of 45 k, less than the launches)
-    D.pre_assembled = ((a_global || N >= 24) && !trace && !std::getenv("BTBA_NO_BIG_ASSEMBLY")) ? 1 : 0;
+    D.pre_assembled = ((a_global || N >= 24) && !trace && ws->tune.big_assembly) ? 1 : 0;
     if (a_global || D.pre_assembled) { if ((rc = ws->big_A.ensure((size_t)B * (n + 2) * ld * sizeof(float)))) return rc; }      // per instance: A[n][ld], rhs[ld], prec[ld]
     if (D.pre_assembled && D.pairsum_in_lds) { D.pairsum_in_lds = 0; if ((rc = ws->pairsum.ensure((size_t)B * lds_pairs + 16))) return rc; }
     if (lds_bytes > 64 * 1024 || !ws->lds_attr_set) {
@@ -547,19 +603,37 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     }
     if (Z.frame_slot && B != 1) return BTBA_EINVAL;
     D.frame_slot = Z.frame_slot;
-    // block walk of the pinhole sweep: per-block depth ranges for its dead-block test, and the LDS it needs for the list of live blocks
+    // pinhole sweeps (compact cache, zero-skew K): k_pair_setup prepares every (instance, work position) once per iteration -- relative pose,
+    // congruence, slots and, for the block walk, the per-band lists of live blocks from the per-block depth ranges
     size_t blist_bytes = 0;
-    if (D.walk_blocks && zn_layout == 1 && use_dense && !compaction) {
+    const bool pinhole = zn_layout == 1 && use_dense;
+    if (!(pinhole && !compaction)) D.walk_blocks = 0;
+    if (D.walk_blocks) {
         const int bw = Wd / 8, bh = Hd / 8;
-        blist_bytes = 32 + sizeof(uint32_t) * (size_t)((bh + tiles - 1) / tiles) * bw;
-        if (blist_bytes > 16384) { D.walk_blocks = 0; blist_bytes = 0; }        // very large caches: row strips
-        else if (!std::getenv("BTBA_NO_BLOCK_SKIP")) {                          // developer A/B: walk every block
-            if (Z.block_ranges) D.block_ranges = reinterpret_cast<const float2 *>(Z.block_ranges);      // part of the caller's / the pool's frame cache
-            else if (!Z.frame_slot) {                                           // not given: one pass over the frames per solve
-                if ((rc = ws->block_ranges.ensure(sizeof(float2) * (size_t)B * N * bw * bh))) return rc;
-                k_block_ranges<<<dim3((unsigned)((bw * bh + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)(B * N)), kBlock, 0, ws->stream>>>(Wd, Hd, reinterpret_cast<const float4 *>(Z.zn), nullptr, ws->block_ranges.as<float2>());
-                D.block_ranges = ws->block_ranges.as<float2>();
+        const size_t band_blocks = (size_t)((bh + tiles - 1) / tiles) * bw;
+        if (band_blocks > 1024) D.walk_blocks = 0;                               // very large caches: row strips (a band's list is staged by 4 x 256 lanes)
+        else {
+            blist_bytes = 32 + sizeof(uint32_t) * band_blocks;
+            if (ws->tune.block_skip) {                                          // (off: every block is walked)
+                if (Z.block_ranges) D.block_ranges = reinterpret_cast<const float2 *>(Z.block_ranges);      // part of the caller's / the pool's frame cache
+                else if (!Z.frame_slot) {                                       // not given: one pass over the frames per solve
+                    if ((rc = ws->block_ranges.ensure(sizeof(float2) * (size_t)B * N * bw * bh))) return rc;
+                    k_block_ranges<<<dim3((unsigned)((bw * bh + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)(B * N)), kBlock, 0, ws->stream>>>(Wd, Hd, reinterpret_cast<const float4 *>(Z.zn), nullptr, ws->block_ranges.as<float2>());
+                    D.block_ranges = ws->block_ranges.as<float2>();
+                }
             }
+        }
+    }
+    if (pinhole) {
+        if ((rc = ws->dense_desc.ensure(sizeof(DenseDesc) * (size_t)B * Pd))) return rc;
+        D.dense_desc = ws->dense_desc.as<DenseDesc>();
+        if ((rc = ws->item_queue.ensure(sizeof(unsigned) * 256 * btba_workspace::kMaxGroups))) return rc;
+        D.item_queue = ws->item_queue.as<unsigned>();
+        if (D.walk_blocks) {
+            if ((rc = ws->live_counts.ensure(sizeof(int) * (size_t)B * Pd * tiles))) return rc;
+            if ((rc = ws->live_lists.ensure(sizeof(uint32_t) * (size_t)B * Pd * (size_t)((Wd / 8) * (Hd / 8))))) return rc;
+            D.live_counts = ws->live_counts.as<int>();
+            D.live_lists = ws->live_lists.as<uint32_t>();
         }
     }
     // Software pipelining across instances: the batch is split in two halves on two streams, so one half's
@@ -567,15 +641,14 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // half's dense sweep.  Halves never touch each other's data; fork/join events keep the caller's stream
     // ordering.  Small batches run as one piece.
     int n_halves = (B >= 8 && (prm->flags & BTBA_FLAG_OVERLAP)) ? 2 : 1;
-    if (n_halves == 2) if (const char *e = std::getenv("BTBA_GROUPS")) n_halves = std::max(1, std::min({ std::atoi(e), (int)btba_workspace::kMaxGroups, B / 2 }));
+    if (n_halves == 2) n_halves = std::max(1, std::min({ ws->tune.overlap_groups, (int)btba_workspace::kMaxGroups, B / 2 }));
     for (int g = 1; g < n_halves; g++) {
         if (ws->aux_streams[g - 1]) continue;
         // LOWEST priority by default: equal-priority streams with identical kernel sequences were measured to time-share the chip in
         // lockstep; with a priority gap the main group is never held up and the others fill the CUs it leaves idle.
         int prio_least = 0, prio_greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        const char *pe = std::getenv("BTBA_GROUP_PRIO");
-        HIP_TRY(hipStreamCreateWithPriority(&ws->aux_streams[g - 1], hipStreamNonBlocking, (pe && pe[0] == 'e') ? 0 : prio_least));
+        HIP_TRY(hipStreamCreateWithPriority(&ws->aux_streams[g - 1], hipStreamNonBlocking, ws->tune.overlap_equal_prio ? 0 : prio_least));
         HIP_TRY(hipEventCreateWithFlags(&ws->ev_join[g - 1], hipEventDisableTiming));
         if (!ws->ev_fork) HIP_TRY(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
     }
@@ -589,6 +662,12 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         for (int g = 1; g < n_halves; g++) HIP_TRY(hipStreamWaitEvent(ws->aux_streams[g - 1], ws->ev_fork, 0));
     }
     const size_t pairsum_floats = lds_pairs / sizeof(float);
+    int n_resident = 0;                 // workgroups of the fused sweep the device holds at once: BTBA_FUSED_WAVES per SIMD = as many 4-wave workgroups per CU
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, ws->device));
+        n_resident = prop.multiProcessorCount * BTBA_FUSED_WAVES;
+    }
     const size_t lut_bytes = sizeof(float) * (size_t)((Wd + Hd + 3) & ~3) + (zn_layout == 1 ? sizeof(float4) * (size_t)(Wd + Hd) : 0) + blist_bytes;         // coordinate look-up tables of the compact dense sweep (+ its list of live blocks)
     for (int it = 0; it < prm->n_gn_iters; it++) {
         const bool timing_it = timing && (timed_iteration < 0 || timed_iteration == it);
@@ -609,6 +688,11 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             size_t slot;
             SolveDims Dh = D;                                   // the sweeps' view of this half
             if (Dh.block_ranges) Dh.block_ranges += b0 * N * (size_t)((Wd / 8) * (Hd / 8));
+            if (pinhole) {
+                Dh.dense_desc += b0 * (size_t)Pd;
+                if (Dh.live_counts) { Dh.live_counts += b0 * (size_t)Pd * tiles; Dh.live_lists += b0 * (size_t)Pd * (size_t)((Wd / 8) * (Hd / 8)); }
+                Dh.item_queue += 256 * h;
+            }
 #ifdef BTBA_WG_TRACE
             static DevBuf wg_trace_buf;
             const char *wg_trace_file = std::getenv("BTBA_WG_TRACE_FILE");
@@ -620,6 +704,11 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             }
 #endif
             const unsigned n_d = (unsigned)tiles * D.n_dense_pairs * H.nb, n_s = (unsigned)chunks * P * H.nb;
+            if (pinhole) {
+                if ((rc = time_begin(ws, timing_it, 5, &slot, H.st))) return rc;
+                k_pair_setup<<<dim3((unsigned)Pd, (unsigned)H.nb), kBlock, 0, H.st>>>(Dh, T_h, Ti_h, const_cast<DenseDesc *>(Dh.dense_desc), const_cast<int *>(Dh.live_counts), const_cast<uint32_t *>(Dh.live_lists));
+                if ((rc = time_end(ws, slot, H.st))) return rc;
+            }
             // one interleaved launch of both sweeps: the dense workgroups are VALU-bound, the sparse ones stream HBM, and the
             // two fill each other's idle pipes -- measured at c3 (scripts/ab_dense.py, fused vs separate step time):
             // B=1 0.486 / 0.554 ms, B=8 0.871 / 0.950 ms, B=32 2.271 / 2.380 ms
@@ -630,6 +719,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
 #define BTBA_FUSED_ARGS(CACHE) Dh, n_d, n_s, CACHE, reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, corr_h, off_h, sp_h, vl_h, vc_h
                 const int lay = zn_layout ? zn_layout + (compaction ? 2 : 0) : 0;
                 if (lay == 0) k_fused_sweeps<0><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(reinterpret_cast<const float4 *>(campos_h)));
+                else if (lay == 1 && ws->tune.persistent && n_d + n_s > (unsigned)n_resident) {
+                    const FusedArgs fa{ BTBA_FUSED_ARGS(zn_h) };
+                    k_fused_persist<1><<<dim3(n_resident), kBlock, lut_bytes, H.st>>>(fa);
+                }
                 else if (lay == 1) k_fused_sweeps<1><<<dim3(n_d + n_s), kBlock, lut_bytes, H.st>>>(BTBA_FUSED_ARGS(zn_h));
                 else if (lay == 2) k_fused_sweeps<2><<<dim3(n_d + n_s), kBlock, lut_bytes, H.st>>>(BTBA_FUSED_ARGS(zn_h));
                 else if (lay == 3) k_fused_sweeps<3><<<dim3(n_d + n_s), kBlock, lut_bytes, H.st>>>(BTBA_FUSED_ARGS(zn_h));
@@ -706,6 +799,7 @@ int btba_collect_stats(btba_workspace *ws, btba_stats *stats)
             case 2: S.ms_system_solve += ms; S.n_solve_launches++; break;
             case 3: S.ms_solve += ms; break;
             case 4: S.ms_cache += ms; break;
+            case 5: S.ms_pair_setup += ms; S.n_setup_launches++; break;
             default: break;
             }
         }
@@ -714,8 +808,8 @@ int btba_collect_stats(btba_workspace *ws, btba_stats *stats)
     }
     ws->events.clear();
     if (stats) *stats = S;
-    S.ms_dense_sweep = S.ms_sparse_sweep = S.ms_system_solve = S.ms_solve = S.ms_cache = 0.0f;
-    S.n_dense_launches = S.n_sparse_launches = S.n_solve_launches = 0;
+    S.ms_dense_sweep = S.ms_sparse_sweep = S.ms_system_solve = S.ms_solve = S.ms_cache = S.ms_pair_setup = 0.0f;
+    S.n_dense_launches = S.n_sparse_launches = S.n_solve_launches = S.n_setup_launches = 0;
     return BTBA_OK;
 }
 
@@ -886,8 +980,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     // the frames' CURRENT window positions (they shift as the window slides) and checking the new segments' own indices.
     int corr_pairs_uploaded = P;
     // (below 1 MB the whole array crosses PCIe faster than the bookkeeping runs)
-    const char *kc_env = std::getenv("BTBA_KEYED_CORR_MIN_BYTES");        // tests lower the threshold
-    const size_t kc_min = kc_env ? (size_t)std::strtoull(kc_env, nullptr, 10) : ((size_t)1 << 20);
+    const size_t kc_min = ws->tune.keyed_corr_min_bytes;                  // tests lower the threshold (BTBA_OPT_KEYED_CORR_MIN_BYTES)
     bool use_corr_cache = frame_keys != nullptr && trust && ws_in && (prm.flags & BTBA_FLAG_KEYED_CORR) && kept > 0 && (size_t)kept * sizeof(btba_entryj) >= kc_min;
     std::vector<uint32_t> desc;                                 // outlives the asynchronous copy (the call ends with a synchronisation)
     auto upload_inputs = [&]() -> hipError_t {

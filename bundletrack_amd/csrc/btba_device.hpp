@@ -204,6 +204,22 @@ __device__ __forceinline__ float huber_weight(float e, float delta)
     return (float)((double)delta / sq);
 }
 
+// A pointer to data that no kernel launch writes while it reads it (poses, offsets, descriptors of the previous launch), as a CONSTANT
+// address-space pointer: a wave-uniform load through it becomes a scalar load (s_load_dword*) whatever else the kernel stores --
+// inside the persistent sweep the compiler otherwise assumes the previous item's stores may alias and keeps such values in vector registers.
+template <class T> __device__ __forceinline__ const __attribute__((address_space(4))) T *as_const(const T *p) { return (const __attribute__((address_space(4))) T *)p; }
+
+typedef float btba_f4v __attribute__((ext_vector_type(4)));
+typedef int btba_i4v __attribute__((ext_vector_type(4)));
+// 16 aligned bytes through a constant-address-space pointer (the HIP vector classes cannot be copied out of another address space)
+__device__ __forceinline__ float4 ld_const_f4(const void *p) { const btba_f4v v = *as_const(reinterpret_cast<const btba_f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ int4 ld_const_i4(const void *p) { const btba_i4v v = *as_const(reinterpret_cast<const btba_i4v *>(p)); return make_int4(v.x, v.y, v.z, v.w); }
+
+// threadIdx.x through an opaque copy.  Inside the item loop of the persistent sweep (k_fused_persist) everything derived from the thread
+// index is loop-invariant to the compiler, which hoists it all out of the loop and then spills it (52 vector spills); taken through this
+// function at the top of each per-item block, the values live only as long as the item.
+__device__ __forceinline__ unsigned item_tid() { unsigned t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+
 // ---- wave64 reductions on DPP (no LDS, no ds_bpermute) -----------------------------------
 // Butterfly inside each row of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror: every
 // lane of the row ends with the row sum), then row_bcast:15 / row_bcast:31 fold the four rows so
@@ -267,7 +283,7 @@ __device__ __forceinline__ void wave_fold_store(const float (&acc)[NV], float *d
 {
     float q[NV / 4];
     wave_fold_sums<NV>(acc, q);
-    const int lane = threadIdx.x & 63;
+    const int lane = item_tid() & 63;
     if ((lane & 15) == 0) {
 #pragma unroll
         for (int k = 0; k < NV / 4; k++) dst[k + (NV / 4) * (lane >> 4)] = q[k];
@@ -280,10 +296,10 @@ __device__ __forceinline__ void wave_fold_store(const float (&acc)[NV], float *d
 template <int NV, int NWAVES>
 __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float *lds_scratch, float *out)
 {
-    const int wave = threadIdx.x >> 6;
+    const int tid = (int)item_tid(), wave = tid >> 6;
     wave_fold_store<NV>(acc, lds_scratch + wave * NV);
     __syncthreads();
-    for (int k = threadIdx.x; k < NV; k += blockDim.x) {
+    for (int k = tid; k < NV; k += 64 * NWAVES) {
         float s = lds_scratch[k];
 #pragma unroll
         for (int w = 1; w < NWAVES; w++) s += lds_scratch[w * NV + k];

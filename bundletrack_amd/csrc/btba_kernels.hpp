@@ -21,13 +21,8 @@
 // Summation is deterministic (fixed DPP tree inside a wave, fixed order across waves, tiles and
 // pairs); the reference uses float atomics (SURVEY.md section 5 "race detection").
 #pragma once
-// tuning switches of the pinhole dense sweep (A/B builds override them on the command line)
-#ifndef BTBA_AB_BUILD
-#define BTBA_PINHOLE_SGPR_POSE
-#define BTBA_PINHOLE_SGPR_CONST
-#define BTBA_PAIR_ACC
-#define BTBA_RAY_TABLES
-#define BTBA_FUSED_WAVES 6
+#ifndef BTBA_FUSED_WAVES
+#define BTBA_FUSED_WAVES 6      // waves per SIMD the fused sweep is compiled for (80 VGPRs)
 #endif
 #include <type_traits>
 #include <hip/hip_runtime.h>
@@ -75,9 +70,13 @@ struct SolveDims {
 #ifdef BTBA_WG_TRACE
     unsigned long long *wg_trace; // developer build (scripts/wg_trace.py): per workgroup of the fused sweep (start, end) in 100 MHz ticks, hardware id, kind
 #endif
-    const int4 *dense_work;       // fused sweep: work position -> (target, source, dense pair, -), heaviest pairs first (nullptr: list order)
-    int dense_work_stride;        // entries per instance (0: one table for all)
-    const float2 *block_ranges;   // per (cache slot, 8 x 8 block): [min, max] valid depth (k_block_ranges); nullptr: no block is skipped
+    const int4 *dense_work;       // work position q -> (target, source, dense pair, -): the order the sweeps work the pairs off, heaviest first
+    const float2 *block_ranges;   // per (cache slot, 8 x 8 block): [min, max] valid depth (k_block_ranges); nullptr: no block is skipped (read by k_pair_setup)
+    // pinhole sweeps on the compact cache: what k_pair_setup leaves per (instance, work position) for this iterate's poses
+    const struct DenseDesc *dense_desc;
+    const int *live_counts;       // [B][Pd][dense_tiles]: live 8 x 8 blocks of the band
+    unsigned *item_queue;         // [8][32]: item cursors of the persistent fused sweep per (XCD, group), zeroed by k_pair_setup
+    const uint32_t *live_lists;   // [B][Pd][blocks per frame]: their codes (block row << 16 | block column), band t's from block index r0(t) * bw on, ascending
     int tile_major;      // dense work order inside an instance: 1 = (tile, pair) -- all pairs' band t of the images together -- 0 = (pair, tile)
     int *order_flag;     // non-null: the sparse sweep ORs 1 into it when an entry does not belong to the pair of its segment
     // compact (z, nx, ny, nz) frame cache: how a cached pixel maps back to camera space -- the arithmetic of k_build_cache
@@ -104,6 +103,17 @@ __device__ __forceinline__ Mat4 load_mat4(const float *p)
     Mat4 m;
     const float4 *q = reinterpret_cast<const float4 *>(p);
     float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    m.m[0] = a.x; m.m[1] = a.y; m.m[2] = a.z; m.m[3] = a.w;
+    m.m[4] = b.x; m.m[5] = b.y; m.m[6] = b.z; m.m[7] = b.w;
+    m.m[8] = c.x; m.m[9] = c.y; m.m[10] = c.z; m.m[11] = c.w;
+    m.m[12] = d.x; m.m[13] = d.y; m.m[14] = d.z; m.m[15] = d.w;
+    return m;
+}
+// the same through a constant-address-space pointer (wave-uniform address: four s_load_dwordx4)
+__device__ __forceinline__ Mat4 load_mat4_uniform(const float *p)
+{
+    Mat4 m;
+    const float4 a = ld_const_f4(p), b = ld_const_f4(p + 4), c = ld_const_f4(p + 8), d = ld_const_f4(p + 12);
     m.m[0] = a.x; m.m[1] = a.y; m.m[2] = a.z; m.m[3] = a.w;
     m.m[4] = b.x; m.m[5] = b.y; m.m[6] = b.z; m.m[7] = b.w;
     m.m[8] = c.x; m.m[9] = c.y; m.m[10] = c.z; m.m[11] = c.w;
@@ -287,15 +297,16 @@ __global__ void __launch_bounds__(256) k_gather_corr(const uint4 *__restrict__ d
 __device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
                                              const float *__restrict__ T, float *__restrict__ partials, int chunk, int p, int b, float *red)
 {
+    const unsigned tid = item_tid();
     int fi, fj;
     pair_from_index(p, D.n_frames, fi, fj);
-    const uint32_t *off = pair_offsets + (size_t)b * (D.n_pairs + 1);
+    const auto off = as_const(pair_offsets + (size_t)b * (D.n_pairs + 1));
     const uint32_t seg0 = off[p], seg1 = off[p + 1];
     const uint32_t len = seg1 - seg0;
     const uint32_t per = (len + D.sparse_chunks - 1) / D.sparse_chunks;
     const uint32_t lo = seg0 + min(len, per * chunk), hi = seg0 + min(len, per * (chunk + 1));
-    const Mat4 Ti = load_mat4(T + 16 * ((size_t)b * D.n_frames + fi));
-    const Mat4 Tj = load_mat4(T + 16 * ((size_t)b * D.n_frames + fj));
+    const Mat4 Ti = load_mat4_uniform(T + 16 * ((size_t)b * D.n_frames + fi));
+    const Mat4 Tj = load_mat4_uniform(T + 16 * ((size_t)b * D.n_frames + fj));
     const float4 *cb = corr + 2 * (size_t)b * D.corr_stride;
     float acc[kSparseVals];
 #pragma unroll
@@ -332,7 +343,7 @@ __device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *_
         acc[41] += rho * (wjy * wjy + wjz * wjz); acc[42] += rho * (wjx * wjx + wjz * wjz); acc[43] += rho * (wjx * wjx + wjy * wjy);
     };
     // two correspondences per lane per trip: four independent 16-byte loads in flight
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += 2 * kBlock) {
+    for (uint32_t e = lo + tid; e < hi; e += 2 * kBlock) {
         const uint32_t e2 = e + kBlock;
         const bool live2 = e2 < hi;
         const uint32_t e2c = live2 ? e2 : e;
@@ -496,18 +507,19 @@ __device__ __forceinline__ void dense_stage_M(float *red, const float *__restric
 
 __device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *red, float *out)
 {
-    wave_fold_store<kDenseVals>(acc, red + (threadIdx.x >> 6) * kDenseVals);
+    const unsigned tid = item_tid();
+    wave_fold_store<kDenseVals>(acc, red + (tid >> 6) * kDenseVals);
     __syncthreads();
     float *Sp = red + 4 * kDenseVals;                    // the workgroup's camera-frame sums (28) ...
     float *Mt = Sp + kDenseVals + 4;                     // ... and M (36)
-    if (threadIdx.x < kDenseVals) {
-        float s = red[threadIdx.x];
+    if (tid < kDenseVals) {
+        float s = red[tid];
 #pragma unroll
-        for (int w = 1; w < 4; w++) s += red[w * kDenseVals + threadIdx.x];
-        Sp[threadIdx.x] = s;
+        for (int w = 1; w < 4; w++) s += red[w * kDenseVals + tid];
+        Sp[tid] = s;
     }
     __syncthreads();
-    const int idx = (int)threadIdx.x;
+    const int idx = (int)tid;
     if (idx < 21) {
         int r = 0, rem = idx;
         while (rem >= 6 - r) { rem -= 6 - r; r++; }
@@ -775,100 +787,226 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
 __shared__ unsigned long long wg_dbg[4];       // developer build: (end of prologue, end of pixel loop, live blocks) of the workgroup's dense item
 #endif
 struct PinholeCtx {
-    float R[9], t[3];                 // relative pose source camera -> target camera
+    float R[9], t[3];                 // relative pose source camera -> target camera (scalar registers)
     float fx, fy, cx, cy, wm1, hm1, wm2, hm2, w16, normal_thresh, dist2_thresh, wdelta, w_dense, ybase4;
     unsigned row16;                   // bytes per cache row
     unsigned zmin_bits, zrange_bits;  // depth_min < z < depth_max  <=>  bits(z) - (bits(depth_min) + 1) < zrange_bits (unsigned)
 };
 
+// What a pinhole dense workgroup needs that depends on this iterate's poses, per (instance, work position): written once per Gauss-Newton
+// iteration by k_pair_setup, so that a dense workgroup starts with ONE round of loads (descriptor, live-block count and list, all addressed
+// by its own grid position) instead of the chain work table -> poses / block ranges -> hull test -> list that used to take 7.2 of its 39 us
+// (profiles/r02/wg_trace_c3x32_v17.json).  256 bytes.
+struct DenseDesc {
+    float Rt[12];                     // rows of [R | t] of T_target^-1 T_source (mat_mul of the two matrices, as the workgroups used to compute it)
+    int slot_t, slot_s, pair, pad0;   // cache slots of the target / source frame, the dense pair the partial sums belong to
+    float M[36];                      // congruence of the epilogue, from the target frame's pose (dense_stage_M)
+    float pad1[12];
+};
+static_assert(sizeof(DenseDesc) == 256, "DenseDesc is read as 16-byte rows");
+
 __device__ __forceinline__ float lds_f32_at(const float *base, unsigned byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); }
 __device__ __forceinline__ float2 lds_f32x2_at(const float *base, unsigned byte_off) { const char *q = reinterpret_cast<const char *>(base) + byte_off; return make_float2(*reinterpret_cast<const float *>(q), *reinterpret_cast<const float *>(q + 4)); }
 __device__ __forceinline__ float4 gather16(const float4 *base, unsigned byte_off) { return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off); }
-// opaque copies: keep a wave-uniform value in a VGPR (the compiler would otherwise fold it back into an SGPR operand, 4 cycles)
-#ifdef BTBA_PINHOLE_SGPR_CONST
-__device__ __forceinline__ float in_vgpr(float x) { return x; }
-__device__ __forceinline__ unsigned in_vgpr(unsigned x) { return x; }
-#else
-__device__ __forceinline__ float in_vgpr(float x) { asm volatile("" : "+v"(x)); return x; }
-__device__ __forceinline__ unsigned in_vgpr(unsigned x) { asm volatile("" : "+v"(x)); return x; }
-#endif
+// opaque copy: keeps a value in a VGPR the compiler cannot see through
 __device__ __forceinline__ unsigned opaque_vgpr(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 // v_min_f32 as the hardware does it: fminf() makes the compiler canonicalise its operands first (v_max_f32 x, x, x -- a half-rate
 // instruction per operand, repeated in the loop even for loop invariants); the operands here are never signalling NaNs
 __device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float sgpr(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
 
-template <int WALK>     // 0: 64-pixel row strips   1: the source frame's valid-pixel list   2: 8 x 8 pixel blocks per wave (cache width and height multiples of 8)
-__device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const float4 *__restrict__ zn, const int2 ij,
-                                                    const float *__restrict__ T, const float *__restrict__ Tinv,
-                                                    float *__restrict__ partials, int tile, int p, int b, float *red,
-                                                    const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts, float *lut)
+// column / row term of the back-projection of cache column / row e (e >= width: row e - width): K^-1[0][0] x_full(e) + K^-1[0][2] resp.
+// K^-1[1][1] y_full + K^-1[1][2] -- the cache builder's nearest-neighbour source coordinate, zn_backproject<true>'s bracket
+__device__ __forceinline__ float pinhole_lut_entry(const SolveDims &D, int e)
 {
-    // lut[0 .. Wd) = K^-1[0][0] x_full(x) + K^-1[0][2] per cache column, lut[Wd .. Wd+Hd) the same for rows (as dense_block_zn<true>)
-    for (int e = (int)threadIdx.x; e < D.width + D.height; e += kBlock) {
-        const bool is_x = e < D.width;
-        const float c = (float)(is_x ? zn_src_coord(e, D.zn_scale_w) : zn_src_coord(e - D.width, D.zn_scale_h));
-        lut[e] = is_x ? D.zn_ki[0] * c + D.zn_ki[2] : D.zn_ki[5] * c + D.zn_ki[6];
+    const bool is_x = e < D.width;
+    const float c = (float)(is_x ? zn_src_coord(e, D.zn_scale_w) : zn_src_coord(e - D.width, D.zn_scale_h));
+    return is_x ? D.zn_ki[0] * c + D.zn_ki[2] : D.zn_ki[5] * c + D.zn_ki[6];
+}
+
+// Is the 8 x 8 block (bxl, byg) of the source frame PROVABLY without a pixel that lands in the target image?  A block's pixels with a
+// usable depth lie in the frustum segment spanned by the block's extreme rays and its depth range [zlo, zhi] (k_block_ranges, clipped to
+// depth_min .. depth_max); the relative pose maps the segment to a convex polytope whose vertices are the 8 transformed corners, and while
+// every corner has q.z > 0 the projection (u, v) of any point inside lies within the corners' [min, max] in u and in v (a ratio of affine
+// functions is quasi-linear on a convex set where the denominator is positive).  If that range misses the image by more than a margin --
+// 0.01 pixel, three orders of magnitude above the rounding differences between this evaluation and the per-pixel one -- no pixel of the
+// block can pass the in-image test of SolverBundlingDenseUtil.h:91-94 and the block contributes exactly nothing, as in the reference.
+// Blocks without any usable depth go the same way.  (lut: the pinhole_lut_entry table; R, t: the relative pose.)
+__device__ __forceinline__ bool block_is_live(const SolveDims &D, const float *lut, const float (&R)[9], const float (&t)[3], float2 zr, int bxl, int byg)
+{
+    zr.x = fmaxf(zr.x, D.depth_min); zr.y = fminf(zr.y, D.depth_max);      // usable depths: depth_min < z < depth_max
+    bool live = zr.x <= zr.y;
+    if (live) {
+        const float xa = lut[8 * bxl], xb = lut[8 * bxl + 7], ya = lut[D.width + 8 * byg], yb = lut[D.width + 8 * byg + 7];
+        float ulo = INFINITY, uhi = -INFINITY, vlo = INFINITY, vhi = -INFINITY, zq = INFINITY;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float x = (k & 1) ? xb : xa, y = (k & 2) ? yb : ya;
+            const float rx = R[0] * x + R[1] * y + R[2], ry = R[3] * x + R[4] * y + R[5], rz = R[6] * x + R[7] * y + R[8];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float d = e ? zr.y : zr.x;
+                const float qx = rx * d + t[0], qy = ry * d + t[1], qz = rz * d + t[2];
+                const float rq = fast_rcp(qz);
+                const float u = qx * D.fx * rq + D.cx, v = qy * D.fy * rq + D.cy;
+                ulo = fminf(ulo, u); uhi = fmaxf(uhi, u); vlo = fminf(vlo, v); vhi = fmaxf(vhi, v); zq = fminf(zq, qz);
+            }
+        }
+        const float m = 0.01f;
+        const bool outside = (uhi < -0.5f - m) | (ulo > (float)D.width - 0.5f + m) | (vhi < -0.5f - m) | (vlo > (float)D.height - 0.5f + m);
+        live = !(zq > 1e-3f && outside);          // NaN anywhere: comparisons false, the block stays
     }
-    __syncthreads();
-    const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
+    return live;
+}
+
+// ---- k_pair_setup: once per Gauss-Newton iteration, grid (Pd, B) x 256 -----------------------------------------------------------
+// Workgroup (q, b) prepares work position q of instance b for the pinhole sweeps: the relative pose, the epilogue's congruence M, the
+// frames' cache slots, and -- for the block walk -- per band of block rows the ordered list of the blocks that are not provably dead
+// (block_is_live; ballot + mbcnt compaction in block order, fixed, as the dense workgroups used to build it for themselves in LDS).
+__global__ void __launch_bounds__(kBlock) k_pair_setup(SolveDims D, const float *__restrict__ T, const float *__restrict__ Tinv,
+                                                      DenseDesc *__restrict__ desc, int *__restrict__ live_counts, uint32_t *__restrict__ live_lists)
+{
+    __shared__ float lut[1024];                    // width + height <= 1024 (checked by the host)
+    __shared__ int hdr[8];
+    const int q = blockIdx.x, b = blockIdx.y;
+    if (D.item_queue && q == 0 && b == 0) D.item_queue[threadIdx.x] = 0u;      // the persistent sweep's item cursors: 8 XCDs x 32 groups = kBlock words
+    const int4 w = D.dense_work[q];
+    const int fi = w.x, fj = w.y;                  // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
-    dense_stage_M(red, T + 16 * (fb + fi));
+    if (D.walk_blocks) for (int e = (int)threadIdx.x; e < D.width + D.height; e += kBlock) lut[e] = pinhole_lut_entry(D, e);
     const Mat4 Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), load_mat4(T + 16 * (fb + fj)));
-    PinholeCtx C;
+    const int slot_t = (int)frame_slot_of(D, fb + fi), slot_s = (int)frame_slot_of(D, fb + fj);
+    DenseDesc *o = desc + ((size_t)b * D.n_dense_pairs + q);
+    if (threadIdx.x < 12) o->Rt[threadIdx.x] = Tij.m[threadIdx.x];
+    if (threadIdx.x == 12) { o->slot_t = slot_t; o->slot_s = slot_s; o->pair = w.z; o->pad0 = 0; }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 36) {
+        const float *T_target = T + 16 * (fb + fi);
+        const int e = (int)threadIdx.x - 64, r = e / 6, c = e % 6;
+        float v;
+        if (r < 3) v = (c < 3) ? T_target[4 * r + c] : 0.0f;
+        else {
+            const int qq = r - 3, qa = (qq + 1) % 3, qb = (qq + 2) % 3;     // ([t]x R)[q][c] = t[qa] R[qb][c] - t[qb] R[qa][c]
+            v = (c < 3) ? T_target[4 * qa + 3] * T_target[4 * qb + c] - T_target[4 * qb + 3] * T_target[4 * qa + c] : T_target[4 * qq + (c - 3)];
+        }
+        o->M[e] = v;
+    }
+    if (!D.walk_blocks) return;
+    float R[9], t[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
 #pragma unroll
-#ifdef BTBA_PINHOLE_SGPR_POSE
-        for (int c = 0; c < 3; c++) C.R[3 * r + c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Tij.m[4 * r + c])));
-        C.t[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Tij.m[4 * r + 3])));
-#else
-        for (int c = 0; c < 3; c++) C.R[3 * r + c] = in_vgpr(Tij.m[4 * r + c]);
-        C.t[r] = in_vgpr(Tij.m[4 * r + 3]);
-#endif
+        for (int c = 0; c < 3; c++) R[3 * r + c] = sgpr(Tij.m[4 * r + c]);
+        t[r] = sgpr(Tij.m[4 * r + 3]);
     }
-    C.fx = in_vgpr(D.fx); C.fy = in_vgpr(D.fy); C.cx = in_vgpr(D.cx); C.cy = in_vgpr(D.cy);
+    __syncthreads();
+    const int bw = D.width >> 3, bh = D.height >> 3;
+    const int rows_per = (bh + D.dense_tiles - 1) / D.dense_tiles;
+    const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const float2 *rng = D.block_ranges ? D.block_ranges + (size_t)slot_s * (size_t)(bw * bh) : nullptr;
+    uint32_t *list = live_lists + ((size_t)b * D.n_dense_pairs + q) * (size_t)(bw * bh);
+    for (int tile = 0; tile < D.dense_tiles; tile++) {
+        const int r0 = min(bh, rows_per * tile), r1 = min(bh, rows_per * (tile + 1));
+        const int nb = (r1 - r0) * bw;
+        int n_live = 0;
+        for (int c0 = 0; c0 < nb; c0 += kBlock) {
+            const int idx = c0 + (int)threadIdx.x;
+            bool live = false;
+            unsigned code = 0;
+            if (idx < nb) {
+                const int byl = idx / bw, bxl = idx - byl * bw, byg = r0 + byl;
+                code = ((unsigned)byg << 16) | (unsigned)bxl;
+                live = rng ? block_is_live(D, lut, R, t, rng[byg * bw + bxl], bxl, byg) : true;
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(live);
+            if (lane == 0) hdr[wave] = __popcll(bal);
+            __syncthreads();
+            int base = n_live, total = 0;
+#pragma unroll
+            for (int wv = 0; wv < kBlock / 64; wv++) { const int tt = hdr[wv]; if (wv < wave) base += tt; total += tt; }
+            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+            if (live) list[r0 * bw + base + before] = code;
+            n_live += total;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) live_counts[((size_t)b * D.n_dense_pairs + q) * D.dense_tiles + tile] = n_live;
+    }
+}
+
+// ---- the dense sweep for pinhole intrinsics on the GATED compact cache --------------------------------------------
+// (the arithmetic per accepted pixel is dense_block_zn<true, .>'s; the shape is what the VALU of gfx950 charges for, see above)
+template <int WALK>     // 0: 64-pixel row strips   1: the source frame's valid-pixel list   2: 8 x 8 pixel blocks per wave (cache width and height multiples of 8)
+__device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const float4 *__restrict__ zn, int q,
+                                                    float *__restrict__ partials, int tile, int b, float *red,
+                                                    const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts, float *lut)
+{
+    const unsigned tid = item_tid();
+    // ONE round of loads, every address a function of the workgroup's grid position: this item's descriptor (relative pose, slots, pair, M),
+    // and for the block walk the band's live-block count and list
+    const size_t item = (size_t)b * D.n_dense_pairs + q;
+    const DenseDesc *dd = D.dense_desc + item;
+    const float4 d0 = ld_const_f4(dd->Rt), d1 = ld_const_f4(dd->Rt + 4), d2 = ld_const_f4(dd->Rt + 8);
+    const int4 di = ld_const_i4(&dd->slot_t);
+    float m_stage = 0.0f;
+    if (tid >= 64 && tid < 64 + 36) m_stage = dd->M[tid - 64];
+    const int bw = D.width >> 3, bh = D.height >> 3;
+    const int rows_per = (bh + D.dense_tiles - 1) / D.dense_tiles;
+    const int r0 = min(bh, rows_per * tile), r1 = min(bh, rows_per * (tile + 1));
+    const int nb = (WALK == 2) ? (r1 - r0) * bw : 0;
+    int n_live = 0;
+    unsigned code_stage[4] = { 0u, 0u, 0u, 0u };            // up to 1 024 blocks per band (the host keeps the band's list within the LDS it reserves)
+    if (WALK == 2) {
+        n_live = as_const(D.live_counts)[item * D.dense_tiles + tile];
+        const uint32_t *list = D.live_lists + item * (size_t)(bw * bh) + (size_t)r0 * bw;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k * kBlock + (int)tid < nb) code_stage[k] = list[k * kBlock + tid];
+    }
+    // tables in LDS: lut[0 .. Wd) = K^-1[0][0] x_full(x) + K^-1[0][2] per cache column, lut[Wd .. Wd+Hd) the same for rows (the taps' back-projection),
+    // and the ROTATED RAYS: the transformed point of source pixel (x, y) with depth d is q = d (R (lx, ly, 1)) + t = d (colA[x] + rowB[y]) + t with
+    // colA[x] = R[:, 0] lx(x), rowB[y] = R[:, 1] ly(y) + R[:, 2] -- two 16-byte LDS reads, 3 adds and 3 FMAs per pixel instead of 2 reads,
+    // 2 multiplies and 12 operations with a scalar-register operand (which issue at half rate, profiles/r02/valu_calibration.md).  One pass, one barrier.
+    PinholeCtx C;
+    C.R[0] = sgpr(d0.x); C.R[1] = sgpr(d0.y); C.R[2] = sgpr(d0.z); C.t[0] = sgpr(d0.w);
+    C.R[3] = sgpr(d1.x); C.R[4] = sgpr(d1.y); C.R[5] = sgpr(d1.z); C.t[1] = sgpr(d1.w);
+    C.R[6] = sgpr(d2.x); C.R[7] = sgpr(d2.y); C.R[8] = sgpr(d2.z); C.t[2] = sgpr(d2.w);
+    float4 *colA = reinterpret_cast<float4 *>(lut + ((D.width + D.height + 3) & ~3));
+    float4 *rowB = colA + D.width;
+    for (int e = (int)tid; e < D.width + D.height; e += kBlock) {
+        const float l = pinhole_lut_entry(D, e);
+        lut[e] = l;
+        if (e < D.width) colA[e] = make_float4(C.R[0] * l, C.R[3] * l, C.R[6] * l, 0.0f);
+        else rowB[e - D.width] = make_float4(C.R[1] * l + C.R[2], C.R[4] * l + C.R[5], C.R[7] * l + C.R[8], 0.0f);
+    }
+    if (tid >= 64 && tid < 64 + 36) red[4 * kDenseVals + kDenseVals + 4 + ((int)tid - 64)] = m_stage;      // M of the epilogue
+    int *hdr = reinterpret_cast<int *>(rowB + D.height);
+    unsigned *blist = reinterpret_cast<unsigned *>(hdr + 8);
+    if (WALK == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k * kBlock + (int)tid < nb) blist[k * kBlock + tid] = code_stage[k];
+    }
+    __syncthreads();
+    C.fx = D.fx; C.fy = D.fy; C.cx = D.cx; C.cy = D.cy;
     C.wm1 = (float)(D.width - 1); C.hm1 = (float)(D.height - 1); C.wm2 = (float)(D.width - 2); C.hm2 = (float)(D.height - 2);
-    C.w16 = in_vgpr(16.0f * (float)D.width); C.row16 = in_vgpr(16u * (unsigned)D.width);
-    C.ybase4 = in_vgpr(4.0f * (float)D.width);            // LDS byte offset of the row table
+    C.w16 = 16.0f * (float)D.width; C.row16 = 16u * (unsigned)D.width;
+    C.ybase4 = 4.0f * (float)D.width;                     // LDS byte offset of the row table
     C.normal_thresh = D.normal_thresh; C.dist2_thresh = D.dist_thresh * D.dist_thresh;
-    C.wdelta = in_vgpr(D.w_dense * D.robust_delta); C.w_dense = in_vgpr(D.w_dense);
-    C.zmin_bits = in_vgpr(__float_as_uint(D.depth_min) + 1u); C.zrange_bits = __float_as_uint(D.depth_max) - __float_as_uint(D.depth_min) - 1u;
-    const size_t slot_t = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fi));
-    const size_t slot_s = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fj));
+    C.wdelta = D.w_dense * D.robust_delta; C.w_dense = D.w_dense;
+    C.zmin_bits = __float_as_uint(D.depth_min) + 1u; C.zrange_bits = __float_as_uint(D.depth_max) - __float_as_uint(D.depth_min) - 1u;
+    const size_t slot_t = (size_t)__builtin_amdgcn_readfirstlane(di.x), slot_s = (size_t)__builtin_amdgcn_readfirstlane(di.y);
+    const int p = __builtin_amdgcn_readfirstlane(di.z);
     const float4 *zn_t = zn + slot_t * (size_t)D.npix, *zn_s = zn + slot_s * (size_t)D.npix;
     constexpr bool LISTS = (WALK == 1);
     float acc[kDenseVals];
 #pragma unroll
     for (int k = 0; k < kDenseVals; k++) acc[k] = 0.0f;
-#ifdef BTBA_RAY_TABLES
-    // Rotated rays: the transformed point of source pixel (x, y) with depth d is q = d (R (lx, ly, 1)) + t = d (colA[x] + rowB[y]) + t with
-    // colA[x] = R[:, 0] lx(x), rowB[y] = R[:, 1] ly(y) + R[:, 2] -- two 16-byte LDS reads, 3 adds and 3 FMAs per pixel instead of 2 reads,
-    // 2 multiplies and 12 operations with a scalar-register operand (which issue at half rate, profiles/r02/valu_calibration.md).
-    float4 *colA = reinterpret_cast<float4 *>(lut + ((D.width + D.height + 3) & ~3));
-    float4 *rowB = colA + D.width;
-    for (int e = (int)threadIdx.x; e < D.width + D.height; e += kBlock) {
-        const float l = lut[e];
-        if (e < D.width) colA[e] = make_float4(C.R[0] * l, C.R[3] * l, C.R[6] * l, 0.0f);
-        else rowB[e - D.width] = make_float4(C.R[1] * l + C.R[2], C.R[4] * l + C.R[5], C.R[7] * l + C.R[8], 0.0f);
-    }
-    if (WALK != 2) __syncthreads();           // (the block walk's pre-pass has barriers of its own before the first pixel)
-#endif
 
-    // one source pixel: zs = its (gated depth, normal), ox / oy = LDS byte offsets of its column / row terms (ray tables: of its 16-byte entries, from colA)
+    // one source pixel: zs = its (gated depth, normal), ox / oy = LDS byte offsets of its column / row entries in the ray tables (from colA)
     auto pixel = [&](const float4 &zs, unsigned ox, unsigned oy) {
         // source pixel -> camera space (gated depth: 0 where invalid), depth-range test on the bit pattern
         const float d = zs.x;
         const bool src_ok = (__float_as_uint(d) - C.zmin_bits) < C.zrange_bits;
         // transform the point, project
-#ifdef BTBA_RAY_TABLES
         const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(colA) + ox), rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(colA) + oy);
         const float qx = (ra.x + rb.x) * d + C.t[0], qy = (ra.y + rb.y) * d + C.t[1], qz = (ra.z + rb.z) * d + C.t[2];
-#else
-        const float sx = lds_f32_at(lut, ox) * d, sy = lds_f32_at(lut, oy) * d;
-        const float qx = C.R[0] * sx + C.R[1] * sy + C.R[2] * d + C.t[0];
-        const float qy = C.R[3] * sx + C.R[4] * sy + C.R[5] * d + C.t[1];
-        const float qz = C.R[6] * sx + C.R[7] * sy + C.R[8] * d + C.t[2];
-#endif
         const float rqz = fast_rcp(qz);
         const float u = qx * C.fx * rqz + C.cx, v = qy * C.fy * rqz + C.cy;
         const float uc = __builtin_amdgcn_fmed3f(u, 0.0f, C.wm1), vc = __builtin_amdgcn_fmed3f(v, 0.0f, C.hm1);      // NaN -> 0: addresses stay in the frame
@@ -909,7 +1047,6 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const float mx = masked(nix), my = masked(niy), mz = masked(niz);
         const float a[6] = { -mx, -my, -mz, my * qz - mz * qy, mz * qx - mx * qz, mx * qy - my * qx };
         int k = 0;
-#ifdef BTBA_PAIR_ACC
         // acc += wa_r * a_c is a read-modify-write FMA: it issues at full rate only when its two multiplicands sit in VGPRs of
         // different parity (profiles/r02/valu_calibration.md).  (wa_r, a_r) held as an aligned register PAIR puts every wa in an
         // even and every a in an odd register, whatever the allocator does with the rest.
@@ -925,103 +1062,23 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
             for (int c = r; c < 6; c++) acc[k++] += pr[r].x * pr[c].y;
             acc[21 + r] += pr[r].x * rr.y;
         }
-#else
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-            const float wa = wgt * a[r];
-#pragma unroll
-            for (int c = r; c < 6; c++) acc[k++] += wa * a[c];
-            acc[21 + r] += wa * res;
-        }
-#endif
         acc[27] += masked(1.0f);
     };
 
     if (WALK == 2) {
         // Waves walk 8 x 8 pixel blocks of this band of block rows; lane = (row, column) inside the block.  The region of a source
         // frame that projects into the target is a compact blob, so whole blocks fall outside it (51 % of them at c3; 64 x 1 strips:
-        // 31 %), and a block's taps land in a compact patch of the target.
-        //
-        // Dead blocks are removed BEFORE the walk where that can be PROVEN: a block's pixels with a usable depth lie in the frustum
-        // segment spanned by the block's extreme rays and its depth range [zlo, zhi] (k_block_ranges); the relative pose maps the
-        // segment to a convex polytope whose vertices are the 8 transformed corners, and while every corner has q.z > 0 the
-        // projection (u, v) of any point inside lies within the corners' [min, max] in u and in v (a ratio of affine functions is
-        // quasi-linear on a convex set where the denominator is positive).  If that range misses the image by more than a margin
-        // -- 0.01 pixel, three orders of magnitude above the rounding differences between this evaluation and the per-pixel one --
-        // no pixel of the block can pass the in-image test, and the block contributes exactly nothing, as in the reference
-        // (SolverBundlingDenseUtil.h:91-94).  Blocks without any usable depth go the same way.  90 % of the dead blocks are proven
-        // dead at c3; the live ones are compacted into an ordered list in LDS (deterministic) that the four waves share round-robin.
-        const int bw = D.width >> 3, bh = D.height >> 3;
-        const int rows_per = (bh + D.dense_tiles - 1) / D.dense_tiles;
-        const int r0 = min(bh, rows_per * tile), r1 = min(bh, rows_per * (tile + 1));
-        const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-#ifdef BTBA_RAY_TABLES
-        int *hdr = reinterpret_cast<int *>(rowB + D.height);                // [0 .. 4) wave totals, [4] running total
-#else
-        int *hdr = reinterpret_cast<int *>(lut + D.width + D.height);       // [0 .. 4) wave totals, [4] running total
-#endif
-        unsigned *blist = reinterpret_cast<unsigned *>(hdr + 8);
-        const int nb = (r1 - r0) * bw;
-        const float2 *rng = D.block_ranges ? D.block_ranges + slot_s * (size_t)(bw * bh) : nullptr;
-        int n_live = 0;
-        for (int c0 = 0; c0 < nb; c0 += kBlock) {
-            const int idx = c0 + (int)threadIdx.x;
-            bool live = false;
-            unsigned code = 0;
-            if (idx < nb) {
-                const int byl = idx / bw, bxl = idx - byl * bw, byg = r0 + byl;
-                code = ((unsigned)byg << 16) | (unsigned)bxl;
-                live = true;
-                if (rng) {
-                    float2 zr = rng[byg * bw + bxl];
-                    zr.x = fmaxf(zr.x, D.depth_min); zr.y = fminf(zr.y, D.depth_max);      // usable depths: depth_min < z < depth_max
-                    live = zr.x <= zr.y;
-                    if (live) {
-                        const float xa = lut[8 * bxl], xb = lut[8 * bxl + 7], ya = lut[D.width + 8 * byg], yb = lut[D.width + 8 * byg + 7];
-                        float ulo = INFINITY, uhi = -INFINITY, vlo = INFINITY, vhi = -INFINITY, zq = INFINITY;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const float x = (k & 1) ? xb : xa, y = (k & 2) ? yb : ya;
-                            const float rx = C.R[0] * x + C.R[1] * y + C.R[2], ry = C.R[3] * x + C.R[4] * y + C.R[5], rz = C.R[6] * x + C.R[7] * y + C.R[8];
-#pragma unroll
-                            for (int e = 0; e < 2; e++) {
-                                const float d = e ? zr.y : zr.x;
-                                const float qx = rx * d + C.t[0], qy = ry * d + C.t[1], qz = rz * d + C.t[2];
-                                const float rq = fast_rcp(qz);
-                                const float u = qx * D.fx * rq + D.cx, v = qy * D.fy * rq + D.cy;
-                                ulo = fminf(ulo, u); uhi = fmaxf(uhi, u); vlo = fminf(vlo, v); vhi = fmaxf(vhi, v); zq = fminf(zq, qz);
-                            }
-                        }
-                        const float m = 0.01f;
-                        const bool outside = (uhi < -0.5f - m) | (ulo > (float)D.width - 0.5f + m) | (vhi < -0.5f - m) | (vlo > (float)D.height - 0.5f + m);
-                        live = !(zq > 1e-3f && outside);          // NaN anywhere: comparisons false, the block stays
-                    }
-                }
-            }
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(live);
-            if (lane == 0) hdr[wave] = __popcll(bal);
-            __syncthreads();
-            int base = n_live, total = 0;
-#pragma unroll
-            for (int w = 0; w < kBlock / 64; w++) { const int t = hdr[w]; if (w < wave) base += t; total += t; }
-            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-            if (live) blist[base + before] = code;
-            n_live += total;
-            __syncthreads();
-        }
+        // 31 %), and a block's taps land in a compact patch of the target.  Blocks that are provably dead (block_is_live, k_pair_setup:
+        // 90 % of the dead ones at c3) are not in the list; the four waves share the list round-robin.
+        const int lane = (int)tid & 63, wave = __builtin_amdgcn_readfirstlane((int)tid >> 6);
         n_live = __builtin_amdgcn_readfirstlane(n_live);
 #ifdef BTBA_WG_TRACE
-        if (threadIdx.x == 0) { wg_dbg[0] = wall_clock64(); wg_dbg[2] = (unsigned long long)n_live; }
+        if (tid == 0) { wg_dbg[0] = wall_clock64(); wg_dbg[2] = (unsigned long long)n_live; }
 #endif
         const unsigned lx = (unsigned)lane & 7u, ly = (unsigned)lane >> 3;
         const unsigned lane_px = ly * (unsigned)D.width + lx;          // pixel offset of the lane inside its block
-#ifdef BTBA_RAY_TABLES
         const unsigned ox_l = 16u * lx, oy_l = 16u * ly + 16u * (unsigned)D.width;
         constexpr unsigned kBlockStep = 128u;            // 8 entries of 16 bytes
-#else
-        const unsigned ox_l = 4u * lx, oy_l = 4u * ly + 4u * (unsigned)D.width;
-        constexpr unsigned kBlockStep = 32u;
-#endif
         // this wave's current and next block (scalar registers), the next block's pixels in flight while the current one is worked on
         int k = wave;
         unsigned code_n = (k < n_live) ? (unsigned)__builtin_amdgcn_readfirstlane((int)blist[k]) : 0u;
@@ -1038,7 +1095,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
             pixel(zs, ox_l + kBlockStep * (code & 0xFFFFu), oy_l + kBlockStep * (code >> 16));
         }
 #ifdef BTBA_WG_TRACE
-        if (threadIdx.x == 0) wg_dbg[1] = wall_clock64();
+        if (tid == 0) wg_dbg[1] = wall_clock64();
 #endif
     } else {
         const int n_src = LISTS ? valid_counts[slot_s] : D.npix;
@@ -1046,13 +1103,13 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const int per = (n_src + D.dense_tiles - 1) / D.dense_tiles;
         const int lo = min(n_src, per * tile), hi = min(n_src, per * (tile + 1));
         const float inv_w = 1.0f / (float)D.width;
-        int t = lo + (int)threadIdx.x;
+        int t = lo + (int)tid;
         int s_n = (t < hi) ? (LISTS ? (int)list[t] : t) : 0;
         // direct walk: LDS byte offsets of the pixel's column / row entries (row table behind the column table), advanced by
         // one workgroup stride per trip
         const unsigned w4 = 4u * (unsigned)D.width;
         unsigned px4 = 4u * (unsigned)(s_n % D.width), py4 = 4u * (unsigned)(s_n / D.width) + w4;
-        const unsigned step_x4 = in_vgpr(4u * (unsigned)(kBlock % D.width)), step_y4 = in_vgpr(4u * (unsigned)(kBlock / D.width));
+        const unsigned step_x4 = 4u * (unsigned)(kBlock % D.width), step_y4 = 4u * (unsigned)(kBlock / D.width);
         float4 zs_n = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < hi) zs_n = zn_s[s_n];
         for (; t < hi; t += kBlock) {
@@ -1069,11 +1126,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
                 const float pyf = floorf((sf + 0.5f) * inv_w);              // exact: the margin 0.5 / W is far above the rounding of the product
                 ox = (unsigned)(4.0f * (sf - pyf * (float)D.width)); oy = (unsigned)(4.0f * pyf + C.ybase4);
             }
-#ifdef BTBA_RAY_TABLES
             pixel(zs, 4u * ox, 4u * oy);                  // 4-byte table offsets -> 16-byte entries (rowB follows colA as the row table follows the column table)
-#else
-            pixel(zs, ox, oy);
-#endif
         }
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
@@ -1091,10 +1144,10 @@ __global__ void __launch_bounds__(kBlock, 5) k_dense_sweep_zn(SolveDims D, const
     const int tile = (int)(L % (unsigned)D.dense_tiles);
     const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
     const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
-    // pinhole intrinsics: the same block as in the fused launch (same partial sums, bit for bit)
-    if (SIMPLE && LISTS) dense_block_pinhole<1>(D, zn, dense_pairs[p], T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
-    else if (SIMPLE && D.walk_blocks) dense_block_pinhole<2>(D, zn, dense_pairs[p], T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
-    else if (SIMPLE) dense_block_pinhole<0>(D, zn, dense_pairs[p], T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+    // pinhole intrinsics: the same block as in the fused launch (same partial sums, bit for bit); `p` is then a WORK POSITION (k_pair_setup)
+    if (SIMPLE && LISTS) dense_block_pinhole<1>(D, zn, p, partials, tile, b, red, valid_lists, valid_counts, zn_lut);
+    else if (SIMPLE && D.walk_blocks) dense_block_pinhole<2>(D, zn, p, partials, tile, b, red, valid_lists, valid_counts, zn_lut);
+    else if (SIMPLE) dense_block_pinhole<0>(D, zn, p, partials, tile, b, red, valid_lists, valid_counts, zn_lut);
     else dense_block_zn<false, LISTS>(D, zn, dense_pairs[p], T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
 }
 
@@ -1150,17 +1203,20 @@ __device__ __forceinline__ void fused_item(const SolveDims &D, unsigned n_d, uns
         const unsigned Lb = L - (unsigned)b * (unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs;
         const int tile = D.tile_major ? (int)(Lb / (unsigned)D.n_dense_pairs) : (int)(Lb % (unsigned)D.dense_tiles);
         int p = D.tile_major ? (int)(Lb % (unsigned)D.n_dense_pairs) : (int)(Lb / (unsigned)D.dense_tiles);
-        // work order: the pairs of a band heaviest first, so that the workgroups still running when the launch drains are short ones;
-        // a work-table entry is (target, source, pair, -): one load instead of order -> pair list
-        int2 ij;
-        if (D.dense_work) { const int4 w = D.dense_work[(size_t)b * D.dense_work_stride + p]; ij = make_int2(w.x, w.y); p = w.z; }
-        else ij = dense_pairs[p];
-        if (LAYOUT == 0) dense_block(D, campos, normals, ij, T, Tinv, dense_partials, tile, p, b, red);
-        else if (LAYOUT == 1 && D.walk_blocks) dense_block_pinhole<2>(D, campos, ij, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
-        else if (LAYOUT == 1) dense_block_pinhole<0>(D, campos, ij, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);     // `campos` carries the compact cache
-        else if (LAYOUT == 2) dense_block_zn<false, false>(D, campos, ij, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
-        else if (LAYOUT == 3) dense_block_pinhole<1>(D, campos, ij, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
-        else dense_block_zn<false, true>(D, campos, ij, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+        // work order: the pairs of a band heaviest first, so that the workgroups still running when the launch drains are short ones.
+        // p is a WORK POSITION: the pinhole blocks find everything about it in k_pair_setup's descriptor; the other layouts read the
+        // work table entry (target, source, pair, -) themselves
+        if (LAYOUT == 1 && D.walk_blocks) dense_block_pinhole<2>(D, campos, p, dense_partials, tile, b, red, valid_lists, valid_counts, zn_lut);
+        else if (LAYOUT == 1) dense_block_pinhole<0>(D, campos, p, dense_partials, tile, b, red, valid_lists, valid_counts, zn_lut);     // `campos` carries the compact cache
+        else if (LAYOUT == 3) dense_block_pinhole<1>(D, campos, p, dense_partials, tile, b, red, valid_lists, valid_counts, zn_lut);
+        else {
+            const int4 w = D.dense_work[p];
+            const int2 ij = make_int2(w.x, w.y);
+            p = w.z;
+            if (LAYOUT == 0) dense_block(D, campos, normals, ij, T, Tinv, dense_partials, tile, p, b, red);
+            else if (LAYOUT == 2) dense_block_zn<false, false>(D, campos, ij, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+            else dense_block_zn<false, true>(D, campos, ij, T, Tinv, dense_partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
+        }
     }
 #ifdef BTBA_WG_TRACE
     if (D.wg_trace && threadIdx.x == 0) {
@@ -1186,6 +1242,83 @@ __global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_fused_sweeps(Solve
     extern __shared__ __attribute__((aligned(16))) float zn_lut[];        // (Wd + Hd) floats (+ the block walk's list), compact layouts only
     const unsigned g = blockIdx.x;
     fused_item<LAYOUT>(BTBA_FUSED_ITEM_ARGS);
+}
+
+// The same items worked off by PERSISTENT workgroups: as many workgroups as the chip holds at once (6 per CU), each pulling the next item
+// of ITS XCD's sequence (the order and the per-XCD ranges of the one-workgroup-per-item launch: L2 locality unchanged) from atomic
+// cursors.  No slot stays empty between two items (measured: ~3 us per 39-us item while the hardware recycles a workgroup slot), and the
+// launch drains evenly: whoever is free takes the next item.
+// Cursors: ONE cursor per XCD was measured to be the bottleneck itself -- same-address atomics serialise at ~100 ns each, 1 260 items per
+// XCD are 126 us of cursor time in a 200-us launch, and the 192 workgroups of an XCD needed 20 us just to get their first item
+// (gpurun_out/r03_04).  So an XCD's sequence is dealt round-robin to kItemGroups sub-sequences (slot s belongs to group s mod 32) with a
+// cursor each, a workgroup draws from the group it shares with ~5 others and, when that is exhausted, from whichever group still has
+// items (one read of all 32 cursors, then a claim).  The next item is claimed when the current one STARTS and picked up when it ends.
+constexpr unsigned kItemGroups = 32;
+struct FusedArgs {
+    SolveDims D;
+    unsigned n_d, n_s;
+    const float4 *campos, *normals;
+    const int2 *dense_pairs;
+    const float *T, *Tinv;
+    float *dense_partials;
+    const float4 *corr;
+    const uint32_t *pair_offsets;
+    float *sparse_partials;
+    const uint32_t *valid_lists;
+    const int *valid_counts;
+};
+template <int LAYOUT>
+__global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_fused_persist(FusedArgs args_in_kernarg_segment)
+{
+    __shared__ float red[kRedFloats];
+    __shared__ unsigned ctl[2];
+    extern __shared__ __attribute__((aligned(16))) float zn_lut[];
+    typedef const __attribute__((address_space(4))) FusedArgs *ArgPtr;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    const unsigned n_items = ((ArgPtr)__builtin_amdgcn_kernarg_segment_ptr())->n_d + ((ArgPtr)__builtin_amdgcn_kernarg_segment_ptr())->n_s;
+    const unsigned Gx = (n_items - xcc + 7u) >> 3;               // items of this XCD: slots 0 .. Gx-1
+    unsigned *const cursors = ((ArgPtr)__builtin_amdgcn_kernarg_segment_ptr())->D.item_queue + kItemGroups * xcc;
+    // wave 0 does the claiming; `grp` (the group this workgroup draws from) and `pending` (the claim in flight: a position inside that group)
+    // are wave-uniform there
+    unsigned grp = ((blockIdx.x >> 3) / BTBA_FUSED_WAVES) % kItemGroups;
+    unsigned pending = 0;
+    if (threadIdx.x == 0) pending = atomicAdd(&cursors[grp], 1u);
+    for (;;) {
+        ArgPtr A = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(A));                              // opaque: nothing read through A is loop-invariant to the compiler
+        if (threadIdx.x < 64) {
+            const unsigned lane = threadIdx.x;
+            unsigned slot = kItemGroups * (unsigned)__builtin_amdgcn_readfirstlane((int)pending) + grp;
+            if (slot >= Gx) {
+                // own group exhausted: ONE coalesced read of all 32 cursors (lane = group), then a claim from a group that still has items,
+                // searched from a rotation that differs from workgroup to workgroup (so that the thieves do not all descend on the same group)
+                slot = 0xFFFFFFFFu;
+                for (unsigned tries = 0; tries < 8u && slot == 0xFFFFFFFFu; tries++) {
+                    const unsigned c = lane < kItemGroups ? __hip_atomic_load(&cursors[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFu;
+                    const unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(lane < kItemGroups && kItemGroups * c + lane < Gx);
+                    if (mask == 0u) break;                       // every cursor is past its group's last slot
+                    const unsigned rot = (blockIdx.x * 7u + tries * 13u + grp + 1u) % kItemGroups;
+                    const unsigned turned = rot ? (mask >> rot) | (mask << (kItemGroups - rot)) : mask;
+                    grp = (rot + (unsigned)__builtin_ctz(turned)) % kItemGroups;
+                    unsigned got = 0;
+                    if (lane == 0) got = atomicAdd(&cursors[grp], 1u);
+                    const unsigned s2 = kItemGroups * (unsigned)__builtin_amdgcn_readfirstlane((int)got) + grp;
+                    if (s2 < Gx) slot = s2;
+                }
+            }
+            if (lane == 0) ctl[0] = slot;
+        }
+        __syncthreads();
+        const unsigned slot = ctl[0];
+        if (slot == 0xFFFFFFFFu) break;                          // this XCD's items are done
+        if (threadIdx.x == 0) pending = atomicAdd(&cursors[grp], 1u);
+        const unsigned g = 8u * slot + xcc;
+        fused_item<LAYOUT>(*(const SolveDims *)&A->D, A->n_d, A->n_s, g, A->campos, A->normals, A->dense_pairs, A->T, A->Tinv, A->dense_partials,
+                           A->corr, A->pair_offsets, A->sparse_partials, A->valid_lists, A->valid_counts, red, zn_lut);
+        __syncthreads();                                      // the item's LDS (red, tables, ctl) is free again
+    }
 }
 #undef BTBA_FUSED_ITEM_ARGS
 

@@ -45,6 +45,10 @@ class Workspace:
     def sync(self):
         check(lib().btba_workspace_sync(self._h), "btba_workspace_sync")
 
+    def set_option(self, option: int, value: int):
+        """Developer / tuning switch of this workspace (_lib.OPT_*, include/btba.h BTBA_OPT_*): schedules and equivalent code paths only."""
+        check(lib().btba_workspace_set_option(self._h, int(option), int(value)), "btba_workspace_set_option")
+
     def wait_stream(self, stream: int | None):
         """Work enqueued on the workspace after this call waits (on the device) for what `stream` (a raw HIP stream handle,
         None = the default stream) holds now: inputs produced on another stream."""

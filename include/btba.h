@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BTBA_VERSION 100
+#define BTBA_VERSION 103     /* 103: btba_params.reduction_mode, btba_stats.ms_pair_setup / n_setup_launches, BTBA_FLAG_KEYED_CORR = 4096, btba_workspace_set_option */
 
 #if defined(__GNUC__)
 #define BTBA_API __attribute__((visibility("default")))
@@ -80,7 +80,8 @@ enum {
                                        overlaps the other half's sweeps; per-kernel timings then overlap too (+4 % at c3 x 32) */
     BTBA_FLAG_NO_FUSE       = 64,   /* launch the sparse and the dense sweep separately (default: ONE interleaved launch) */
     BTBA_FLAG_FLOAT4_CACHE  = 256,  /* btba_optimize_frames: build the reference-layout float4 cache instead of the compact one */
-    BTBA_FLAG_KEYED_CORR    = 128,  /* btba_optimize_frames_keyed: keep every frame PAIR's correspondence segment on the device under the
+    /* 128: reserved.  It was BTBA_FLAG_FUSE ("accepted for compatibility") up to version 100 and must not acquire a meaning: ignored. */
+    BTBA_FLAG_KEYED_CORR    = 4096, /* btba_optimize_frames_keyed: keep every frame PAIR's correspondence segment on the device under the
                                        pair's two frame keys and upload only segments not seen before (in a sliding window: the new
                                        frame's n_frames - 1 pairs).  CONTRACT: the correspondences of a pair do not change while both
                                        frames stay cached -- the reference never recomputes a pair's matches either (findCorres returns
@@ -140,6 +141,8 @@ typedef struct btba_stats {
     int32_t fused_sweeps;         /* 1: sparse + dense sweeps ran as ONE launch (timed as ms_dense_sweep) */
     int32_t cache_frames_built;   /* optimize_frames: frames cached in this call (n_frames unless keyed and already cached) */
     int32_t corr_pairs_uploaded;  /* optimize_frames: frame-pair segments that crossed PCIe in this call (all P unless BTBA_FLAG_KEYED_CORR) */
+    float ms_pair_setup;          /* sum over GN iterations of k_pair_setup (per-pair relative poses + live-block lists of the pinhole sweeps) */
+    int32_t n_setup_launches;
 } btba_stats;
 
 /* Per-instance, per-GN-iteration trace record (floats), written when BTBA_FLAG_TRACE is set.
@@ -178,6 +181,22 @@ BTBA_API int btba_workspace_create(btba_workspace **out, void *stream);
 BTBA_API int btba_workspace_create_on_stream(btba_workspace **out, void *stream);
 BTBA_API void btba_workspace_destroy(btba_workspace *ws);
 BTBA_API int btba_workspace_sync(btba_workspace *ws);
+
+/* Developer / tuning switches of a workspace.  None of them changes WHAT is computed (only schedules and which of two equivalent
+ * code paths runs); they exist for A/B measurements and for tests that hold one path against the other.  Each also has an environment
+ * variable that sets the initial value -- read once, inside btba_workspace_create*, never on the solve path. */
+enum {
+    BTBA_OPT_DENSE_ORDER          = 1,  /* 1 (default): dense pairs worked off heaviest first (|i - j| ascending); 0: list order.  env BTBA_NO_DENSE_ORDER */
+    BTBA_OPT_TILE_MAJOR           = 2,  /* 1 (default): (band, pair) work order inside an instance; 0: (pair, band).            env BTBA_PAIR_MAJOR     */
+    BTBA_OPT_BLOCK_WALK           = 3,  /* 1 (default): pinhole sweep walks 8 x 8 pixel blocks; 0: 64 x 1 strips.               env BTBA_NO_BLOCK_WALK  */
+    BTBA_OPT_BLOCK_SKIP           = 4,  /* 1 (default): provably dead blocks are not walked; 0: every block is.                 env BTBA_NO_BLOCK_SKIP  */
+    BTBA_OPT_BIG_ASSEMBLY         = 5,  /* 1 (default): many-workgroup reduction / assembly from 24 frames on; 0: one workgroup. env BTBA_NO_BIG_ASSEMBLY */
+    BTBA_OPT_OVERLAP_GROUPS       = 6,  /* instance groups of BTBA_FLAG_OVERLAP, 1 .. 8 (default 2).                            env BTBA_GROUPS         */
+    BTBA_OPT_OVERLAP_EQUAL_PRIO   = 7,  /* 1: the groups' streams get equal priority (default 0: lowest for groups >= 1).        env BTBA_GROUP_PRIO=e   */
+    BTBA_OPT_PERSISTENT           = 9,  /* 1 (default): big batches run the fused sweep as persistent workgroups pulling items from per-XCD cursors; 0: one workgroup per item. env BTBA_NO_PERSISTENT */
+    BTBA_OPT_KEYED_CORR_MIN_BYTES = 8   /* BTBA_FLAG_KEYED_CORR is ignored below this many bytes of correspondences (default 1 MiB). env of the same name */
+};
+BTBA_API int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value);
 /* Stream ordering without a host wait, for callers whose producers / consumers run on another HIP stream (PyTorch's
  * current stream, a camera driver's copy stream): _wait_stream makes everything enqueued on the workspace stream AFTER the
  * call wait for what `stream` holds at the time of the call (inputs uploaded or rendered there); _signal_stream makes

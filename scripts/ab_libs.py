@@ -38,7 +38,7 @@ def child(lib):
         st = ws.collect_stats()
         p = poses_d.cpu().numpy()
         out[tag] = {"ms_per_step": round(dt * 1e3, 4), "sweep_us": round(st["ms_dense_sweep"] / max(st["n_dense_launches"], 1) * 1e3, 2),
-                    "solve_us": round(st["ms_system_solve"] / max(st["n_solve_launches"], 1) * 1e3, 2), "tiles": st["dense_tiles"],
+                    "solve_us": round(st["ms_system_solve"] / max(st["n_solve_launches"], 1) * 1e3, 2), "setup_us": round(st["ms_pair_setup"] / max(st["n_setup_launches"], 1) * 1e3, 2), "tiles": st["dense_tiles"],
                     "git_per_s": round(B * 7 / dt, 0), "checksum": float(np.abs(p).sum()), "finite": bool(np.isfinite(p).all())}
     print(json.dumps(out), flush=True)
 
@@ -52,10 +52,12 @@ def main():
     if not os.path.exists(CACHE):
         data = {"full": bench.generate_instances(cfg, list(range(8))), "masked": bench.generate_instances(cfg, list(range(8)), masked=True)}
         pickle.dump(data, open(CACHE, "wb"))
-    for lib in sys.argv[1:]:
+    for spec in sys.argv[1:]:
+        lib, *sets = spec.split(":")                       # build/ab/x.so:BTBA_NO_PERSISTENT=1 -- environment of that child only
         env = dict(os.environ, BTBA_LIB_PATH=os.path.abspath(lib))
+        env.update(dict(kv.split("=", 1) for kv in sets))
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", lib], env=env, capture_output=True, text=True, timeout=300)
-        print(r.stdout.strip() or ("FAILED " + lib + " " + r.stderr[-600:]), flush=True)
+        print((r.stdout.strip()[:-1] + ', "env": ' + json.dumps(sets) + "}") if r.stdout.strip() else ("FAILED " + lib + " " + r.stderr[-600:]), flush=True)
 
 
 if __name__ == "__main__":

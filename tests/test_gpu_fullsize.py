@@ -3,7 +3,7 @@ seconds, plus size-independent properties (determinism, finiteness, objective de
 import numpy as np
 import pytest
 
-from bundletrack_amd import synthetic as S
+from bundletrack_amd import _lib, synthetic as S
 
 pytestmark = pytest.mark.gpu
 
@@ -94,10 +94,10 @@ def test_c3_realistic_mask_matches_oracle(gpu, oracle):
             assert r < 1e-4 and t < 1e-4, (it, k, r, t)
 
 
-def test_dead_block_skip_is_exact(gpu, monkeypatch):
+def test_dead_block_skip_is_exact(gpu):
     """The dense sweep drops 8 x 8 blocks whose frustum segment provably projects outside the target image before walking them
     (k_block_ranges + the hull test in dense_block_pinhole).  It must never drop a block that holds an accepted pixel: with the
-    skip disabled (BTBA_NO_BLOCK_SKIP, every block walked) the accepted-pixel counts of every dense pair are IDENTICAL at the
+    skip disabled (BTBA_OPT_BLOCK_SKIP = 0, every block walked) the accepted-pixel counts of every dense pair are IDENTICAL at the
     first linearisation (same poses), the sums agree to fp32 grouping, and the solves stay within round-off of each other.
     Eight windows, among them ones with poses far from the truth (large relative motion: most blocks dead) and a masked one."""
     pbs = [S.make_problem(15, 2000, S.config_seed(5, 40 + b), background=(b != 7), full_res=False) for b in range(8)]
@@ -106,9 +106,11 @@ def test_dead_block_skip_is_exact(gpu, monkeypatch):
         for k in range(1, 15):
             pbs[b].poses_init[k] = (S.se3_exp(rng.uniform(-0.5, 0.5, 3), rng.uniform(-0.2, 0.2, 3)) @ pbs[b].poses_init[k].astype(np.float64)).astype(np.float32)
     out_a, tv_a, _ = run_gpu(gpu, pbs)
-    monkeypatch.setenv("BTBA_NO_BLOCK_SKIP", "1")
-    out_b, tv_b, _ = run_gpu(gpu, pbs)
-    monkeypatch.delenv("BTBA_NO_BLOCK_SKIP")
+    gpu.ws.set_option(_lib.OPT_BLOCK_SKIP, 0)
+    try:
+        out_b, tv_b, _ = run_gpu(gpu, pbs)
+    finally:
+        gpu.ws.set_option(_lib.OPT_BLOCK_SKIP, 1)
     ca, cb = tv_a.dense_pair[:, 0, :, 27], tv_b.dense_pair[:, 0, :, 27]
     assert np.array_equal(ca, cb)
     assert ca.sum() > 0

@@ -563,11 +563,11 @@ def test_edge_shapes_through_the_boundary(gpu, oracle):
         if N_big == 40:
             # the same window with reduction and assembly on ONE workgroup (the path a traced solve takes) instead of k_big_reduce /
             # k_big_assemble: the same sums in another grouping
-            os.environ["BTBA_NO_BIG_ASSEMBLY"] = "1"
+            gpu.ws.set_option(_lib.OPT_BIG_ASSEMBLY, 0)
             try:
                 _, poses_one, _, _ = run(pbN)
             finally:
-                del os.environ["BTBA_NO_BIG_ASSEMBLY"]
+                gpu.ws.set_option(_lib.OPT_BIG_ASSEMBLY, 1)
             d_paths = max(max(S.pose_error(posesN[k], poses_one[k])) for k in range(N_big))
             print(f"N=40: many-workgroup assembly vs one workgroup: worst pose diff {d_paths:.2e}")
             assert 0 < d_paths < 5e-5 or np.array_equal(posesN, poses_one), d_paths

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from bundletrack_amd import synthetic as S
+from bundletrack_amd import _lib, synthetic as S
 from bundletrack_amd.bundler import Bundler, FrameRef, format_pose_txt, load_pose_txt, solve_rigid_transform_between_points
 
 from helpers import OracleOptimizer, ParityOptimizer
@@ -156,8 +156,8 @@ def test_session_with_persistent_frame_cache_is_identical():
     # ... and with the pairs' correspondence segments kept on the device too (BTBA_FLAG_KEYED_CORR): still the same bits, and after
     # the first call only the NEW frame's pairs (window size - 1 segments) cross PCIe (the library skips the bookkeeping below 1 MB
     # of correspondences; the environment variable lowers that threshold for this small session)
-    os.environ["BTBA_KEYED_CORR_MIN_BYTES"] = "0"
     c_opt = OptimizerGpu(workspace=Workspace(), keyed_correspondences=True)
+    c_opt.workspace.set_option(_lib.OPT_KEYED_CORR_MIN_BYTES, 0)
     uploaded, window = [], []
     orig_c = c_opt.optimizeFrames
     def counting_c(*a, **k):
@@ -166,7 +166,6 @@ def test_session_with_persistent_frame_cache_is_identical():
     _, _, fc, _ = run_session(c_opt, n, to_device=up, persistent_frame_cache=True)
     for x, y in zip(fa, fc):
         assert np.array_equal(x.pose_in_model, y.pose_in_model)
-    os.environ.pop("BTBA_KEYED_CORR_MIN_BYTES", None)
     # at least the new frame's w - 1 pairs; more only when the keyframe selection brings two old frames together for the first time
     odd = [(k, u, w) for k, (u, w) in enumerate(zip(uploaded, window)) if u != w - 1]
     assert uploaded[0] == 1 and all(w - 1 <= u <= w * (w - 1) // 2 for u, w in zip(uploaded, window)) and len(odd) <= len(uploaded) // 5, odd
