@@ -54,7 +54,7 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
-struct EventPair { hipEvent_t a, b; int kind; };   // kind 0 dense, 1 sparse, 2 system, 3 solve region, 4 cache, 5 pair set-up
+struct EventPair { hipEvent_t a, b; int kind; };   // kind 0 dense, 1 sparse, 2 system, 3 solve region, 4 cache
 
 }  // namespace
 
@@ -66,7 +66,6 @@ struct btba_workspace {
     DevBuf corr, offsets, poses, campos, normals, nvalid;   // optimize_frames staging
     DevBuf valid_lists, valid_counts;                       // per-frame lists of pixels with a depth (compact cache)
     DevBuf block_ranges;                                    // per (frame, 8 x 8 block) usable depth range: dead-block test of the dense sweep
-    DevBuf dense_desc, live_counts, live_lists, item_queue;             // k_pair_setup's output per (instance, work position): descriptor, live-block counts and lists
     // Developer / tuning switches.  Read from the environment ONCE, when the workspace is created (never on the solve path), and settable
     // per workspace through btba_workspace_set_option (include/btba.h: BTBA_OPT_*).  None of them changes what is computed.
     struct Tuning {
@@ -74,7 +73,6 @@ struct btba_workspace {
         bool tile_major = true;        // BTBA_OPT_TILE_MAJOR    (env BTBA_PAIR_MAJOR=1 turns it off): (band, pair) instead of (pair, band) work order
         bool block_walk = true;        // BTBA_OPT_BLOCK_WALK    (env BTBA_NO_BLOCK_WALK=1): waves walk 8 x 8 blocks instead of 64 x 1 strips
         bool block_skip = true;        // BTBA_OPT_BLOCK_SKIP    (env BTBA_NO_BLOCK_SKIP=1): provably dead blocks are not walked
-        bool persistent = true;        // BTBA_OPT_PERSISTENT    (env BTBA_NO_PERSISTENT=1): the fused sweep as persistent workgroups pulling items from per-XCD cursors
         bool big_assembly = true;      // BTBA_OPT_BIG_ASSEMBLY  (env BTBA_NO_BIG_ASSEMBLY=1): many-workgroup reduction / assembly from 24 frames on
         int overlap_groups = 2;        // BTBA_OPT_OVERLAP_GROUPS (env BTBA_GROUPS): instance groups of BTBA_FLAG_OVERLAP
         bool overlap_equal_prio = false;   // BTBA_OPT_OVERLAP_EQUAL_PRIO (env BTBA_GROUP_PRIO=e...)
@@ -83,6 +81,7 @@ struct btba_workspace {
     std::vector<int32_t> dense_pairs_host;                  // what dense_pairs currently holds
     int dense_pairs_frames = -1;
     size_t dense_work_offset = 0;                           // ints into dense_pairs: the fused sweep's work table
+    int work_formula = 0;                                   // SolveDims::work_formula of that table
     int solve_tab_frames = -1;                              // window size solve_tab was built for
     std::vector<EventPair> events;                          // pending timed regions
     std::vector<hipEvent_t> event_pool;
@@ -199,7 +198,6 @@ static int workspace_create(btba_workspace **out, void *stream, bool use_given)
         t.block_walk = !on("BTBA_NO_BLOCK_WALK");
         t.block_skip = !on("BTBA_NO_BLOCK_SKIP");
         t.big_assembly = !on("BTBA_NO_BIG_ASSEMBLY");
-        t.persistent = !on("BTBA_NO_PERSISTENT");
         if (const char *e = std::getenv("BTBA_GROUPS")) t.overlap_groups = std::atoi(e);
         if (const char *e = std::getenv("BTBA_GROUP_PRIO")) t.overlap_equal_prio = e[0] == 'e';
         if (const char *e = std::getenv("BTBA_KEYED_CORR_MIN_BYTES")) t.keyed_corr_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
@@ -224,7 +222,7 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A, &ws->solve_tab,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts, &ws->block_ranges,
-                       &ws->dense_desc, &ws->live_counts, &ws->live_lists, &ws->item_queue, &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc };
+                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc };
     for (auto b : bufs) b->release();
     if (ws->corr_stage) (void)hipHostFree(ws->corr_stage);
     for (auto st : ws->aux_streams) if (st) (void)hipStreamDestroy(st);
@@ -245,7 +243,6 @@ int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
     case BTBA_OPT_BLOCK_WALK: t.block_walk = value != 0; break;
     case BTBA_OPT_BLOCK_SKIP: t.block_skip = value != 0; break;
     case BTBA_OPT_BIG_ASSEMBLY: t.big_assembly = value != 0; break;
-    case BTBA_OPT_PERSISTENT: t.persistent = value != 0; break;
     case BTBA_OPT_OVERLAP_GROUPS: if (value < 1 || value > btba_workspace::kMaxGroups) return BTBA_EINVAL; t.overlap_groups = (int)value; break;
     case BTBA_OPT_OVERLAP_EQUAL_PRIO: t.overlap_equal_prio = value != 0; break;
     case BTBA_OPT_KEYED_CORR_MIN_BYTES: if (value < 0) return BTBA_EINVAL; t.keyed_corr_min_bytes = (size_t)value; break;
@@ -486,6 +483,21 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         std::vector<int32_t> order(Pd);
         for (int q = 0; q < Pd; q++) order[q] = q;
         if (ws->tune.dense_order) std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b2) { return std::abs(pairs[2 * a] - pairs[2 * a + 1]) < std::abs(pairs[2 * b2] - pairs[2 * b2 + 1]); });
+        // is that order the closed form the pinhole sweeps can compute for themselves?  (all pairs by ascending |i - j|, then ascending
+        // lower frame, every pair's index = its canonical index, target = the lower (1) or the higher (2) frame throughout)
+        ws->work_formula = 0;
+        if (Pd == N * (N - 1) / 2) {
+            for (int form = 1; form <= 2 && !ws->work_formula; form++) {
+                bool same = true;
+                int q = 0;
+                for (int d = 1; d < N && same; d++)
+                    for (int i = 0; i + d < N && same; i++, q++) {
+                        const int pc = pair_index(N, (uint32_t)i, (uint32_t)(i + d));
+                        same = order[q] == pc && pairs[2 * pc] == (form == 1 ? i : i + d) && pairs[2 * pc + 1] == (form == 1 ? i + d : i);
+                    }
+                if (same) ws->work_formula = form;
+            }
+        }
         while (tab.size() % 4) tab.push_back(0);           // 16-byte entries
         ws->dense_work_offset = tab.size();
         for (int q = 0; q < Pd; q++) { tab.push_back(pairs[2 * order[q]]); tab.push_back(pairs[2 * order[q] + 1]); tab.push_back(order[q]); tab.push_back(0); }
@@ -517,11 +529,12 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.use_sparse = use_sparse; D.use_dense = use_dense;
     D.fx = intr[0]; D.fy = intr[1]; D.cx = intr[2]; D.cy = intr[3];
     D.robust_delta = prm->robust_delta; D.dist_thresh = prm->dense_dist_thresh; D.normal_thresh = prm->dense_normal_thresh;
+    D.dist2_thresh = prm->dense_dist_thresh * prm->dense_dist_thresh;
     D.depth_min = prm->depth_min; D.depth_max = prm->depth_max;
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;
     D.order_flag = order_flag;
-    if (Pd > 0) D.dense_work = reinterpret_cast<const int4 *>(ws->dense_pairs.as<int32_t>() + ws->dense_work_offset);      // work position -> (target, source, pair, -)
+    if (Pd > 0) { D.dense_work = reinterpret_cast<const int4 *>(ws->dense_pairs.as<int32_t>() + ws->dense_work_offset); D.work_formula = ws->work_formula; }      // work position -> (target, source, pair, -)
     D.tile_major = ws->tune.tile_major ? 1 : 0;
     D.walk_blocks = (Wd % 8 == 0 && Hd % 8 == 0 && Wd + Hd <= 1024 && ws->tune.block_walk) ? 1 : 0;
     D.n_gn = prm->n_gn_iters;
@@ -603,15 +616,13 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     }
     if (Z.frame_slot && B != 1) return BTBA_EINVAL;
     D.frame_slot = Z.frame_slot;
-    // pinhole sweeps (compact cache, zero-skew K): k_pair_setup prepares every (instance, work position) once per iteration -- relative pose,
-    // congruence, slots and, for the block walk, the per-band lists of live blocks from the per-block depth ranges
+    // block walk of the pinhole sweep: per-block depth ranges for its dead-block test, and the LDS it needs for the list of live blocks
     size_t blist_bytes = 0;
-    const bool pinhole = zn_layout == 1 && use_dense;
-    if (!(pinhole && !compaction)) D.walk_blocks = 0;
+    if (!(zn_layout == 1 && use_dense && !compaction)) D.walk_blocks = 0;
     if (D.walk_blocks) {
         const int bw = Wd / 8, bh = Hd / 8;
         const size_t band_blocks = (size_t)((bh + tiles - 1) / tiles) * bw;
-        if (band_blocks > 1024) D.walk_blocks = 0;                               // very large caches: row strips (a band's list is staged by 4 x 256 lanes)
+        if (band_blocks > 1024) D.walk_blocks = 0;                               // very large caches: row strips (a band's blocks are tested by 4 x 256 lanes)
         else {
             blist_bytes = 32 + sizeof(uint32_t) * band_blocks;
             if (ws->tune.block_skip) {                                          // (off: every block is walked)
@@ -622,18 +633,6 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                     D.block_ranges = ws->block_ranges.as<float2>();
                 }
             }
-        }
-    }
-    if (pinhole) {
-        if ((rc = ws->dense_desc.ensure(sizeof(DenseDesc) * (size_t)B * Pd))) return rc;
-        D.dense_desc = ws->dense_desc.as<DenseDesc>();
-        if ((rc = ws->item_queue.ensure(sizeof(unsigned) * 256 * btba_workspace::kMaxGroups))) return rc;
-        D.item_queue = ws->item_queue.as<unsigned>();
-        if (D.walk_blocks) {
-            if ((rc = ws->live_counts.ensure(sizeof(int) * (size_t)B * Pd * tiles))) return rc;
-            if ((rc = ws->live_lists.ensure(sizeof(uint32_t) * (size_t)B * Pd * (size_t)((Wd / 8) * (Hd / 8))))) return rc;
-            D.live_counts = ws->live_counts.as<int>();
-            D.live_lists = ws->live_lists.as<uint32_t>();
         }
     }
     // Software pipelining across instances: the batch is split in two halves on two streams, so one half's
@@ -662,12 +661,6 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         for (int g = 1; g < n_halves; g++) HIP_TRY(hipStreamWaitEvent(ws->aux_streams[g - 1], ws->ev_fork, 0));
     }
     const size_t pairsum_floats = lds_pairs / sizeof(float);
-    int n_resident = 0;                 // workgroups of the fused sweep the device holds at once: BTBA_FUSED_WAVES per SIMD = as many 4-wave workgroups per CU
-    {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, ws->device));
-        n_resident = prop.multiProcessorCount * BTBA_FUSED_WAVES;
-    }
     const size_t lut_bytes = sizeof(float) * (size_t)((Wd + Hd + 3) & ~3) + (zn_layout == 1 ? sizeof(float4) * (size_t)(Wd + Hd) : 0) + blist_bytes;         // coordinate look-up tables of the compact dense sweep (+ its list of live blocks)
     for (int it = 0; it < prm->n_gn_iters; it++) {
         const bool timing_it = timing && (timed_iteration < 0 || timed_iteration == it);
@@ -688,11 +681,6 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             size_t slot;
             SolveDims Dh = D;                                   // the sweeps' view of this half
             if (Dh.block_ranges) Dh.block_ranges += b0 * N * (size_t)((Wd / 8) * (Hd / 8));
-            if (pinhole) {
-                Dh.dense_desc += b0 * (size_t)Pd;
-                if (Dh.live_counts) { Dh.live_counts += b0 * (size_t)Pd * tiles; Dh.live_lists += b0 * (size_t)Pd * (size_t)((Wd / 8) * (Hd / 8)); }
-                Dh.item_queue += 256 * h;
-            }
 #ifdef BTBA_WG_TRACE
             static DevBuf wg_trace_buf;
             const char *wg_trace_file = std::getenv("BTBA_WG_TRACE_FILE");
@@ -704,11 +692,6 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             }
 #endif
             const unsigned n_d = (unsigned)tiles * D.n_dense_pairs * H.nb, n_s = (unsigned)chunks * P * H.nb;
-            if (pinhole) {
-                if ((rc = time_begin(ws, timing_it, 5, &slot, H.st))) return rc;
-                k_pair_setup<<<dim3((unsigned)Pd, (unsigned)H.nb), kBlock, 0, H.st>>>(Dh, T_h, Ti_h, const_cast<DenseDesc *>(Dh.dense_desc), const_cast<int *>(Dh.live_counts), const_cast<uint32_t *>(Dh.live_lists));
-                if ((rc = time_end(ws, slot, H.st))) return rc;
-            }
             // one interleaved launch of both sweeps: the dense workgroups are VALU-bound, the sparse ones stream HBM, and the
             // two fill each other's idle pipes -- measured at c3 (scripts/ab_dense.py, fused vs separate step time):
             // B=1 0.486 / 0.554 ms, B=8 0.871 / 0.950 ms, B=32 2.271 / 2.380 ms
@@ -719,10 +702,6 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
 #define BTBA_FUSED_ARGS(CACHE) Dh, n_d, n_s, CACHE, reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, corr_h, off_h, sp_h, vl_h, vc_h
                 const int lay = zn_layout ? zn_layout + (compaction ? 2 : 0) : 0;
                 if (lay == 0) k_fused_sweeps<0><<<dim3(n_d + n_s), kBlock, 0, H.st>>>(BTBA_FUSED_ARGS(reinterpret_cast<const float4 *>(campos_h)));
-                else if (lay == 1 && ws->tune.persistent && n_d + n_s > (unsigned)n_resident) {
-                    const FusedArgs fa{ BTBA_FUSED_ARGS(zn_h) };
-                    k_fused_persist<1><<<dim3(n_resident), kBlock, lut_bytes, H.st>>>(fa);
-                }
                 else if (lay == 1) k_fused_sweeps<1><<<dim3(n_d + n_s), kBlock, lut_bytes, H.st>>>(BTBA_FUSED_ARGS(zn_h));
                 else if (lay == 2) k_fused_sweeps<2><<<dim3(n_d + n_s), kBlock, lut_bytes, H.st>>>(BTBA_FUSED_ARGS(zn_h));
                 else if (lay == 3) k_fused_sweeps<3><<<dim3(n_d + n_s), kBlock, lut_bytes, H.st>>>(BTBA_FUSED_ARGS(zn_h));
@@ -799,7 +778,6 @@ int btba_collect_stats(btba_workspace *ws, btba_stats *stats)
             case 2: S.ms_system_solve += ms; S.n_solve_launches++; break;
             case 3: S.ms_solve += ms; break;
             case 4: S.ms_cache += ms; break;
-            case 5: S.ms_pair_setup += ms; S.n_setup_launches++; break;
             default: break;
             }
         }
@@ -808,8 +786,8 @@ int btba_collect_stats(btba_workspace *ws, btba_stats *stats)
     }
     ws->events.clear();
     if (stats) *stats = S;
-    S.ms_dense_sweep = S.ms_sparse_sweep = S.ms_system_solve = S.ms_solve = S.ms_cache = S.ms_pair_setup = 0.0f;
-    S.n_dense_launches = S.n_sparse_launches = S.n_solve_launches = S.n_setup_launches = 0;
+    S.ms_dense_sweep = S.ms_sparse_sweep = S.ms_system_solve = S.ms_solve = S.ms_cache = 0.0f;
+    S.n_dense_launches = S.n_sparse_launches = S.n_solve_launches = 0;
     return BTBA_OK;
 }
 

@@ -58,6 +58,7 @@ struct SolveDims {
     int use_sparse, use_dense;
     float fx, fy, cx, cy;
     float robust_delta, dist_thresh, normal_thresh, depth_min, depth_max;
+    float dist2_thresh;  // dist_thresh^2 (fp32 product, formed once on the host)
     float w_sparse, w_dense;
     int64_t corr_stride; // EntryJ per instance block
     int trace_on;
@@ -71,12 +72,9 @@ struct SolveDims {
     unsigned long long *wg_trace; // developer build (scripts/wg_trace.py): per workgroup of the fused sweep (start, end) in 100 MHz ticks, hardware id, kind
 #endif
     const int4 *dense_work;       // work position q -> (target, source, dense pair, -): the order the sweeps work the pairs off, heaviest first
-    const float2 *block_ranges;   // per (cache slot, 8 x 8 block): [min, max] valid depth (k_block_ranges); nullptr: no block is skipped (read by k_pair_setup)
-    // pinhole sweeps on the compact cache: what k_pair_setup leaves per (instance, work position) for this iterate's poses
-    const struct DenseDesc *dense_desc;
-    const int *live_counts;       // [B][Pd][dense_tiles]: live 8 x 8 blocks of the band
-    unsigned *item_queue;         // [8][32]: item cursors of the persistent fused sweep per (XCD, group), zeroed by k_pair_setup
-    const uint32_t *live_lists;   // [B][Pd][blocks per frame]: their codes (block row << 16 | block column), band t's from block index r0(t) * bw on, ascending
+    int work_formula;             // 1 / 2: the table is the closed form "all pairs by ascending |i - j|, then ascending i" with target = lower / higher
+                                  // frame -- the pinhole sweeps then compute their item instead of loading it (one memory round trip less)
+    const float2 *block_ranges;   // per (cache slot, 8 x 8 block): [min, max] valid depth (k_block_ranges); nullptr: no block is skipped
     int tile_major;      // dense work order inside an instance: 1 = (tile, pair) -- all pairs' band t of the images together -- 0 = (pair, tile)
     int *order_flag;     // non-null: the sparse sweep ORs 1 into it when an entry does not belong to the pair of its segment
     // compact (z, nx, ny, nz) frame cache: how a cached pixel maps back to camera space -- the arithmetic of k_build_cache
@@ -505,6 +503,9 @@ __device__ __forceinline__ void dense_stage_M(float *red, const float *__restric
     }
 }
 
+// FLIPPED: the sums were accumulated with a+ = D a, res+ = -res (dense_block_pinhole): S = D S+ D negates the nine entries that couple a
+// translation row with a rotation row, g = -D g+ negates the three rotation entries -- exact.
+template <bool FLIPPED = false>
 __device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *red, float *out)
 {
     const unsigned tid = item_tid();
@@ -516,6 +517,11 @@ __device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *
         float s = red[tid];
 #pragma unroll
         for (int w = 1; w < 4; w++) s += red[w * kDenseVals + tid];
+        if (FLIPPED) {
+            // upper-triangle packing (tri21): row r < 3 holds columns r .. 5 from r * 6 - r (r - 1) / 2 on; its columns 3 .. 5 are the mixed entries
+            const bool mixed = (tid >= 3 && tid < 6) || (tid >= 8 && tid < 11) || (tid >= 12 && tid < 15);
+            if (mixed || (tid >= 24 && tid < 27)) s = -s;
+        }
         Sp[tid] = s;
     }
     __syncthreads();
@@ -793,18 +799,6 @@ struct PinholeCtx {
     unsigned zmin_bits, zrange_bits;  // depth_min < z < depth_max  <=>  bits(z) - (bits(depth_min) + 1) < zrange_bits (unsigned)
 };
 
-// What a pinhole dense workgroup needs that depends on this iterate's poses, per (instance, work position): written once per Gauss-Newton
-// iteration by k_pair_setup, so that a dense workgroup starts with ONE round of loads (descriptor, live-block count and list, all addressed
-// by its own grid position) instead of the chain work table -> poses / block ranges -> hull test -> list that used to take 7.2 of its 39 us
-// (profiles/r02/wg_trace_c3x32_v17.json).  256 bytes.
-struct DenseDesc {
-    float Rt[12];                     // rows of [R | t] of T_target^-1 T_source (mat_mul of the two matrices, as the workgroups used to compute it)
-    int slot_t, slot_s, pair, pad0;   // cache slots of the target / source frame, the dense pair the partial sums belong to
-    float M[36];                      // congruence of the epilogue, from the target frame's pose (dense_stage_M)
-    float pad1[12];
-};
-static_assert(sizeof(DenseDesc) == 256, "DenseDesc is read as 16-byte rows");
-
 __device__ __forceinline__ float lds_f32_at(const float *base, unsigned byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); }
 __device__ __forceinline__ float2 lds_f32x2_at(const float *base, unsigned byte_off) { const char *q = reinterpret_cast<const char *>(base) + byte_off; return make_float2(*reinterpret_cast<const float *>(q), *reinterpret_cast<const float *>(q + 4)); }
 __device__ __forceinline__ float4 gather16(const float4 *base, unsigned byte_off) { return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off); }
@@ -832,12 +826,14 @@ __device__ __forceinline__ float pinhole_lut_entry(const SolveDims &D, int e)
 // 0.01 pixel, three orders of magnitude above the rounding differences between this evaluation and the per-pixel one -- no pixel of the
 // block can pass the in-image test of SolverBundlingDenseUtil.h:91-94 and the block contributes exactly nothing, as in the reference.
 // Blocks without any usable depth go the same way.  (lut: the pinhole_lut_entry table; R, t: the relative pose.)
-__device__ __forceinline__ bool block_is_live(const SolveDims &D, const float *lut, const float (&R)[9], const float (&t)[3], float2 zr, int bxl, int byg)
+__device__ __forceinline__ bool block_is_live(const SolveDims &D, const float (&R)[9], const float (&t)[3], float2 zr, int bxl, int byg)
 {
     zr.x = fmaxf(zr.x, D.depth_min); zr.y = fminf(zr.y, D.depth_max);      // usable depths: depth_min < z < depth_max
     bool live = zr.x <= zr.y;
     if (live) {
-        const float xa = lut[8 * bxl], xb = lut[8 * bxl + 7], ya = lut[D.width + 8 * byg], yb = lut[D.width + 8 * byg + 7];
+        // the block's extreme rays: column / row terms of its first and last column / row (the table entries, evaluated in place)
+        const float xa = pinhole_lut_entry(D, 8 * bxl), xb = pinhole_lut_entry(D, 8 * bxl + 7);
+        const float ya = pinhole_lut_entry(D, D.width + 8 * byg), yb = pinhole_lut_entry(D, D.width + 8 * byg + 7);
         float ulo = INFINITY, uhi = -INFINITY, vlo = INFINITY, vhi = -INFINITY, zq = INFINITY;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -859,76 +855,19 @@ __device__ __forceinline__ bool block_is_live(const SolveDims &D, const float *l
     return live;
 }
 
-// ---- k_pair_setup: once per Gauss-Newton iteration, grid (Pd, B) x 256 -----------------------------------------------------------
-// Workgroup (q, b) prepares work position q of instance b for the pinhole sweeps: the relative pose, the epilogue's congruence M, the
-// frames' cache slots, and -- for the block walk -- per band of block rows the ordered list of the blocks that are not provably dead
-// (block_is_live; ballot + mbcnt compaction in block order, fixed, as the dense workgroups used to build it for themselves in LDS).
-__global__ void __launch_bounds__(kBlock) k_pair_setup(SolveDims D, const float *__restrict__ T, const float *__restrict__ Tinv,
-                                                      DenseDesc *__restrict__ desc, int *__restrict__ live_counts, uint32_t *__restrict__ live_lists)
+// (target, source, dense pair) of work position q: computed where the work order is the closed form (the default pair policies), read from
+// the work table otherwise.  q is wave-uniform: scalar arithmetic / a scalar load.
+__device__ __forceinline__ void dense_work_item(const SolveDims &D, int q, int &fi, int &fj, int &p)
 {
-    __shared__ float lut[1024];                    // width + height <= 1024 (checked by the host)
-    __shared__ int hdr[8];
-    const int q = blockIdx.x, b = blockIdx.y;
-    if (D.item_queue && q == 0 && b == 0) D.item_queue[threadIdx.x] = 0u;      // the persistent sweep's item cursors: 8 XCDs x 32 groups = kBlock words
-    const int4 w = D.dense_work[q];
-    const int fi = w.x, fj = w.y;                  // fi = target, fj = source
-    const size_t fb = (size_t)b * D.n_frames;
-    if (D.walk_blocks) for (int e = (int)threadIdx.x; e < D.width + D.height; e += kBlock) lut[e] = pinhole_lut_entry(D, e);
-    const Mat4 Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), load_mat4(T + 16 * (fb + fj)));
-    const int slot_t = (int)frame_slot_of(D, fb + fi), slot_s = (int)frame_slot_of(D, fb + fj);
-    DenseDesc *o = desc + ((size_t)b * D.n_dense_pairs + q);
-    if (threadIdx.x < 12) o->Rt[threadIdx.x] = Tij.m[threadIdx.x];
-    if (threadIdx.x == 12) { o->slot_t = slot_t; o->slot_s = slot_s; o->pair = w.z; o->pad0 = 0; }
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + 36) {
-        const float *T_target = T + 16 * (fb + fi);
-        const int e = (int)threadIdx.x - 64, r = e / 6, c = e % 6;
-        float v;
-        if (r < 3) v = (c < 3) ? T_target[4 * r + c] : 0.0f;
-        else {
-            const int qq = r - 3, qa = (qq + 1) % 3, qb = (qq + 2) % 3;     // ([t]x R)[q][c] = t[qa] R[qb][c] - t[qb] R[qa][c]
-            v = (c < 3) ? T_target[4 * qa + 3] * T_target[4 * qb + c] - T_target[4 * qb + 3] * T_target[4 * qa + c] : T_target[4 * qq + (c - 3)];
-        }
-        o->M[e] = v;
-    }
-    if (!D.walk_blocks) return;
-    float R[9], t[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) R[3 * r + c] = sgpr(Tij.m[4 * r + c]);
-        t[r] = sgpr(Tij.m[4 * r + 3]);
-    }
-    __syncthreads();
-    const int bw = D.width >> 3, bh = D.height >> 3;
-    const int rows_per = (bh + D.dense_tiles - 1) / D.dense_tiles;
-    const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const float2 *rng = D.block_ranges ? D.block_ranges + (size_t)slot_s * (size_t)(bw * bh) : nullptr;
-    uint32_t *list = live_lists + ((size_t)b * D.n_dense_pairs + q) * (size_t)(bw * bh);
-    for (int tile = 0; tile < D.dense_tiles; tile++) {
-        const int r0 = min(bh, rows_per * tile), r1 = min(bh, rows_per * (tile + 1));
-        const int nb = (r1 - r0) * bw;
-        int n_live = 0;
-        for (int c0 = 0; c0 < nb; c0 += kBlock) {
-            const int idx = c0 + (int)threadIdx.x;
-            bool live = false;
-            unsigned code = 0;
-            if (idx < nb) {
-                const int byl = idx / bw, bxl = idx - byl * bw, byg = r0 + byl;
-                code = ((unsigned)byg << 16) | (unsigned)bxl;
-                live = rng ? block_is_live(D, lut, R, t, rng[byg * bw + bxl], bxl, byg) : true;
-            }
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(live);
-            if (lane == 0) hdr[wave] = __popcll(bal);
-            __syncthreads();
-            int base = n_live, total = 0;
-#pragma unroll
-            for (int wv = 0; wv < kBlock / 64; wv++) { const int tt = hdr[wv]; if (wv < wave) base += tt; total += tt; }
-            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-            if (live) list[r0 * bw + base + before] = code;
-            n_live += total;
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) live_counts[((size_t)b * D.n_dense_pairs + q) * D.dense_tiles + tile] = n_live;
+    if (D.work_formula) {
+        int d = 1, rem = q;                        // pairs at frame distance d: (i, i + d), i = 0 .. N-1-d, distances ascending
+        while (rem >= D.n_frames - d) { rem -= D.n_frames - d; d++; }
+        p = pair_index(rem, rem + d, D.n_frames);  // the canonical list IS the dense pair list of these policies
+        fi = D.work_formula == 1 ? rem : rem + d;
+        fj = D.work_formula == 1 ? rem + d : rem;
+    } else {
+        const int4 w = ld_const_i4(D.dense_work + q);
+        fi = w.x; fj = w.y; p = w.z;
     }
 }
 
@@ -936,38 +875,48 @@ __global__ void __launch_bounds__(kBlock) k_pair_setup(SolveDims D, const float 
 // (the arithmetic per accepted pixel is dense_block_zn<true, .>'s; the shape is what the VALU of gfx950 charges for, see above)
 template <int WALK>     // 0: 64-pixel row strips   1: the source frame's valid-pixel list   2: 8 x 8 pixel blocks per wave (cache width and height multiples of 8)
 __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const float4 *__restrict__ zn, int q,
+                                                    const float *__restrict__ T, const float *__restrict__ Tinv,
                                                     float *__restrict__ partials, int tile, int b, float *red,
                                                     const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts, float *lut)
 {
     const unsigned tid = item_tid();
-    // ONE round of loads, every address a function of the workgroup's grid position: this item's descriptor (relative pose, slots, pair, M),
-    // and for the block walk the band's live-block count and list
-    const size_t item = (size_t)b * D.n_dense_pairs + q;
-    const DenseDesc *dd = D.dense_desc + item;
-    const float4 d0 = ld_const_f4(dd->Rt), d1 = ld_const_f4(dd->Rt + 4), d2 = ld_const_f4(dd->Rt + 8);
-    const int4 di = ld_const_i4(&dd->slot_t);
-    float m_stage = 0.0f;
-    if (tid >= 64 && tid < 64 + 36) m_stage = dd->M[tid - 64];
+    // The prologue is ONE round of memory loads, every address a function of the workgroup's grid position: the item (computed, or one
+    // scalar load), the two poses (scalar loads: the previous launch wrote them), the target pose for M, the band's block ranges.
+    // (Round 2: work table -> poses / ranges -> hull test -> list, four dependent round trips, 7.2 of a workgroup's 39 us.)
+    int fi, fj, p;                                        // fi = target, fj = source
+    dense_work_item(D, q, fi, fj, p);
+    const size_t fb = (size_t)b * D.n_frames;
+    const size_t slot_t = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fi));
+    const size_t slot_s = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fj));
+    const Mat4 Tinv_i = load_mat4_uniform(Tinv + 16 * (fb + fi)), T_j = load_mat4_uniform(T + 16 * (fb + fj));
+    float m_stage = 0.0f;                                 // M of the epilogue's congruence, from the target frame's pose (see dense_stage_M)
+    if (tid >= 64 && tid < 64 + 36) {
+        const float *T_target = T + 16 * (fb + fi);
+        const int e = (int)tid - 64, r = e / 6, c = e % 6;
+        if (r < 3) m_stage = (c < 3) ? T_target[4 * r + c] : 0.0f;
+        else {
+            const int qq = r - 3, qa = (qq + 1) % 3, qb = (qq + 2) % 3;     // ([t]x R)[q][c] = t[qa] R[qb][c] - t[qb] R[qa][c]
+            m_stage = (c < 3) ? T_target[4 * qa + 3] * T_target[4 * qb + c] - T_target[4 * qb + 3] * T_target[4 * qa + c] : T_target[4 * qq + (c - 3)];
+        }
+    }
     const int bw = D.width >> 3, bh = D.height >> 3;
     const int rows_per = (bh + D.dense_tiles - 1) / D.dense_tiles;
     const int r0 = min(bh, rows_per * tile), r1 = min(bh, rows_per * (tile + 1));
-    const int nb = (WALK == 2) ? (r1 - r0) * bw : 0;
-    int n_live = 0;
-    unsigned code_stage[4] = { 0u, 0u, 0u, 0u };            // up to 1 024 blocks per band (the host keeps the band's list within the LDS it reserves)
-    if (WALK == 2) {
-        n_live = as_const(D.live_counts)[item * D.dense_tiles + tile];
-        const uint32_t *list = D.live_lists + item * (size_t)(bw * bh) + (size_t)r0 * bw;
+    const int nb = (WALK == 2) ? (r1 - r0) * bw : 0;      // blocks of this band (the host keeps it <= 4 x 256)
+    const float2 *rng = (WALK == 2 && D.block_ranges) ? D.block_ranges + slot_s * (size_t)(bw * bh) + (size_t)r0 * bw : nullptr;
+    const float2 zr0 = (rng && (int)tid < nb) ? rng[tid] : make_float2(0.0f, 0.0f);      // (bands of more than 256 blocks fetch the rest in the compaction loop)
+    const Mat4 Tij = mat_mul(Tinv_i, T_j);                // source camera -> target camera
+    PinholeCtx C;
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (k * kBlock + (int)tid < nb) code_stage[k] = list[k * kBlock + tid];
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) C.R[3 * r + c] = sgpr(Tij.m[4 * r + c]);
+        C.t[r] = sgpr(Tij.m[4 * r + 3]);
     }
     // tables in LDS: lut[0 .. Wd) = K^-1[0][0] x_full(x) + K^-1[0][2] per cache column, lut[Wd .. Wd+Hd) the same for rows (the taps' back-projection),
     // and the ROTATED RAYS: the transformed point of source pixel (x, y) with depth d is q = d (R (lx, ly, 1)) + t = d (colA[x] + rowB[y]) + t with
     // colA[x] = R[:, 0] lx(x), rowB[y] = R[:, 1] ly(y) + R[:, 2] -- two 16-byte LDS reads, 3 adds and 3 FMAs per pixel instead of 2 reads,
-    // 2 multiplies and 12 operations with a scalar-register operand (which issue at half rate, profiles/r02/valu_calibration.md).  One pass, one barrier.
-    PinholeCtx C;
-    C.R[0] = sgpr(d0.x); C.R[1] = sgpr(d0.y); C.R[2] = sgpr(d0.z); C.t[0] = sgpr(d0.w);
-    C.R[3] = sgpr(d1.x); C.R[4] = sgpr(d1.y); C.R[5] = sgpr(d1.z); C.t[1] = sgpr(d1.w);
-    C.R[6] = sgpr(d2.x); C.R[7] = sgpr(d2.y); C.R[8] = sgpr(d2.z); C.t[2] = sgpr(d2.w);
+    // 2 multiplies and 12 operations with a scalar-register operand (which issue at half rate, profiles/r02/valu_calibration.md).  One pass.
     float4 *colA = reinterpret_cast<float4 *>(lut + ((D.width + D.height + 3) & ~3));
     float4 *rowB = colA + D.width;
     for (int e = (int)tid; e < D.width + D.height; e += kBlock) {
@@ -976,23 +925,42 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         if (e < D.width) colA[e] = make_float4(C.R[0] * l, C.R[3] * l, C.R[6] * l, 0.0f);
         else rowB[e - D.width] = make_float4(C.R[1] * l + C.R[2], C.R[4] * l + C.R[5], C.R[7] * l + C.R[8], 0.0f);
     }
-    if (tid >= 64 && tid < 64 + 36) red[4 * kDenseVals + kDenseVals + 4 + ((int)tid - 64)] = m_stage;      // M of the epilogue
-    int *hdr = reinterpret_cast<int *>(rowB + D.height);
+    if (tid >= 64 && tid < 64 + 36) red[4 * kDenseVals + kDenseVals + 4 + ((int)tid - 64)] = m_stage;
+    int *hdr = reinterpret_cast<int *>(rowB + D.height);                  // [0 .. 4) wave totals of the list compaction
     unsigned *blist = reinterpret_cast<unsigned *>(hdr + 8);
+    int n_live = 0;
     if (WALK == 2) {
+        // Blocks that are provably dead (block_is_live: 90 % of the dead ones at c3) are removed BEFORE the walk; the live ones are compacted
+        // into an ordered list in LDS (ballot + mbcnt, block order: deterministic) that the four waves share round-robin.
+        const int lane_c = (int)tid & 63, wave_c = __builtin_amdgcn_readfirstlane((int)tid >> 6);
+        for (int c0 = 0; c0 < nb; c0 += kBlock) {
+            const int idx = c0 + (int)tid;
+            bool live = false;
+            unsigned code = 0;
+            if (idx < nb) {
+                const int byl = idx / bw, bxl = idx - byl * bw, byg = r0 + byl;
+                code = ((unsigned)byg << 16) | (unsigned)bxl;
+                live = rng ? block_is_live(D, C.R, C.t, c0 ? rng[idx] : zr0, bxl, byg) : true;
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(live);
+            if (lane_c == 0) hdr[wave_c] = __popcll(bal);
+            __syncthreads();
+            int base = n_live, total = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (k * kBlock + (int)tid < nb) blist[k * kBlock + tid] = code_stage[k];
-    }
-    __syncthreads();
+            for (int w = 0; w < kBlock / 64; w++) { const int tt = hdr[w]; if (w < wave_c) base += tt; total += tt; }
+            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+            if (live) blist[base + before] = code;
+            n_live += total;
+            __syncthreads();
+        }
+    } else __syncthreads();
     C.fx = D.fx; C.fy = D.fy; C.cx = D.cx; C.cy = D.cy;
     C.wm1 = (float)(D.width - 1); C.hm1 = (float)(D.height - 1); C.wm2 = (float)(D.width - 2); C.hm2 = (float)(D.height - 2);
     C.w16 = 16.0f * (float)D.width; C.row16 = 16u * (unsigned)D.width;
     C.ybase4 = 4.0f * (float)D.width;                     // LDS byte offset of the row table
-    C.normal_thresh = D.normal_thresh; C.dist2_thresh = D.dist_thresh * D.dist_thresh;
+    C.normal_thresh = D.normal_thresh; C.dist2_thresh = D.dist2_thresh;
     C.wdelta = D.w_dense * D.robust_delta; C.w_dense = D.w_dense;
     C.zmin_bits = __float_as_uint(D.depth_min) + 1u; C.zrange_bits = __float_as_uint(D.depth_max) - __float_as_uint(D.depth_min) - 1u;
-    const size_t slot_t = (size_t)__builtin_amdgcn_readfirstlane(di.x), slot_s = (size_t)__builtin_amdgcn_readfirstlane(di.y);
-    const int p = __builtin_amdgcn_readfirstlane(di.z);
     const float4 *zn_t = zn + slot_t * (size_t)D.npix, *zn_s = zn + slot_s * (size_t)D.npix;
     constexpr bool LISTS = (WALK == 1);
     float acc[kDenseVals];
@@ -1041,11 +1009,15 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         // rejected pixels contribute exact zeros: AND with 0 / ~0 (one select, then 2-cycle v_and_b32; NaN-safe, unlike a multiply)
         const unsigned keep = opaque_vgpr(ok ? 0xFFFFFFFFu : 0u);
         auto masked = [keep](float x) { return __uint_as_float(__float_as_uint(x) & keep); };
-        const float res = masked(-(dx * nix + dy * niy + dz * niz));
-        // Huber (SolverBundlingUtil.h:24-40) times the dense weight: rho' = 1 for e <= delta^2, delta / sqrt(e) above  <=>  min(1, delta rsq(e))
-        const float wgt = masked(min_raw(C.w_dense, C.wdelta * fast_rsq(res * res)));
+        // SIGNS: the row is accumulated as a+ = [n_i ; n_i x q] and the residual as res+ = (q - c_i) . n_i, i.e. a = D a+ with
+        // D = diag(-1, -1, -1, 1, 1, 1) and res = -res+ (SolverBundlingDenseUtil.h:78-110, LieDerivUtil.h:228-273).  Then S = D S+ D and
+        // g = -D g+ : exact sign changes of whole sums, applied once per workgroup in the epilogue instead of four negations per pixel.
+        const float res = masked(dx * nix + dy * niy + dz * niz);
+        // Huber (SolverBundlingUtil.h:24-40) times the dense weight: rho' = 1 for e <= delta^2, delta / sqrt(e) above  <=>  min(1, delta rsq(e)).
+        // Not masked: a rejected pixel has res = 0, rsq(0) = inf, min(w, inf) = w -- finite, and it multiplies a masked (zero) row.
+        const float wgt = min_raw(C.w_dense, C.wdelta * fast_rsq(res * res));
         const float mx = masked(nix), my = masked(niy), mz = masked(niz);
-        const float a[6] = { -mx, -my, -mz, my * qz - mz * qy, mz * qx - mx * qz, mx * qy - my * qx };
+        const float a[6] = { mx, my, mz, my * qz - mz * qy, mz * qx - mx * qz, mx * qy - my * qx };
         int k = 0;
         // acc += wa_r * a_c is a read-modify-write FMA: it issues at full rate only when its two multiplicands sit in VGPRs of
         // different parity (profiles/r02/valu_calibration.md).  (wa_r, a_r) held as an aligned register PAIR puts every wa in an
@@ -1068,8 +1040,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     if (WALK == 2) {
         // Waves walk 8 x 8 pixel blocks of this band of block rows; lane = (row, column) inside the block.  The region of a source
         // frame that projects into the target is a compact blob, so whole blocks fall outside it (51 % of them at c3; 64 x 1 strips:
-        // 31 %), and a block's taps land in a compact patch of the target.  Blocks that are provably dead (block_is_live, k_pair_setup:
-        // 90 % of the dead ones at c3) are not in the list; the four waves share the list round-robin.
+        // 31 %), and a block's taps land in a compact patch of the target.  The list holds the blocks that are not provably dead.
         const int lane = (int)tid & 63, wave = __builtin_amdgcn_readfirstlane((int)tid >> 6);
         n_live = __builtin_amdgcn_readfirstlane(n_live);
 #ifdef BTBA_WG_TRACE
@@ -1079,20 +1050,31 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const unsigned lane_px = ly * (unsigned)D.width + lx;          // pixel offset of the lane inside its block
         const unsigned ox_l = 16u * lx, oy_l = 16u * ly + 16u * (unsigned)D.width;
         constexpr unsigned kBlockStep = 128u;            // 8 entries of 16 bytes
-        // this wave's current and next block (scalar registers), the next block's pixels in flight while the current one is worked on
+        // this wave's current and next block (scalar registers), the next block's pixels in flight while the current one is worked on.
+        // Two trips per loop iteration with the two register sets swapping roles: a single-trip loop rotates (next -> current) through
+        // eight v_mov per trip, 5 % of its instructions.
+        auto fetch = [&](int kk, unsigned &code, float4 &zs) {
+            code = (unsigned)__builtin_amdgcn_readfirstlane((int)blist[kk]);
+            zs = gather16(zn_s, 16u * ((code >> 16) * 8u * (unsigned)D.width + (code & 0xFFFFu) * 8u + lane_px));
+        };
+        auto work = [&](const float4 &zs, unsigned code) { pixel(zs, ox_l + kBlockStep * (code & 0xFFFFu), oy_l + kBlockStep * (code >> 16)); };
         int k = wave;
-        unsigned code_n = (k < n_live) ? (unsigned)__builtin_amdgcn_readfirstlane((int)blist[k]) : 0u;
-        float4 zs_n = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < n_live) zs_n = gather16(zn_s, 16u * ((code_n >> 16) * 8u * (unsigned)D.width + (code_n & 0xFFFFu) * 8u + lane_px));
-        while (k < n_live) {
-            const float4 zs = zs_n;
-            const unsigned code = code_n;
-            k += kBlock / 64;
-            if (k < n_live) {
-                code_n = (unsigned)__builtin_amdgcn_readfirstlane((int)blist[k]);
-                zs_n = gather16(zn_s, 16u * ((code_n >> 16) * 8u * (unsigned)D.width + (code_n & 0xFFFFu) * 8u + lane_px));
+        if (k < n_live) {
+            unsigned code_a, code_b = 0u;
+            float4 zs_a, zs_b = make_float4(0.f, 0.f, 0.f, 0.f);
+            fetch(k, code_a, zs_a);
+            for (;;) {
+                k += kBlock / 64;
+                const bool more_b = k < n_live;
+                if (more_b) fetch(k, code_b, zs_b);
+                work(zs_a, code_a);
+                if (!more_b) break;
+                k += kBlock / 64;
+                const bool more_a = k < n_live;
+                if (more_a) fetch(k, code_a, zs_a);
+                work(zs_b, code_b);
+                if (!more_a) break;
             }
-            pixel(zs, ox_l + kBlockStep * (code & 0xFFFFu), oy_l + kBlockStep * (code >> 16));
         }
 #ifdef BTBA_WG_TRACE
         if (tid == 0) wg_dbg[1] = wall_clock64();
@@ -1130,7 +1112,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         }
     }
     float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
-    dense_epilogue(acc, red, out);
+    dense_epilogue<true>(acc, red, out);
 }
 
 template <bool SIMPLE, bool LISTS>
@@ -1144,10 +1126,10 @@ __global__ void __launch_bounds__(kBlock, 5) k_dense_sweep_zn(SolveDims D, const
     const int tile = (int)(L % (unsigned)D.dense_tiles);
     const int p = (int)((L / (unsigned)D.dense_tiles) % (unsigned)D.n_dense_pairs);
     const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));
-    // pinhole intrinsics: the same block as in the fused launch (same partial sums, bit for bit); `p` is then a WORK POSITION (k_pair_setup)
-    if (SIMPLE && LISTS) dense_block_pinhole<1>(D, zn, p, partials, tile, b, red, valid_lists, valid_counts, zn_lut);
-    else if (SIMPLE && D.walk_blocks) dense_block_pinhole<2>(D, zn, p, partials, tile, b, red, valid_lists, valid_counts, zn_lut);
-    else if (SIMPLE) dense_block_pinhole<0>(D, zn, p, partials, tile, b, red, valid_lists, valid_counts, zn_lut);
+    // pinhole intrinsics: the same block as in the fused launch (same partial sums, bit for bit); `p` is then a WORK POSITION (dense_work_item)
+    if (SIMPLE && LISTS) dense_block_pinhole<1>(D, zn, p, T, Tinv, partials, tile, b, red, valid_lists, valid_counts, zn_lut);
+    else if (SIMPLE && D.walk_blocks) dense_block_pinhole<2>(D, zn, p, T, Tinv, partials, tile, b, red, valid_lists, valid_counts, zn_lut);
+    else if (SIMPLE) dense_block_pinhole<0>(D, zn, p, T, Tinv, partials, tile, b, red, valid_lists, valid_counts, zn_lut);
     else dense_block_zn<false, LISTS>(D, zn, dense_pairs[p], T, Tinv, partials, tile, p, b, red, valid_lists, valid_counts, zn_lut);
 }
 
@@ -1204,11 +1186,10 @@ __device__ __forceinline__ void fused_item(const SolveDims &D, unsigned n_d, uns
         const int tile = D.tile_major ? (int)(Lb / (unsigned)D.n_dense_pairs) : (int)(Lb % (unsigned)D.dense_tiles);
         int p = D.tile_major ? (int)(Lb % (unsigned)D.n_dense_pairs) : (int)(Lb / (unsigned)D.dense_tiles);
         // work order: the pairs of a band heaviest first, so that the workgroups still running when the launch drains are short ones.
-        // p is a WORK POSITION: the pinhole blocks find everything about it in k_pair_setup's descriptor; the other layouts read the
-        // work table entry (target, source, pair, -) themselves
-        if (LAYOUT == 1 && D.walk_blocks) dense_block_pinhole<2>(D, campos, p, dense_partials, tile, b, red, valid_lists, valid_counts, zn_lut);
-        else if (LAYOUT == 1) dense_block_pinhole<0>(D, campos, p, dense_partials, tile, b, red, valid_lists, valid_counts, zn_lut);     // `campos` carries the compact cache
-        else if (LAYOUT == 3) dense_block_pinhole<1>(D, campos, p, dense_partials, tile, b, red, valid_lists, valid_counts, zn_lut);
+        // p is a WORK POSITION: the pinhole blocks compute their item from it (dense_work_item), the other layouts read the work table entry
+        if (LAYOUT == 1 && D.walk_blocks) dense_block_pinhole<2>(D, campos, p, T, Tinv, dense_partials, tile, b, red, valid_lists, valid_counts, zn_lut);
+        else if (LAYOUT == 1) dense_block_pinhole<0>(D, campos, p, T, Tinv, dense_partials, tile, b, red, valid_lists, valid_counts, zn_lut);     // `campos` carries the compact cache
+        else if (LAYOUT == 3) dense_block_pinhole<1>(D, campos, p, T, Tinv, dense_partials, tile, b, red, valid_lists, valid_counts, zn_lut);
         else {
             const int4 w = D.dense_work[p];
             const int2 ij = make_int2(w.x, w.y);
@@ -1244,82 +1225,6 @@ __global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_fused_sweeps(Solve
     fused_item<LAYOUT>(BTBA_FUSED_ITEM_ARGS);
 }
 
-// The same items worked off by PERSISTENT workgroups: as many workgroups as the chip holds at once (6 per CU), each pulling the next item
-// of ITS XCD's sequence (the order and the per-XCD ranges of the one-workgroup-per-item launch: L2 locality unchanged) from atomic
-// cursors.  No slot stays empty between two items (measured: ~3 us per 39-us item while the hardware recycles a workgroup slot), and the
-// launch drains evenly: whoever is free takes the next item.
-// Cursors: ONE cursor per XCD was measured to be the bottleneck itself -- same-address atomics serialise at ~100 ns each, 1 260 items per
-// XCD are 126 us of cursor time in a 200-us launch, and the 192 workgroups of an XCD needed 20 us just to get their first item
-// (gpurun_out/r03_04).  So an XCD's sequence is dealt round-robin to kItemGroups sub-sequences (slot s belongs to group s mod 32) with a
-// cursor each, a workgroup draws from the group it shares with ~5 others and, when that is exhausted, from whichever group still has
-// items (one read of all 32 cursors, then a claim).  The next item is claimed when the current one STARTS and picked up when it ends.
-constexpr unsigned kItemGroups = 32;
-struct FusedArgs {
-    SolveDims D;
-    unsigned n_d, n_s;
-    const float4 *campos, *normals;
-    const int2 *dense_pairs;
-    const float *T, *Tinv;
-    float *dense_partials;
-    const float4 *corr;
-    const uint32_t *pair_offsets;
-    float *sparse_partials;
-    const uint32_t *valid_lists;
-    const int *valid_counts;
-};
-template <int LAYOUT>
-__global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_fused_persist(FusedArgs args_in_kernarg_segment)
-{
-    __shared__ float red[kRedFloats];
-    __shared__ unsigned ctl[2];
-    extern __shared__ __attribute__((aligned(16))) float zn_lut[];
-    typedef const __attribute__((address_space(4))) FusedArgs *ArgPtr;
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 7u;
-    const unsigned n_items = ((ArgPtr)__builtin_amdgcn_kernarg_segment_ptr())->n_d + ((ArgPtr)__builtin_amdgcn_kernarg_segment_ptr())->n_s;
-    const unsigned Gx = (n_items - xcc + 7u) >> 3;               // items of this XCD: slots 0 .. Gx-1
-    unsigned *const cursors = ((ArgPtr)__builtin_amdgcn_kernarg_segment_ptr())->D.item_queue + kItemGroups * xcc;
-    // wave 0 does the claiming; `grp` (the group this workgroup draws from) and `pending` (the claim in flight: a position inside that group)
-    // are wave-uniform there
-    unsigned grp = ((blockIdx.x >> 3) / BTBA_FUSED_WAVES) % kItemGroups;
-    unsigned pending = 0;
-    if (threadIdx.x == 0) pending = atomicAdd(&cursors[grp], 1u);
-    for (;;) {
-        ArgPtr A = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(A));                              // opaque: nothing read through A is loop-invariant to the compiler
-        if (threadIdx.x < 64) {
-            const unsigned lane = threadIdx.x;
-            unsigned slot = kItemGroups * (unsigned)__builtin_amdgcn_readfirstlane((int)pending) + grp;
-            if (slot >= Gx) {
-                // own group exhausted: ONE coalesced read of all 32 cursors (lane = group), then a claim from a group that still has items,
-                // searched from a rotation that differs from workgroup to workgroup (so that the thieves do not all descend on the same group)
-                slot = 0xFFFFFFFFu;
-                for (unsigned tries = 0; tries < 8u && slot == 0xFFFFFFFFu; tries++) {
-                    const unsigned c = lane < kItemGroups ? __hip_atomic_load(&cursors[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFu;
-                    const unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(lane < kItemGroups && kItemGroups * c + lane < Gx);
-                    if (mask == 0u) break;                       // every cursor is past its group's last slot
-                    const unsigned rot = (blockIdx.x * 7u + tries * 13u + grp + 1u) % kItemGroups;
-                    const unsigned turned = rot ? (mask >> rot) | (mask << (kItemGroups - rot)) : mask;
-                    grp = (rot + (unsigned)__builtin_ctz(turned)) % kItemGroups;
-                    unsigned got = 0;
-                    if (lane == 0) got = atomicAdd(&cursors[grp], 1u);
-                    const unsigned s2 = kItemGroups * (unsigned)__builtin_amdgcn_readfirstlane((int)got) + grp;
-                    if (s2 < Gx) slot = s2;
-                }
-            }
-            if (lane == 0) ctl[0] = slot;
-        }
-        __syncthreads();
-        const unsigned slot = ctl[0];
-        if (slot == 0xFFFFFFFFu) break;                          // this XCD's items are done
-        if (threadIdx.x == 0) pending = atomicAdd(&cursors[grp], 1u);
-        const unsigned g = 8u * slot + xcc;
-        fused_item<LAYOUT>(*(const SolveDims *)&A->D, A->n_d, A->n_s, g, A->campos, A->normals, A->dense_pairs, A->T, A->Tinv, A->dense_partials,
-                           A->corr, A->pair_offsets, A->sparse_partials, A->valid_lists, A->valid_counts, red, zn_lut);
-        __syncthreads();                                      // the item's LDS (red, tables, ctl) is free again
-    }
-}
 #undef BTBA_FUSED_ITEM_ARGS
 
 // ---- system solve -------------------------------------------------------------------------------

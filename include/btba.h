@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BTBA_VERSION 103     /* 103: btba_params.reduction_mode, btba_stats.ms_pair_setup / n_setup_launches, BTBA_FLAG_KEYED_CORR = 4096, btba_workspace_set_option */
+#define BTBA_VERSION 103     /* 103: btba_params.reduction_mode, BTBA_FLAG_KEYED_CORR = 4096, btba_workspace_set_option */
 
 #if defined(__GNUC__)
 #define BTBA_API __attribute__((visibility("default")))
@@ -141,8 +141,6 @@ typedef struct btba_stats {
     int32_t fused_sweeps;         /* 1: sparse + dense sweeps ran as ONE launch (timed as ms_dense_sweep) */
     int32_t cache_frames_built;   /* optimize_frames: frames cached in this call (n_frames unless keyed and already cached) */
     int32_t corr_pairs_uploaded;  /* optimize_frames: frame-pair segments that crossed PCIe in this call (all P unless BTBA_FLAG_KEYED_CORR) */
-    float ms_pair_setup;          /* sum over GN iterations of k_pair_setup (per-pair relative poses + live-block lists of the pinhole sweeps) */
-    int32_t n_setup_launches;
 } btba_stats;
 
 /* Per-instance, per-GN-iteration trace record (floats), written when BTBA_FLAG_TRACE is set.
@@ -193,7 +191,6 @@ enum {
     BTBA_OPT_BIG_ASSEMBLY         = 5,  /* 1 (default): many-workgroup reduction / assembly from 24 frames on; 0: one workgroup. env BTBA_NO_BIG_ASSEMBLY */
     BTBA_OPT_OVERLAP_GROUPS       = 6,  /* instance groups of BTBA_FLAG_OVERLAP, 1 .. 8 (default 2).                            env BTBA_GROUPS         */
     BTBA_OPT_OVERLAP_EQUAL_PRIO   = 7,  /* 1: the groups' streams get equal priority (default 0: lowest for groups >= 1).        env BTBA_GROUP_PRIO=e   */
-    BTBA_OPT_PERSISTENT           = 9,  /* 1 (default): big batches run the fused sweep as persistent workgroups pulling items from per-XCD cursors; 0: one workgroup per item. env BTBA_NO_PERSISTENT */
     BTBA_OPT_KEYED_CORR_MIN_BYTES = 8   /* BTBA_FLAG_KEYED_CORR is ignored below this many bytes of correspondences (default 1 MiB). env of the same name */
 };
 BTBA_API int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value);

@@ -38,7 +38,7 @@ def child(lib):
         st = ws.collect_stats()
         p = poses_d.cpu().numpy()
         out[tag] = {"ms_per_step": round(dt * 1e3, 4), "sweep_us": round(st["ms_dense_sweep"] / max(st["n_dense_launches"], 1) * 1e3, 2),
-                    "solve_us": round(st["ms_system_solve"] / max(st["n_solve_launches"], 1) * 1e3, 2), "setup_us": round(st["ms_pair_setup"] / max(st["n_setup_launches"], 1) * 1e3, 2), "tiles": st["dense_tiles"],
+                    "solve_us": round(st["ms_system_solve"] / max(st["n_solve_launches"], 1) * 1e3, 2), "tiles": st["dense_tiles"],
                     "git_per_s": round(B * 7 / dt, 0), "checksum": float(np.abs(p).sum()), "finite": bool(np.isfinite(p).all())}
     print(json.dumps(out), flush=True)
 

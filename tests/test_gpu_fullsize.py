@@ -137,7 +137,6 @@ def test_dead_block_skip_is_exact(gpu):
     lo = np.where(zb > 0, zb, np.inf).min(-1); hi = np.where(zb > 0, zb, -np.inf).max(-1)
     assert np.array_equal(rng[..., 0], lo) and np.array_equal(rng[..., 1], hi)
     # ... and the valid-pixel lists: supplied lists == lists built inside the solve, and they are the ascending valid pixels
-    from bundletrack_amd import _lib
     bl = gpu.BatchSolver(gpu.ws, flags=_lib.FLAG_COMPACTION)
     pa, pb_ = gpu.torch.from_numpy(np.stack([pb.poses_init for pb in pbs])).to(gpu.dev), gpu.torch.from_numpy(np.stack([pb.poses_init for pb in pbs])).to(gpu.dev)
     bl.solve_zn(zn_d, pbs[0].H, pbs[0].W, pbs[0].K, corr_d, offs_d, mx, pa)
