@@ -52,6 +52,21 @@ def generate_instances(cfg, ids, masked=False):
     jobs = [(cfg["K"], cfg["m"], S.config_seed(5 if cfg["config"] == 3 else cfg["config"], i), masked) for i in ids]
     nproc = min(len(jobs), 8, max(1, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     nproc = int(os.environ.get("BTBA_BENCH_NPROC", nproc))      # 1 under rocprofv3 --pmc (no child processes)
+    cache = os.environ.get("BTBA_BENCH_CACHE")                  # profiling passes of one workload: generate once, reuse (scripts/profile_bench.sh)
+    if cache:
+        import pickle
+        key = (cfg["K"], cfg["m"], tuple(ids), bool(masked))
+        if os.path.exists(cache):
+            k2, data = pickle.load(open(cache, "rb"))
+            if k2 == key:
+                return data
+        data = [_gen(j) for j in jobs] if nproc <= 1 else None
+        if data is None:
+            import multiprocessing as mp
+            with mp.get_context("spawn").Pool(nproc) as pool:
+                data = pool.map(_gen, jobs)
+        pickle.dump((key, data), open(cache, "wb"))
+        return data
     if nproc > 1:
         import multiprocessing as mp
         with mp.get_context("spawn").Pool(nproc) as pool:
@@ -69,16 +84,21 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def profiled_counters(config, B, masked, float4_cache, fused):
-    """PMC summary of the dominant kernel written by scripts/summarize_profiles.py -- only if it was taken on THESE sources and this workload."""
+def profiled_counters(config, B, masked, float4_cache, fused, distinct=None, entryj=False):
+    """PMC summary of the dominant kernel written by scripts/summarize_profiles.py -- only if it was taken on THESE sources and THIS workload
+    (config, instances, distinct instances, mask, cache and correspondence layout); profiles/sweep_counters.json holds one record per workload."""
     tp = os.path.join(ROOT, "profiles", "sweep_counters.json")
     try:
         tj = json.load(open(tp))
     except Exception:
         return None
-    same = (tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("instances") == B and tj.get("config") == config
-            and bool(tj.get("fused")) == fused and bool(tj.get("masked")) == masked and bool(tj.get("float4_cache")) == float4_cache)
-    return tj if same else None
+    records = tj.get("records", [tj]) if isinstance(tj, dict) else tj
+    for r in records:
+        if (r.get("kernel_source_hash") == kernel_source_hash() and r.get("instances") == B and r.get("config") == config
+                and bool(r.get("fused")) == fused and bool(r.get("masked")) == masked and bool(r.get("float4_cache")) == float4_cache
+                and r.get("distinct") == distinct and bool(r.get("entryj")) == bool(entryj)):
+            return r
+    return None
 
 
 def _cpu_model():
@@ -187,6 +207,25 @@ def measured_copy_bandwidth(torch, dev, nbytes=1 << 30, reps=10):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started by hand: re-run this command line under torch.distributed.run with N ranks on this node and pass
+    rank 0's JSON line through.  Refuses to pretend: fewer than N visible GPUs is an error unless BTBA_DIST_BACKEND=gloo is forced
+    (the functional test that runs two ranks on a one-GPU box)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and os.environ.get("BTBA_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node (set BTBA_DIST_BACKEND=gloo to share GPUs in a functional test)")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    note(f"--gpus {n} without a launcher: starting {n} ranks under torch.distributed.run on port {port}")
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
 _T0 = time.perf_counter()
 
 
@@ -198,7 +237,7 @@ def note(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=250, help="timed steps (default: ~0.35 s of GPU time at c3 x 32, long enough for an external busy sampler to see)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--instances", type=int, default=32, help="instances per GPU")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
@@ -208,7 +247,13 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--float4-cache", action="store_true", help="reference-layout float4 camPos + float4 normal caches (32 B/pixel) instead of the compact (z, n) cache")
     ap.add_argument("--latency", action="store_true", help="also measure single-instance latency mode (extra field)")
+    ap.add_argument("--entryj", action="store_true", help="keep the device-resident correspondences as 32-byte EntryJ instead of packing them to 24-byte records before the timed region")
+    ap.add_argument("--corr24", action="store_true", help="24-byte records also with --masked (default there: EntryJ, which measured 4 %% faster on the masked launch: profiles/r03)")
     args = ap.parse_args()
+
+    # --gpus N without a launcher: become the launcher (one rank per GPU under torch.distributed.run, RCCL via backend nccl)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
 
     import torch
     from bundletrack_amd import _lib, sharding
@@ -257,13 +302,20 @@ def main():
     # what the solve derives from the caches alone (per-block depth ranges; the valid-pixel lists of masked frames) belongs to the frame
     # cache: built here, with the caches, once
     aux_d = None if args.float4_cache else bs.cache_aux(cam_d, valid_lists=bool(bs.params.flags & _lib.FLAG_COMPACTION))
+    # ... and so does the device layout of the correspondences: a batch that stays resident keeps them as 24-byte records (pos_i, pos_j --
+    # the frame indices are implied by the pair-major segment), packed once here from the EntryJ wire format (btba_pack_correspondences24)
+    use_c24 = not args.entryj and not args.float4_cache and n_corr > 0 and (args.corr24 or not args.masked)
+    if use_c24:
+        aux_d["corr24"], order_flag = bs.pack_correspondences24(corr_d, offs_d, mx, K, check_order=True)
+        torch.cuda.synchronize()
+        assert int(order_flag.cpu()[0]) == 0, "synthetic correspondences are pair-major"
 
     def step():
         poses_d.copy_(poses0)                               # pose in ...
         if args.float4_cache:
             bs.solve(cam_d, nrm_d, intr, corr_d, offs_d, mx, poses_d)   # ... pose out (7 GN iterations per instance)
         else:
-            bs.solve_zn(cam_d, pick[0]["H"], pick[0]["W"], pick[0]["K"], corr_d, offs_d, mx, poses_d, aux=aux_d)
+            bs.solve_zn(cam_d, pick[0]["H"], pick[0]["W"], pick[0]["K"], None if use_c24 else corr_d, offs_d, mx, poses_d, aux=aux_d, corr_stride=corr_d.shape[1])
 
     note("warm-up")
     for _ in range(args.warmup):
@@ -302,7 +354,8 @@ def main():
                                    f"{'~5%-valid object mask' if args.masked else '100%-valid (object + background)'}, 7 GN x 5 PCG, pair policy TARGET_LOWER",
                        "keyframes": K, "corr_per_pair": cfg["m"], "instances_per_gpu": B, "distinct_instances_per_gpu": n_distinct,
                        "gn_iters": int(bs.params.n_gn_iters), "pcg_iters": int(bs.params.n_pcg_iters),
-                       "dense_tiles": st["dense_tiles"], "sparse_chunks": st["sparse_chunks"], "frame_cache": "float4 camPos + float4 normal (32 B/px)" if args.float4_cache else "compact z + normal (16 B/px)", "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+                       "dense_tiles": st["dense_tiles"], "sparse_chunks": st["sparse_chunks"], "frame_cache": "float4 camPos + float4 normal (32 B/px)" if args.float4_cache else "compact z + normal (16 B/px)",
+                       "correspondences": "24-byte records (pos_i, pos_j), packed once from EntryJ before the timed region" if use_c24 else "EntryJ (32 B)", "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "per_rank": [{"seconds": round(s, 6), "gn_iters": g, "pose_checksum": round(c, 6)} for (s, g), c in zip(per_rank, sharding.gather_throughput.checksums)],
             "collective": {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
                            "what": "one all-gather of {seconds, GN iterations, pose checksum} per rank after the timed region; no data-path collective"},
@@ -321,14 +374,29 @@ def main():
             flops_alg = 200.0 * pair_pixels + (120.0 * n_corr if fused else 0.0)
             bytes_alg = 64 * pair_pixels + (32 * n_corr if fused else 0)
             tflops = flops_alg / (avg_ms * 1e-3) / 1e12
-            pc = profiled_counters(args.config, B, args.masked, args.float4_cache, fused)
+            pc = profiled_counters(args.config, B, args.masked, args.float4_cache, fused, n_distinct, not use_c24)
             traffic = pc.get("hbm_bytes_per_launch") if pc else None
-            res["roofline"] = {"bound": "valu", "kernel": "k_fused_sweeps (dense + sparse workgroups)" if fused else "k_dense_sweep",
-                               "achieved": round(tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
-                               "traffic": traffic, "algorithmic_flops_per_launch": flops_alg, "pair_pixels_per_launch": pair_pixels,
-                               "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_dense_launches"],
-                               "note": "fp32 vector (VALU) roofline: algorithmic flops / launch time against 157.3 TFLOP/s (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz = the "
-                                       "dense f32 MFMA peak); durations from hipEvents on the workspace stream inside the timed region"}
+            corr_bytes = 24 if use_c24 else 32
+            if args.masked:
+                # object-masked frames (the tracker's operating point): the launch streams every correspondence once and touches ~5 % of
+                # the pixels -- it is bound by that stream, not by the vector pipe.  Algorithmic bytes (SURVEY.md 8(d)'s 32 B per
+                # correspondence; every valid cached pixel once, 16 B) over the launch time against the HBM peak; the 24-byte device
+                # records do the same algorithmic work on 3/4 of the correspondence bytes, `layout_bytes_per_launch` is what they move.
+                alg = 32 * n_corr + 16 * int(nvalid.sum())
+                gbs = alg / (avg_ms * 1e-3) / 1e9
+                res["roofline"] = {"bound": "hbm", "kernel": "k_fused_sweeps (dense + sparse workgroups)" if fused else "k_dense_sweep",
+                                   "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                   "algorithmic_bytes_per_launch": alg, "layout_bytes_per_launch": corr_bytes * n_corr + 16 * int(nvalid.sum()),
+                                   "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_dense_launches"],
+                                   "valu_context": {"achieved_TFLOPs": round(tflops, 2), "frac_of_vector_peak": round(tflops / VALU_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": flops_alg},
+                                   "note": "HBM roofline: (32 B x correspondences + 16 B x valid cached pixels) / launch time against 8 TB/s; durations from hipEvents on the workspace stream inside the timed region"}
+            else:
+                res["roofline"] = {"bound": "valu", "kernel": "k_fused_sweeps (dense + sparse workgroups)" if fused else "k_dense_sweep",
+                                   "achieved": round(tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
+                                   "traffic": traffic, "algorithmic_flops_per_launch": flops_alg, "pair_pixels_per_launch": pair_pixels,
+                                   "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_dense_launches"],
+                                   "note": "fp32 vector (VALU) roofline: algorithmic flops / launch time against 157.3 TFLOP/s (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz = the "
+                                           "dense f32 MFMA peak); durations from hipEvents on the workspace stream inside the timed region"}
             if pc and pc.get("valu_busy_frac") is not None:
                 res["roofline"]["valu_issue"] = {"busy_frac": pc["valu_busy_frac"], "cycles_per_instruction": pc.get("valu_cycles_per_inst"),
                                                  "dual_issued_frac": pc.get("valu_dual_issued_frac"), "waves_per_simd": pc.get("waves_per_simd"),
@@ -340,7 +408,7 @@ def main():
                   "note": "SURVEY.md 8(d) accounting; it exceeds the HBM peak because every pair is charged both frames while a frame is reused by its 14 pairs "
                           "out of L2 -- not a bandwidth measurement"}
             if traffic:
-                compulsory = (32 if args.float4_cache else 16) * B * K * npix + (32 * n_corr if fused else 0)       # every cached pixel and every correspondence once
+                compulsory = (32 if args.float4_cache else 16) * (int(nvalid.sum()) if args.masked else B * K * npix) + (corr_bytes * n_corr if fused else 0)       # every (valid) cached pixel and every correspondence once
                 hb.update({"hbm_traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1), "hbm_traffic_frac_of_peak": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            "algorithmic_over_traffic": round(bytes_alg / traffic, 2), "traffic_over_compulsory": round(traffic / compulsory, 2),
                            "source": pc.get("source_hbm")})
@@ -361,9 +429,11 @@ def main():
                 "sparse_alg_GBps": (round(32 * n_corr / max(st["ms_sparse_sweep"] / max(st["n_sparse_launches"], 1), 1e-9) / 1e6, 1) if st["n_sparse_launches"] else None)}
         elif cfg["w_dense"] == 0.0 and not args.no_kernel_timing and st["n_sparse_launches"] > 0:
             avg_ms = st["ms_sparse_sweep"] / st["n_sparse_launches"]
-            achieved = 32 * n_corr / (avg_ms * 1e-3) / 1e9
+            achieved = 32 * n_corr / (avg_ms * 1e-3) / 1e9       # 32 B per correspondence (the 24-byte device records move 3/4 of that)
+            pc = profiled_counters(args.config, B, args.masked, args.float4_cache, False, n_distinct, not use_c24)
             res["roofline"] = {"bound": "hbm", "kernel": "k_sparse_sweep", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": 32 * n_corr,
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pc.get("hbm_bytes_per_launch") if pc else None, "algorithmic_bytes_per_launch": 32 * n_corr,
+                               "layout_bytes_per_launch": (24 if use_c24 else 32) * n_corr,
                                "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_sparse_launches"]}
         if args.latency:
             bs1 = BatchSolver(ws, weight_dense_depth=cfg["w_dense"])
@@ -371,12 +441,15 @@ def main():
             c1d = torch.from_numpy(c1.view(np.uint8).reshape(1, -1, 32)).to(dev)
             o1d = torch.from_numpy(o1.astype(np.int32)).to(dev)
             p1 = poses0[:1].clone()
+            aux1 = None if aux_d is None else {k: v[:K] for k, v in aux_d.items() if k != "corr24"}
+            if use_c24:
+                aux1["corr24"] = bs1.pack_correspondences24(c1d, o1d, m1, K)
 
             def one(p):
                 if args.float4_cache:
                     bs1.solve(cam_d[:1], nrm_d[:1], intr, c1d, o1d, m1, p)
                 else:
-                    bs1.solve_zn(cam_d[:1], pick[0]["H"], pick[0]["W"], pick[0]["K"], c1d, o1d, m1, p, aux=None if aux_d is None else {k: v[:K] for k, v in aux_d.items()})
+                    bs1.solve_zn(cam_d[:1], pick[0]["H"], pick[0]["W"], pick[0]["K"], None if use_c24 else c1d, o1d, m1, p, aux=aux1, corr_stride=c1d.shape[1])
             for _ in range(5):
                 p1.copy_(poses0[:1]); one(p1)
             torch.cuda.synchronize()

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
     "btba_process_depth", "btba_depth_to_normals",
-    "btba_build_cache_zn", "btba_pack_zn", "btba_solve_batch_zn", "btba_zn_block_ranges", "btba_zn_valid_lists", "btba_solve_batch_zn_aux",
+    "btba_build_cache_zn", "btba_pack_zn", "btba_solve_batch_zn", "btba_zn_block_ranges", "btba_zn_valid_lists", "btba_solve_batch_zn_aux", "btba_pack_correspondences24",
 ]
 
 
@@ -70,7 +70,7 @@ class Stats(C.Structure):
 
 class ZnAux(C.Structure):
     """btba_zn_aux (include/btba.h): device pointers to data derived from compact caches alone."""
-    _fields_ = [("block_ranges", C.c_void_p), ("valid_lists", C.c_void_p), ("valid_counts", C.c_void_p)]
+    _fields_ = [("block_ranges", C.c_void_p), ("valid_lists", C.c_void_p), ("valid_counts", C.c_void_p), ("corr24", C.c_void_p)]
 
 
 class TraceLayout(C.Structure):
@@ -139,7 +139,7 @@ def lib() -> C.CDLL:
         L.btba_strerror.restype = C.c_char_p
         L.btba_strerror.argtypes = [C.c_int]
         for name in EXPORTED_SYMBOLS:
-            if "BTBA_LIB_PATH" in os.environ and name == "btba_workspace_set_option" and not hasattr(L, name):
+            if "BTBA_LIB_PATH" in os.environ and name in ("btba_workspace_set_option", "btba_pack_correspondences24") and not hasattr(L, name):
                 continue               # developer A/B against a build from before version 103
             getattr(L, name)           # AttributeError if the ABI and the header drift apart
         L.btba_workspace_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p]
@@ -178,6 +178,8 @@ def lib() -> C.CDLL:
         L.btba_solve_batch_zn.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.btba_zn_block_ranges.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        if hasattr(L, "btba_pack_correspondences24"):
+            L.btba_pack_correspondences24.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.btba_zn_valid_lists.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.btba_solve_batch_zn_aux.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(ZnAux),
                                               C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]

@@ -100,9 +100,9 @@ struct btba_workspace {
     // keyed correspondence cache (BTBA_FLAG_KEYED_CORR): the EntryJ segment of a frame PAIR stays on the device under the pair's two
     // frame keys; a sliding window then uploads only the new frame's K - 1 segments
     struct CorrSeg { uint32_t off = 0, count = 0; };
-    DevBuf corr_pool, corr_desc;
+    DevBuf corr_pool, corr_desc, corr_stage_dev, corr_lens;   // pool of 24-byte correspondences; staging of a call's fresh EntryJ segments; the window's segment lengths
     std::map<std::pair<uint64_t, uint64_t>, CorrSeg> corr_index;
-    size_t corr_pool_used = 0;                              // in EntryJ
+    size_t corr_pool_used = 0;                              // in entries
     void *corr_stage = nullptr; size_t corr_stage_cap = 0;  // pinned host staging of the segments uploaded by one call
     DevBuf ransac;                                          // btba_ransac_pairs staging (points, samples, per-trial poses and counts, results)
     DevBuf ransac_u;                                        // the reference's sample stream: n_trials x 3 uniforms (btba_xorwow.hpp), kept per (seed, n_trials)
@@ -222,7 +222,7 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A, &ws->solve_tab,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts, &ws->block_ranges,
-                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc };
+                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc, &ws->corr_stage_dev, &ws->corr_lens };
     for (auto b : bufs) b->release();
     if (ws->corr_stage) (void)hipHostFree(ws->corr_stage);
     for (auto st : ws->aux_streams) if (st) (void)hipStreamDestroy(st);
@@ -419,7 +419,8 @@ struct ZnSpec {      // compact cache + the full-res geometry it encodes
 static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int N, int Hd, int Wd, const float *intr,
                          const float *campos, const float *normals, const ZnSpec &Z, const btba_entryj *corr, int64_t corr_stride,
                          const uint32_t *pair_offsets, uint32_t max_corr_per_pair,
-                         const int32_t *dense_pairs, int Pd_in, float *poses, float *trace, int *order_flag = nullptr)
+                         const int32_t *dense_pairs, int Pd_in, float *poses, float *trace, int *order_flag = nullptr,
+                         bool corr24 = false, const uint32_t *pair_lens = nullptr)
 {
     if (!ws || !prm || B < 1 || N < 2 || Hd < 2 || Wd < 2 || !intr || !poses) return BTBA_EINVAL;
     if (prm->n_gn_iters < 1 || prm->n_pcg_iters < 0) return BTBA_EINVAL;   // MLIB_ASSERT, CUDASolverBundling.cpp:194
@@ -534,6 +535,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;
     D.order_flag = order_flag;
+    D.corr24 = corr24 ? 1 : 0;
+    D.pair_lens = pair_lens;
     if (Pd > 0) { D.dense_work = reinterpret_cast<const int4 *>(ws->dense_pairs.as<int32_t>() + ws->dense_work_offset); D.work_formula = ws->work_formula; }      // work position -> (target, source, pair, -)
     D.tile_major = ws->tune.tile_major ? 1 : 0;
     D.walk_blocks = (Wd % 8 == 0 && Hd % 8 == 0 && Wd + Hd <= 1024 && ws->tune.block_walk) ? 1 : 0;
@@ -671,7 +674,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             const float4 *zn_h = use_zn ? reinterpret_cast<const float4 *>(Z.zn) + b0 * N * npix : nullptr;
             const uint32_t *vl_h = compaction ? lists_base + b0 * N * npix : nullptr;
             const int *vc_h = compaction ? counts_base + b0 * N : nullptr;
-            const float4 *corr_h = corr ? reinterpret_cast<const float4 *>(corr) + 2 * b0 * (size_t)corr_stride : nullptr;
+            // (24-byte correspondences live in 64-entry groups counted from the start of the array: the half keeps the array's base and its first instance's entry offset)
+            const float4 *corr_h = corr ? (corr24 ? reinterpret_cast<const float4 *>(corr) : reinterpret_cast<const float4 *>(corr) + 2 * b0 * (size_t)corr_stride) : nullptr;
             const uint32_t *off_h = pair_offsets ? pair_offsets + b0 * (P + 1) : nullptr;
             float *x_h = ws->x.as<float>() + 6 * b0 * N, *T_h = ws->T.as<float>() + 16 * b0 * N, *Ti_h = ws->Tinv.as<float>() + 16 * b0 * N;
             float *sp_h = ws->sparse_part.as<float>() + b0 * P * chunks * kSparseVals;
@@ -680,6 +684,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             float *tr_h = trace ? trace + b0 * (size_t)D.n_gn * D.trace_record : nullptr;
             size_t slot;
             SolveDims Dh = D;                                   // the sweeps' view of this half
+            if (Dh.pair_lens) Dh.pair_lens += b0 * P;
+            Dh.corr_entry0 = corr24 ? (int64_t)b0 * corr_stride : 0;
             if (Dh.block_ranges) Dh.block_ranges += b0 * N * (size_t)((Wd / 8) * (Hd / 8));
 #ifdef BTBA_WG_TRACE
             static DevBuf wg_trace_buf;
@@ -711,7 +717,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             } else {
                 if (use_sparse) {
                     if ((rc = time_begin(ws, timing_it, 1, &slot, H.st))) return rc;
-                    k_sparse_sweep<<<dim3(chunks, P, H.nb), kBlock, 0, H.st>>>(D, corr_h, off_h, T_h, sp_h);
+                    k_sparse_sweep<<<dim3(chunks, P, H.nb), kBlock, 0, H.st>>>(Dh, corr_h, off_h, T_h, sp_h);
                     if ((rc = time_end(ws, slot, H.st))) return rc;
                 }
                 if (use_dense) {
@@ -957,14 +963,26 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     // the window's P segments from the pool into the contiguous pair-major array the sweeps read, rewriting imgIdx_i / imgIdx_j to
     // the frames' CURRENT window positions (they shift as the window slides) and checking the new segments' own indices.
     int corr_pairs_uploaded = P;
+    uint32_t stage_longest_fresh = 0;
+    std::vector<uint32_t> offsets_up;                           // the offsets array as uploaded (pool offsets on the keyed path)
     // (below 1 MB the whole array crosses PCIe faster than the bookkeeping runs)
     const size_t kc_min = ws->tune.keyed_corr_min_bytes;                  // tests lower the threshold (BTBA_OPT_KEYED_CORR_MIN_BYTES)
     bool use_corr_cache = frame_keys != nullptr && trust && ws_in && (prm.flags & BTBA_FLAG_KEYED_CORR) && kept > 0 && (size_t)kept * sizeof(btba_entryj) >= kc_min;
-    std::vector<uint32_t> desc;                                 // outlives the asynchronous copy (the call ends with a synchronisation)
+    // Keyed path: the pool holds 24-BYTE correspondences (pos_i, pos_j: the frame indices are implied by the segment and would have to be
+    // rewritten whenever the window slides); the sweeps read the window's segments where they lie in the pool (offset + length per pair),
+    // nothing is gathered.  A fresh segment goes host -> pinned staging -> device staging (EntryJ) -> k_pack_corr24 -> pool, and that
+    // kernel checks its entries against (i, j).  The index is committed only after every copy and launch of this call has been
+    // enqueued: an error on the way leaves no entry behind that points at unwritten pool space.
+    std::vector<uint32_t> desc, lens;                           // outlive the asynchronous copies (the call ends with a synchronisation)
+    std::vector<std::pair<std::pair<uint64_t, uint64_t>, btba_workspace::CorrSeg>> fresh_index;
+    size_t fresh_entries = 0;
+    bool corr_in_pool = false;
     auto upload_inputs = [&]() -> hipError_t {
         hipError_t r;
+        corr_in_pool = false;
+        fresh_index.clear(); fresh_entries = 0;
+        std::vector<uint32_t> offs_up(offsets);                 // what the sweeps get: pair-major offsets, or pool offsets + lens
         if (use_corr_cache && trust) {
-            desc.assign(4 * (size_t)P, 0u);                        // per pair: source offset in the pool, destination offset, length, (i << 16 | j) | fresh << 31
             size_t need = 0;
             for (int pass = 0; pass < 2; pass++) {                  // pass 1 only after the pool had to be reset
                 need = 0;
@@ -975,12 +993,12 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
                         auto it = ws->corr_index.find({ frame_keys[i], frame_keys[j] });
                         if (cnt && (it == ws->corr_index.end() || it->second.count != cnt)) need += cnt;
                     }
-                const size_t cap = ws->corr_pool.cap / sizeof(btba_entryj);
+                const size_t cap = ws->corr_pool.cap / 24 >= 64 ? ws->corr_pool.cap / 24 - 64 : 0;      // (the last 64-entry group may be partly used)
                 if (ws->corr_pool_used + need <= cap) break;
                 // does not fit: start over with an empty pool (sized for a few windows) -- this call then uploads everything once
                 ws->corr_index.clear();
                 ws->corr_pool_used = 0;
-                if (int rc2 = ws->corr_pool.ensure(sizeof(btba_entryj) * std::max<size_t>(16 * (size_t)kept, 1u << 20))) { (void)rc2; return hipErrorOutOfMemory; }      // ~16 windows' worth: resets are rare
+                if (ws->corr_pool.ensure(24 * (std::max<size_t>(16 * (size_t)kept, 1u << 16) + 64)) != BTBA_OK) return hipErrorOutOfMemory;      // ~16 windows' worth: resets are rare
             }
             corr_pairs_uploaded = 0;
             // the new segments are packed into ONE pinned staging buffer and cross PCIe in one copy (a pageable hipMemcpyAsync per
@@ -992,41 +1010,65 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
                 if ((r = hipHostMalloc(&ws->corr_stage, want, hipHostMallocDefault)) != hipSuccess) return r;
                 ws->corr_stage_cap = want;
             }
+            if (ws->corr_stage_dev.ensure(sizeof(btba_entryj) * (need ? need : 1)) != BTBA_OK) return hipErrorOutOfMemory;
             const size_t pool_base = ws->corr_pool_used;
             size_t staged = 0;
+            uint32_t longest_fresh = 0;
+            desc.clear();
+            lens.assign((size_t)P, 0u);
             int q = 0;
             for (int i = 0; i < N; i++)
                 for (int j = i + 1; j < N; j++, q++) {
                     const uint32_t cnt = offsets[q + 1] - offsets[q];
-                    uint32_t src = 0, fresh = 0;
+                    uint32_t at = 0;
                     if (cnt) {
                         auto key = std::make_pair(frame_keys[i], frame_keys[j]);
                         auto it = ws->corr_index.find(key);
                         if (it == ws->corr_index.end() || it->second.count != cnt) {
-                            src = (uint32_t)(pool_base + staged);
+                            at = (uint32_t)(pool_base + staged);
                             std::memcpy(static_cast<btba_entryj *>(ws->corr_stage) + staged, corres_host + offsets[q], sizeof(btba_entryj) * cnt);
+                            desc.insert(desc.end(), { (uint32_t)staged, at, cnt, ((uint32_t)i << 16) | (uint32_t)j });      // staging offset -> pool offset
                             staged += cnt;
-                            ws->corr_index[key] = btba_workspace::CorrSeg{ src, cnt };
+                            fresh_index.push_back({ key, btba_workspace::CorrSeg{ at, cnt } });
+                            longest_fresh = std::max(longest_fresh, cnt);
                             corr_pairs_uploaded++;
-                            fresh = 1;
-                        } else src = it->second.off;
+                        } else at = it->second.off;
                     }
-                    desc[4 * (size_t)q] = src; desc[4 * (size_t)q + 1] = offsets[q]; desc[4 * (size_t)q + 2] = cnt; desc[4 * (size_t)q + 3] = ((uint32_t)i << 16) | (uint32_t)j | (fresh << 31);
+                    offs_up[q] = at;
+                    lens[q] = cnt;
                 }
-            if (staged && (r = hipMemcpyAsync(ws->corr_pool.as<btba_entryj>() + pool_base, ws->corr_stage, sizeof(btba_entryj) * staged, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
-            ws->corr_pool_used += staged;
-            if (ws->corr_desc.ensure(sizeof(uint32_t) * desc.size()) != BTBA_OK) return hipErrorOutOfMemory;
-            if ((r = hipMemcpyAsync(ws->corr_desc.p, desc.data(), sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+            offs_up[P] = 0;
+            fresh_entries = staged;
+            if (staged) {
+                if ((r = hipMemcpyAsync(ws->corr_stage_dev.p, ws->corr_stage, sizeof(btba_entryj) * staged, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+                if (ws->corr_desc.ensure(sizeof(uint32_t) * desc.size()) != BTBA_OK) return hipErrorOutOfMemory;
+                if ((r = hipMemcpyAsync(ws->corr_desc.p, desc.data(), sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+            }
+            if (ws->corr_lens.ensure(sizeof(uint32_t) * (size_t)P) != BTBA_OK) return hipErrorOutOfMemory;
+            if ((r = hipMemcpyAsync(ws->corr_lens.p, lens.data(), sizeof(uint32_t) * (size_t)P, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+            corr_in_pool = true;
+            stage_longest_fresh = longest_fresh;
         } else if (kept && (r = hipMemcpyAsync(ws->corr.p, upload, sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
-        if ((r = hipMemcpyAsync(ws->offsets.p, offsets.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+        offsets_up.swap(offs_up);
+        if ((r = hipMemcpyAsync(ws->offsets.p, offsets_up.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
         std::memcpy(stage.data(), poses, sizeof(float) * 16 * N);
         stage[16 * (size_t)N] = 0.0f;
         return hipMemcpyAsync(ws->poses.p, stage.data(), sizeof(float) * stage.size(), hipMemcpyHostToDevice, ws->stream);
     };
     if ((e = upload_inputs()) != hipSuccess) return hip_fail(e);
-    if (use_corr_cache && trust)
-        k_gather_corr<<<P, 256, 0, ws->stream>>>(ws->corr_desc.as<uint4>(), reinterpret_cast<const uint4 *>(ws->corr_pool.p), reinterpret_cast<uint4 *>(ws->corr.p),
-                                                 reinterpret_cast<int *>(ws->poses.as<float>() + 16 * (size_t)N));
+    auto pack_fresh = [&]() -> hipError_t {                     // after upload_inputs: fresh segments staging -> pool (24 B), order check into the flag word
+        if (!corr_in_pool) return hipSuccess;
+        if (fresh_entries)
+            k_pack_corr24<<<dim3((stage_longest_fresh + 255u) / 256u, (unsigned)(desc.size() / 4)), 256, 0, ws->stream>>>(
+                ws->corr_desc.as<uint4>(), reinterpret_cast<const uint4 *>(ws->corr_stage_dev.p), reinterpret_cast<float2 *>(ws->corr_pool.p),
+                reinterpret_cast<int *>(ws->poses.as<float>() + 16 * (size_t)N));
+        hipError_t r = hipGetLastError();
+        if (r != hipSuccess) return r;
+        for (auto &kv : fresh_index) ws->corr_index[kv.first] = kv.second;      // committed: everything they point at has been enqueued
+        ws->corr_pool_used += fresh_entries;
+        return hipSuccess;
+    };
+    if ((e = pack_fresh()) != hipSuccess) return hip_fail(e);
     // the sources (caller's arrays, `offsets`, `scattered`, `stage`) outlive the synchronising end of this call; the sync only serves the upload timer
     if ((prm.flags & BTBA_FLAG_TIME_KERNELS) && (e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
     const auto tu1 = std::chrono::steady_clock::now();
@@ -1093,8 +1135,10 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     btba_stats S;
     int *order_flag = reinterpret_cast<int *>(ws->poses.as<float>() + 16 * (size_t)N);
     auto solve_and_read = [&]() -> int {
-        int r = solve_enqueue(ws, &prm, 1, N, Hd, Wd, intr, compact ? nullptr : ws->campos.as<float>(), compact ? nullptr : ws->normals.as<float>(), Z, ws->corr.as<btba_entryj>(), (int64_t)(kept ? kept : 1),
-                              ws->offsets.as<uint32_t>(), max_per_pair, pairs_ptr, n_pairs_dense, ws->poses.as<float>(), nullptr, trust ? order_flag : nullptr);
+        int r = solve_enqueue(ws, &prm, 1, N, Hd, Wd, intr, compact ? nullptr : ws->campos.as<float>(), compact ? nullptr : ws->normals.as<float>(), Z,
+                              corr_in_pool ? ws->corr_pool.as<btba_entryj>() : ws->corr.as<btba_entryj>(), (int64_t)(kept ? kept : 1),
+                              ws->offsets.as<uint32_t>(), max_per_pair, pairs_ptr, n_pairs_dense, ws->poses.as<float>(), nullptr, (trust && !corr_in_pool) ? order_flag : nullptr,
+                              corr_in_pool, corr_in_pool ? ws->corr_lens.as<uint32_t>() : nullptr);
         if (r) return r;
         hipError_t he;
         if ((he = hipMemcpyAsync(out.data(), ws->poses.p, sizeof(float) * out.size(), hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) { g_last_hip_error = (int)he; return BTBA_EHIP; }
@@ -1112,7 +1156,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
             if ((rc = bucket_on_host())) { ws->always_time_region = false; return finish(rc); }
             max_per_pair = longest_segment();
             if ((rc = ws->corr.ensure(sizeof(btba_entryj) * (size_t)(kept ? kept : 1)))) { ws->always_time_region = false; return finish(rc); }
-            if ((e = upload_inputs()) != hipSuccess) { ws->always_time_region = false; return hip_fail(e); }
+            if ((e = upload_inputs()) != hipSuccess || (e = pack_fresh()) != hipSuccess) { ws->always_time_region = false; return hip_fail(e); }
             rc = solve_and_read();
         }
     }
@@ -1366,6 +1410,19 @@ int btba_zn_valid_lists(btba_workspace *ws, int n_frames_total, int Hd, int Wd, 
     return BTBA_OK;
 }
 
+int btba_pack_correspondences24(btba_workspace *ws, int n_instances, int n_frames, const btba_entryj *corr_dev, int64_t corr_stride,
+                                const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, float *corr24_dev, int32_t *order_flag_dev)
+{
+    DeviceGuard device_guard(ws);
+    if (!ws || n_instances < 1 || n_frames < 2 || n_frames > BTBA_MAX_FRAMES || !corr_dev || corr_stride < 1 || !pair_offsets_dev || !corr24_dev) return BTBA_EINVAL;
+    if (max_corr_per_pair == 0) return BTBA_OK;
+    const int P = n_frames * (n_frames - 1) / 2;
+    k_pack_corr24_batch<<<dim3((max_corr_per_pair + 255u) / 256u, (unsigned)P, (unsigned)n_instances), 256, 0, ws->stream>>>(
+        n_frames, P, corr_stride, pair_offsets_dev, reinterpret_cast<const uint4 *>(corr_dev), reinterpret_cast<float2 *>(corr24_dev), order_flag_dev);
+    HIP_TRY(hipGetLastError());
+    return BTBA_OK;
+}
+
 int btba_solve_batch_zn(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames, int H, int W, const float *K,
                         const float *zn_dev, const btba_entryj *corr_dev, int64_t corr_stride,
                         const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, const int32_t *dense_pairs, int n_dense_pairs,
@@ -1395,8 +1452,9 @@ int btba_solve_batch_zn_aux(btba_workspace *ws, const btba_params *params, int n
     ZnSpec Z;
     Z.zn = zn_dev; Z.H = H; Z.W = W; Z.K = K;
     if (aux) { Z.block_ranges = aux->block_ranges; if (aux->valid_lists && aux->valid_counts) { Z.lists = aux->valid_lists; Z.counts = aux->valid_counts; } }
-    return solve_enqueue(ws, params, n_instances, n_frames, Hd, Wd, intr, nullptr, nullptr, Z, corr_dev, corr_stride,
-                         pair_offsets_dev, max_corr_per_pair, dense_pairs, dense_pairs ? n_dense_pairs : -1, poses_dev, trace_dev);
+    const bool c24 = aux && aux->corr24;
+    return solve_enqueue(ws, params, n_instances, n_frames, Hd, Wd, intr, nullptr, nullptr, Z, c24 ? reinterpret_cast<const btba_entryj *>(aux->corr24) : corr_dev, corr_stride,
+                         pair_offsets_dev, max_corr_per_pair, dense_pairs, dense_pairs ? n_dense_pairs : -1, poses_dev, trace_dev, nullptr, c24);
 }
 
 

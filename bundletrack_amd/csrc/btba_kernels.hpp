@@ -77,6 +77,9 @@ struct SolveDims {
     const float2 *block_ranges;   // per (cache slot, 8 x 8 block): [min, max] valid depth (k_block_ranges); nullptr: no block is skipped
     int tile_major;      // dense work order inside an instance: 1 = (tile, pair) -- all pairs' band t of the images together -- 0 = (pair, tile)
     int *order_flag;     // non-null: the sparse sweep ORs 1 into it when an entry does not belong to the pair of its segment
+    int corr24;          // the correspondences are 24-byte (pos_i, pos_j) records (k_pack_corr24) instead of EntryJ
+    int64_t corr_entry0; // 24-byte layout: entry index of this launch's first instance in the array
+    const uint32_t *pair_lens;   // non-null: [B][P] segment lengths (segments not back to back: the keyed pool); else offsets[p + 1] - offsets[p]
     // compact (z, nx, ny, nz) frame cache: how a cached pixel maps back to camera space -- the arithmetic of k_build_cache
     float zn_ki[16];     // full-resolution intrinsicsInv (4x4 embedding, generic cofactor inverse)
     float zn_scale_w, zn_scale_h;   // (W-1)/(Wd-1), (H-1)/(Hd-1) of the nearest-neighbour resample
@@ -265,60 +268,43 @@ __global__ void __launch_bounds__(kBlock) k_pack_zn(size_t total, const float4 *
     zn[o] = make_float4(c.z, nr.x, nr.y, nr.z);
 }
 
-// ---- keyed correspondence cache: gather the window's pair segments from the pool ------------------------------------
-// grid (P) x 256.  desc[p] = (source offset in the pool, destination offset, length, i << 16 | j | fresh << 31), offsets in EntryJ.
-// An EntryJ is two uint4: (imgIdx_i, imgIdx_j, pos_i.x, pos_i.y) (pos_i.z, pos_j.xyz).  The indices are rewritten to the frames'
-// current window positions; a FRESH segment (uploaded by this call) whose valid entries do not carry (i, j) raises the order flag
-// (the caller's array was not pair-major: host bucketing takes over).  Invalid entries (imgIdx_i = 0xFFFFFFFF) stay invalid.
-__global__ void __launch_bounds__(256) k_gather_corr(const uint4 *__restrict__ desc, const uint4 *__restrict__ pool, uint4 *__restrict__ out, int *__restrict__ order_flag)
-{
-    const uint4 d = desc[blockIdx.x];
-    const uint32_t i = (d.w >> 16) & 0x7FFFu, j = d.w & 0xFFFFu;
-    const bool fresh = (d.w >> 31) != 0;
-    bool misplaced = false;
-    for (uint32_t e = threadIdx.x; e < d.z; e += 256) {
-        uint4 a = pool[2 * (size_t)(d.x + e)];
-        const uint4 b = pool[2 * (size_t)(d.x + e) + 1];
-        const bool valid = a.x != 0xFFFFFFFFu;
-        misplaced |= fresh & valid & ((a.x != i) | (a.y != j));
-        a.x = valid ? i : a.x;
-        a.y = valid ? j : a.y;
-        out[2 * (size_t)(d.y + e)] = a;
-        out[2 * (size_t)(d.y + e) + 1] = b;
-    }
-    if (misplaced) atomicOr(order_flag, 1);
-}
-
 // ---- sparse sweep -----------------------------------------------------------------------------
-// grid (sparse_chunks, P, B).  Workgroup (c, p, b) owns slice c of pair p's contiguous EntryJ
-// segment: two coalesced 16-byte loads per correspondence, 44 register accumulators per lane.
-__device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
-                                             const float *__restrict__ T, float *__restrict__ partials, int chunk, int p, int b, float *red)
+// grid (sparse_chunks, P, B).  Workgroup (c, p, b) owns slice c of pair p's contiguous correspondence segment, 44 register
+// accumulators per lane.  Two device layouts of a correspondence:
+//   EntryJ (32 B, the wire format, SIFTImageManager.h:44-59): two coalesced 16-byte loads; the frame indices are checked against the
+//            segment's pair on the fly (order_flag) -- what a call that uploads the caller's array runs on;
+//   C24    (24 B: pos_i, pos_j; invalid <=> first word 0xFFFFFFFF): the indices are implied by the segment, so device-RESIDENT
+//            correspondences (batches, the keyed pool) drop them -- a quarter of the stream that bounds the masked / feature-only launches
+//            (k_pack_corr24 converts and checks the order once).  Stored in groups of 64 entries as three planes of float2 --
+//            (pos_i.x, pos_i.y)[64], (pos_i.z, pos_j.x)[64], (pos_j.y, pos_j.z)[64] -- so that each of a wave's three 8-byte loads covers 512
+//            contiguous bytes: plain 24-byte records, three loads at stride 24, touch every cache line three times and measured SLOWER than
+//            EntryJ on the masked launch although they move a quarter less (52.0 vs 49.9 us, gpurun_out/r03_13).
+// float2 index of entry E's first plane (the other two follow at + 64 and + 128); E counts entries from the start of the array
+__device__ __forceinline__ size_t corr24_index(size_t E) { return (E >> 6) * 192 + (E & 63); }
+template <bool C24>
+__device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
+                                                  const float *__restrict__ T, float *__restrict__ partials, int chunk, int p, int b, float *red)
 {
     const unsigned tid = item_tid();
     int fi, fj;
     pair_from_index(p, D.n_frames, fi, fj);
     const auto off = as_const(pair_offsets + (size_t)b * (D.n_pairs + 1));
-    const uint32_t seg0 = off[p], seg1 = off[p + 1];
-    const uint32_t len = seg1 - seg0;
+    const uint32_t seg0 = off[p];
+    const uint32_t len = D.pair_lens ? as_const(D.pair_lens)[(size_t)b * D.n_pairs + p] : off[p + 1] - seg0;       // (pool segments are not back to back)
     const uint32_t per = (len + D.sparse_chunks - 1) / D.sparse_chunks;
     const uint32_t lo = seg0 + min(len, per * chunk), hi = seg0 + min(len, per * (chunk + 1));
     const Mat4 Ti = load_mat4_uniform(T + 16 * ((size_t)b * D.n_frames + fi));
     const Mat4 Tj = load_mat4_uniform(T + 16 * ((size_t)b * D.n_frames + fj));
-    const float4 *cb = corr + 2 * (size_t)b * D.corr_stride;
     float acc[kSparseVals];
 #pragma unroll
     for (int k = 0; k < kSparseVals; k++) acc[k] = 0.0f;
 
     const float delta2 = D.robust_delta * D.robust_delta;
-    bool misplaced = false;                       // an entry whose (imgIdx_i, imgIdx_j) is not this segment's pair
-    auto accumulate = [&](const float4 &q0, const float4 &q1, bool live) {
-        // q0 = (imgIdx_i, imgIdx_j, pos_i.x, pos_i.y)  q1 = (pos_i.z, pos_j.x, pos_j.y, pos_j.z)
-        const float m = (live && __float_as_uint(q0.x) != 0xFFFFFFFFu) ? 1.0f : 0.0f;      // EntryJ::isValid
-        misplaced |= (m != 0.0f) & ((__float_as_uint(q0.x) != (uint32_t)fi) | (__float_as_uint(q0.y) != (uint32_t)fj));
+    auto accumulate = [&](bool valid, float pix, float piy, float piz, float pjx, float pjy, float pjz) {
+        const float m = valid ? 1.0f : 0.0f;
         float wix, wiy, wiz, wjx, wjy, wjz;
-        xform_point(Ti, q0.z, q0.w, q1.x, wix, wiy, wiz);
-        xform_point(Tj, q1.y, q1.z, q1.w, wjx, wjy, wjz);
+        xform_point(Ti, pix, piy, piz, wix, wiy, wiz);
+        xform_point(Tj, pjx, pjy, pjz, wjx, wjy, wjz);
         // an invalid / out-of-range slot contributes exact zeros (its payload may be anything, even NaN)
         wix = m != 0.0f ? wix : 0.0f; wiy = m != 0.0f ? wiy : 0.0f; wiz = m != 0.0f ? wiz : 0.0f;
         wjx = m != 0.0f ? wjx : 0.0f; wjy = m != 0.0f ? wjy : 0.0f; wjz = m != 0.0f ? wjz : 0.0f;
@@ -340,18 +326,84 @@ __device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *_
         acc[38] += rho * (wiy * wiy + wiz * wiz); acc[39] += rho * (wix * wix + wiz * wiz); acc[40] += rho * (wix * wix + wiy * wiy);
         acc[41] += rho * (wjy * wjy + wjz * wjz); acc[42] += rho * (wjx * wjx + wjz * wjz); acc[43] += rho * (wjx * wjx + wjy * wjy);
     };
-    // two correspondences per lane per trip: four independent 16-byte loads in flight
-    for (uint32_t e = lo + tid; e < hi; e += 2 * kBlock) {
-        const uint32_t e2 = e + kBlock;
-        const bool live2 = e2 < hi;
-        const uint32_t e2c = live2 ? e2 : e;
-        const float4 a0 = cb[2 * (size_t)e], a1 = cb[2 * (size_t)e + 1], b0 = cb[2 * (size_t)e2c], b1 = cb[2 * (size_t)e2c + 1];
-        accumulate(a0, a1, true);
-        accumulate(b0, b1, live2);
+    // two correspondences per lane per trip (entries e and e + 256: every load instruction of a wave covers consecutive entries), all of
+    // their loads in flight together
+    if (C24) {
+        const float2 *cb = reinterpret_cast<const float2 *>(corr);
+        const size_t e_base = (size_t)D.corr_entry0 + (size_t)b * (size_t)D.corr_stride;
+        // (three and four entries per lane per trip -- more bytes in flight -- measured slower everywhere: the registers they hold push the
+        // fused kernel into spills, gpurun_out/r03_16)
+        for (uint32_t e = lo + tid; e < hi; e += 2 * kBlock) {
+            const uint32_t e2 = e + kBlock;
+            const bool live2 = e2 < hi;
+            const float2 *qa = cb + corr24_index(e_base + e), *qb = cb + corr24_index(e_base + (live2 ? e2 : e));
+            const float2 a0 = qa[0], a1 = qa[64], a2 = qa[128], b0 = qb[0], b1 = qb[64], b2 = qb[128];
+            accumulate(__float_as_uint(a0.x) != 0xFFFFFFFFu, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
+            accumulate(live2 && __float_as_uint(b0.x) != 0xFFFFFFFFu, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y);
+        }
+    } else {
+        const float4 *cb = corr + 2 * (size_t)b * D.corr_stride;
+        bool misplaced = false;                       // an entry whose (imgIdx_i, imgIdx_j) is not this segment's pair
+        auto entry = [&](const float4 &q0, const float4 &q1, bool live) {
+            // q0 = (imgIdx_i, imgIdx_j, pos_i.x, pos_i.y)  q1 = (pos_i.z, pos_j.x, pos_j.y, pos_j.z)
+            const bool valid = live && __float_as_uint(q0.x) != 0xFFFFFFFFu;      // EntryJ::isValid
+            misplaced |= valid & ((__float_as_uint(q0.x) != (uint32_t)fi) | (__float_as_uint(q0.y) != (uint32_t)fj));
+            accumulate(valid, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w);
+        };
+        for (uint32_t e = lo + tid; e < hi; e += 2 * kBlock) {
+            const uint32_t e2 = e + kBlock;
+            const bool live2 = e2 < hi;
+            const uint32_t e2c = live2 ? e2 : e;
+            const float4 a0 = cb[2 * (size_t)e], a1 = cb[2 * (size_t)e + 1], b0 = cb[2 * (size_t)e2c], b1 = cb[2 * (size_t)e2c + 1];
+            entry(a0, a1, true);
+            entry(b0, b1, live2);
+        }
+        if (D.order_flag && misplaced) atomicOr(D.order_flag, 1);
     }
-    if (D.order_flag && misplaced) atomicOr(D.order_flag, 1);
     float *out = partials + (((size_t)b * D.n_pairs + p) * D.sparse_chunks + chunk) * kSparseVals;
     block_reduce_store<kSparseVals, 4>(acc, red, out);
+}
+__device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
+                                             const float *__restrict__ T, float *__restrict__ partials, int chunk, int p, int b, float *red)
+{
+    if (D.corr24) sparse_block_impl<true>(D, corr, pair_offsets, T, partials, chunk, p, b, red);
+    else sparse_block_impl<false>(D, corr, pair_offsets, T, partials, chunk, p, b, red);
+}
+
+// EntryJ segments -> 24-byte correspondences, in place in the entry index space (entry e of the input is entry e of the output).
+// grid (ceil(longest segment / 256), n_segments); seg[s] = (source offset, destination offset, length, i << 16 | j), offsets in entries.
+// A valid entry that does not carry (i, j) raises the order flag (the array was not pair-major: the caller falls back to bucketing).
+__global__ void __launch_bounds__(256) k_pack_corr24(const uint4 *__restrict__ seg, const uint4 *__restrict__ src, float2 *__restrict__ dst, int *__restrict__ order_flag)
+{
+    const uint4 d = seg[blockIdx.y];
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= d.z) return;
+    const uint4 a = src[2 * (size_t)(d.x + e)], b = src[2 * (size_t)(d.x + e) + 1];
+    const bool valid = a.x != 0xFFFFFFFFu;
+    if (valid && ((a.x != (d.w >> 16)) | (a.y != (d.w & 0xFFFFu)))) atomicOr(order_flag, 1);
+    float2 *o = dst + corr24_index((size_t)(d.y + e));
+    o[0] = make_float2(valid ? __uint_as_float(a.z) : __uint_as_float(0xFFFFFFFFu), __uint_as_float(a.w));
+    o[64] = make_float2(__uint_as_float(b.x), __uint_as_float(b.y));
+    o[128] = make_float2(__uint_as_float(b.z), __uint_as_float(b.w));
+}
+// the same for a batch of pair-major instances described by their offset tables: grid (ceil(longest segment / 256), P, B)
+__global__ void __launch_bounds__(256) k_pack_corr24_batch(int n_frames, int n_pairs, int64_t corr_stride, const uint32_t *__restrict__ pair_offsets,
+                                                          const uint4 *__restrict__ src, float2 *__restrict__ dst, int *__restrict__ order_flag)
+{
+    const int p = blockIdx.y, b = blockIdx.z;
+    const uint32_t *off = pair_offsets + (size_t)b * (n_pairs + 1);
+    const uint32_t seg0 = off[p], len = off[p + 1] - seg0, e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= len) return;
+    int fi, fj;
+    pair_from_index(p, n_frames, fi, fj);
+    const size_t at = (size_t)b * (size_t)corr_stride + seg0 + e;
+    const uint4 a = src[2 * at], q = src[2 * at + 1];
+    const bool valid = a.x != 0xFFFFFFFFu;
+    if (order_flag && valid && ((a.x != (uint32_t)fi) | (a.y != (uint32_t)fj))) atomicOr(order_flag, 1);
+    float2 *o = dst + corr24_index(at);
+    o[0] = make_float2(valid ? __uint_as_float(a.z) : __uint_as_float(0xFFFFFFFFu), __uint_as_float(a.w));
+    o[64] = make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
+    o[128] = make_float2(__uint_as_float(q.z), __uint_as_float(q.w));
 }
 
 // grid (sparse_chunks, P, B).  Workgroup (c, p, b) owns slice c of pair p's contiguous EntryJ segment.

@@ -340,14 +340,28 @@ class BatchSolver:
                   "btba_zn_valid_lists")
         return aux
 
-    def solve_zn(self, zn, H, W, K, corr_dev, pair_offsets_dev, max_corr_per_pair, poses_dev, dense_pairs=None, trace=False, aux=None):
+    def pack_correspondences24(self, corr_dev, pair_offsets_dev, max_corr_per_pair, n_frames, check_order=False):
+        """Device-resident EntryJ [B, stride, 32] (uint8 view) -> 24-byte records, float32 [groups of 64 entries, 3 planes, 64, 2]
+        (btba_pack_correspondences24; entry E = b * stride + e sits in group E // 64 at column E % 64): what a
+        batch that stays on the device hands to solve_zn(aux={"corr24": ...}).  check_order: also return a device int32 flag that is 1 when an
+        entry does not belong to the pair of its segment."""
+        torch = _torch()
+        B, stride = int(corr_dev.shape[0]), int(corr_dev.shape[1])
+        out = torch.zeros((-(-(B * stride) // 64), 3, 64, 2), dtype=torch.float32, device=corr_dev.device)      # groups of 64 entries x 3 planes of float2
+        flag = torch.zeros((1,), dtype=torch.int32, device=corr_dev.device) if check_order else None
+        check(lib().btba_pack_correspondences24(self.ws.handle, B, int(n_frames), _dev_ptr(corr_dev, "corr_dev"), stride, _dev_ptr(pair_offsets_dev, "pair_offsets_dev"),
+                                                int(max_corr_per_pair), _dev_ptr(out, "corr24"), _dev_ptr(flag, "order_flag")), "btba_pack_correspondences24")
+        return (out, flag) if check_order else out
+
+    def solve_zn(self, zn, H, W, K, corr_dev, pair_offsets_dev, max_corr_per_pair, poses_dev, dense_pairs=None, trace=False, aux=None, corr_stride=None):
         """Same as solve() on compact caches: zn CUDA float32 [B,N,Hd,Wd,4] = (z, nx, ny, nz); H, W, K = the FULL-resolution
         frame geometry the caches were built from (Hd = H / image_downscale).  aux: the result of cache_aux(zn) for callers that
-        keep their caches across solves (None: derived inside every solve)."""
+        keep their caches across solves (None: derived inside every solve).  With aux["corr24"] (pack_correspondences24) corr_dev may be None;
+        corr_stride then gives the entries per instance block of the array that was packed."""
         torch = _torch()
         B, N = zn.shape[:2]
         Kf = np.ascontiguousarray(K, np.float32).reshape(9)
-        stride = corr_dev.shape[1] if corr_dev is not None else 0
+        stride = corr_dev.shape[1] if corr_dev is not None else int(corr_stride or 0)
         dp = None
         npd = N * (N - 1) // 2
         if dense_pairs is not None:
@@ -363,7 +377,8 @@ class BatchSolver:
             self.params.flags &= ~_lib.FLAG_TRACE
         za = None
         if aux:
-            za = _lib.ZnAux(_dev_ptr(aux.get("block_ranges"), "block_ranges"), _dev_ptr(aux.get("valid_lists"), "valid_lists"), _dev_ptr(aux.get("valid_counts"), "valid_counts"))
+            za = _lib.ZnAux(_dev_ptr(aux.get("block_ranges"), "block_ranges"), _dev_ptr(aux.get("valid_lists"), "valid_lists"), _dev_ptr(aux.get("valid_counts"), "valid_counts"),
+                            _dev_ptr(aux.get("corr24"), "corr24"))
         rc = lib().btba_solve_batch_zn_aux(
             self.ws.handle, C.byref(self.params), B, N, int(H), int(W), Kf.ctypes.data, _dev_ptr(zn, "zn"), C.byref(za) if za is not None else None,
             _dev_ptr(corr_dev, "corr_dev"), stride,

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BTBA_VERSION 103     /* 103: btba_params.reduction_mode, BTBA_FLAG_KEYED_CORR = 4096, btba_workspace_set_option */
+#define BTBA_VERSION 103     /* 103: btba_params.reduction_mode, BTBA_FLAG_KEYED_CORR = 4096, btba_workspace_set_option, btba_zn_aux.corr24 + btba_pack_correspondences24 */
 
 #if defined(__GNUC__)
 #define BTBA_API __attribute__((visibility("default")))
@@ -350,10 +350,25 @@ typedef struct btba_zn_aux {
     const float *block_ranges;
     const uint32_t *valid_lists;
     const int32_t *valid_counts;
+    const float *corr24;              /* the correspondences as 24-byte records (btba_pack_correspondences24): used INSTEAD of corr_dev, with the
+                                         same corr_stride / pair_offsets_dev.  NULL: corr_dev (EntryJ) is read */
 } btba_zn_aux;
 /* Builders (asynchronous on the workspace stream). */
 BTBA_API int btba_zn_block_ranges(btba_workspace *ws, int n_frames_total, int Hd, int Wd, const float *zn_dev, float *ranges_dev);
 BTBA_API int btba_zn_valid_lists(btba_workspace *ws, int n_frames_total, int Hd, int Wd, const float *zn_dev, uint32_t *lists_dev, int32_t *counts_dev);
+/* Device-resident correspondences without their frame indices.  A pair-major array implies (imgIdx_i, imgIdx_j) of every entry through the
+ * segment it lies in, so a batch that STAYS on the device (or the keyed pool of btba_optimize_frames_keyed) can drop those 8 of 32 bytes:
+ * the sparse sweep streams the array once per Gauss-Newton iteration and is bound by exactly that stream on feature-only windows and on
+ * object-masked frames.  24 bytes per entry, kept in groups of 64 entries as three planes of float2 -- (pos_i.x, pos_i.y)[64],
+ * (pos_i.z, pos_j.x)[64], (pos_j.y, pos_j.z)[64] -- so that a wave's loads are contiguous: entry E (counted from the start of the array,
+ * E = instance * corr_stride + e) has its k-th float2 at float2 index (E / 64) * 192 + k * 64 + E % 64; entry e of the input is entry e of
+ * the output (same offsets, same stride, counted in entries).  corr24_dev must hold 24 * 64 * ceil(n_instances * corr_stride / 64) bytes.
+ * An invalid entry (imgIdx_i = 0xFFFFFFFF) keeps its place with the bit pattern 0xFFFFFFFF in pos_i.x --
+ * consequently a VALID entry whose pos_i.x has that pattern (one particular NaN) is dropped where the reference would propagate the NaN.
+ * The wire format at the boundary stays EntryJ (A1).  order_flag_dev (may be NULL): int on the device, ORed with 1 when a valid entry
+ * does not carry the pair of its segment (the array was not pair-major).  Asynchronous on the workspace stream. */
+BTBA_API int btba_pack_correspondences24(btba_workspace *ws, int n_instances, int n_frames, const btba_entryj *corr_dev, int64_t corr_stride,
+                                         const uint32_t *pair_offsets_dev, uint32_t max_corr_per_pair, float *corr24_dev, int32_t *order_flag_dev);
 /* btba_solve_batch_zn with the caches' derived data supplied (aux NULL, or any member NULL: as btba_solve_batch_zn). */
 BTBA_API int btba_solve_batch_zn_aux(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames,
                                      int H, int W, const float *K_rowmajor, const float *zn_dev, const btba_zn_aux *aux,

@@ -168,22 +168,28 @@ def test_python_constants_match_the_header():
 
 def test_counter_file_matches_the_committed_pmc_summaries():
     """profiles/sweep_counters.json (what bench.py quotes as roofline.traffic / roofline.valu_issue) must carry the numbers of the PMC
-    summaries it names -- both are written by scripts/summarize_profiles.py -- and bench.py must ignore it when it was taken on other
-    kernel sources (kernel_source_hash) or another workload."""
+    summaries it names -- both are written by scripts/summarize_profiles.py -- and bench.py must ignore a record that was taken on other
+    kernel sources (kernel_source_hash) or another workload: config, instances, DISTINCT instances, mask, cache / correspondence layout."""
     import csv, json, os
     import bench
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "profiles", "sweep_counters.json")
     if not os.path.exists(path):
         pytest.skip("no counter summary committed")
-    tj = json.load(open(path))
-    rows = [r for r in csv.DictReader(l for l in open(os.path.join(root, tj["source_hbm"])) if not l.startswith("#")) if r["kernel"] == tj["kernel"]]
-    assert len(rows) == 1 and int(rows[0]["hbm_bytes_per_launch_corrected"]) == tj["hbm_bytes_per_launch"]
-    fetch_kib, write_kib = float(rows[0]["FETCH_SIZE_KiB_mean"]), float(rows[0]["WRITE_SIZE_KiB_mean"])
-    assert abs(int(fetch_kib * 1024 * 2 + write_kib * 1024) - tj["hbm_bytes_per_launch"]) <= 2048      # the guide's gfx950 correction
-    sq = {r["counter"]: float(r["mean_per_launch"]) for r in csv.DictReader(l for l in open(os.path.join(root, tj["source_sq"])) if not l.startswith("#")) if r["kernel"] == tj["kernel"]}
-    busy = 4.0 * (sq["SQ_ACTIVE_INST_VALU"] - sq["SQ_ACTIVE_INST_VALU2"]) / 1024.0 / (sq["SQ_BUSY_CYCLES"] / 32.0)
-    assert abs(busy - tj["valu_busy_frac"]) < 2e-3 and 0.0 < busy <= 1.0
-    got = bench.profiled_counters(tj["config"], tj["instances"], tj["masked"], tj["float4_cache"], tj["fused"])
-    assert (got is not None) == (tj["kernel_source_hash"] == bench.kernel_source_hash())                # stale sources -> not quoted
-    assert bench.profiled_counters(tj["config"], tj["instances"] + 1, tj["masked"], tj["float4_cache"], tj["fused"]) is None
+    recs = json.load(open(path)).get("records", [])
+    for tj in recs:
+        rows = [r for r in csv.DictReader(l for l in open(os.path.join(root, tj["source_hbm"])) if not l.startswith("#")) if r["kernel"] == tj["kernel"]]
+        assert len(rows) == 1 and int(rows[0]["hbm_bytes_per_launch_corrected"]) == tj["hbm_bytes_per_launch"]
+        fetch_kib, write_kib = float(rows[0]["FETCH_SIZE_KiB_mean"]), float(rows[0]["WRITE_SIZE_KiB_mean"])
+        assert abs(int(fetch_kib * 1024 * 2 + write_kib * 1024) - tj["hbm_bytes_per_launch"]) <= 2048      # the guide's gfx950 correction
+        head = [l for l in open(os.path.join(root, tj["source_sq"])) if l.startswith("#")]
+        assert any(f"distinct instances: {tj['distinct']}" in l for l in head)                          # the pass ran the workload the record names
+        sq = {r["counter"]: float(r["mean_per_launch"]) for r in csv.DictReader(l for l in open(os.path.join(root, tj["source_sq"])) if not l.startswith("#")) if r["kernel"] == tj["kernel"]}
+        busy = 4.0 * (sq["SQ_ACTIVE_INST_VALU"] - sq["SQ_ACTIVE_INST_VALU2"]) / 1024.0 / (sq["SQ_BUSY_CYCLES"] / 32.0)
+        assert abs(busy - tj["valu_busy_frac"]) < 2e-3 and 0.0 <= busy <= 1.0
+        args = (tj["config"], tj["instances"], tj["masked"], tj["float4_cache"], tj["fused"])
+        got = bench.profiled_counters(*args, tj["distinct"], tj["entryj"])
+        assert (got is not None) == (tj["kernel_source_hash"] == bench.kernel_source_hash())            # stale sources -> not quoted
+        assert bench.profiled_counters(tj["config"], tj["instances"] + 1, *args[2:], tj["distinct"], tj["entryj"]) is None
+        assert bench.profiled_counters(*args, max(1, tj["distinct"] // 8), tj["entryj"]) is None          # a pass on 4 tiled instances does not speak for 32
+        assert bench.profiled_counters(*args, tj["distinct"], not tj["entryj"]) is None

@@ -676,3 +676,80 @@ def test_trusted_pair_major_upload_and_its_fallback(gpu, small_problem_masked):
         with pytest.raises(_lib.BtbaError) as e:
             run(bad, nm)
         assert e.value.status == _lib.BTBA_EINVAL
+
+
+def test_24_byte_correspondences_are_bit_identical(gpu, small_problem_masked, small_problem):
+    """Device-resident correspondences without their frame indices (btba_pack_correspondences24, 24 B instead of EntryJ's 32 B): the
+    sparse sweep reads the same positions in the same order, so every pose is the SAME BITS as on the EntryJ array -- ragged segments,
+    empty pairs and invalid entries (which keep their place) included; the packer flags an array that is not pair-major; and the keyed
+    correspondence pool of btba_optimize_frames_keyed, which stores 24-byte segments and lets the sweeps read them in place, gives the
+    bits of the plain call, falls back to host bucketing on a shuffled array and recovers afterwards."""
+    pbs = [small_problem_masked, small_problem]
+    N = pbs[0].n_frames
+    bs = gpu.BatchSolver(gpu.ws)
+    corr_list = []
+    for b, pb in enumerate(pbs):
+        c = pb.corr.copy()
+        if b == 0:
+            c["imgIdx_i"][::9] = 0xFFFFFFFF                                  # invalid entries
+            c = c[~((c["imgIdx_i"] == 0) & (c["imgIdx_j"] == 2))]            # an empty pair -> ragged segments
+        corr_list.append(c)
+    corr, offs, mx = bs.pack_correspondences(corr_list, N)
+    # invalid entries dropped by the host packer: put some back IN PLACE so that the device array holds holes
+    corr[1]["imgIdx_i"][5:40:4] = 0xFFFFFFFF
+    zn = gpu.torch.from_numpy(np.stack([S.compact_cache(pb) for pb in pbs])).to(gpu.dev)
+    corr_d = gpu.torch.from_numpy(corr.view(np.uint8).reshape(len(pbs), -1, 32)).to(gpu.dev)
+    offs_d = gpu.torch.from_numpy(offs.astype(np.int32)).to(gpu.dev)
+    p0 = gpu.torch.from_numpy(np.stack([pb.poses_init for pb in pbs])).to(gpu.dev)
+    pa, pb_ = p0.clone(), p0.clone()
+    bs.solve_zn(zn, pbs[0].H, pbs[0].W, pbs[0].K, corr_d, offs_d, mx, pa)
+    c24, flag = bs.pack_correspondences24(corr_d, offs_d, mx, N, check_order=True)
+    bs.solve_zn(zn, pbs[0].H, pbs[0].W, pbs[0].K, None, offs_d, mx, pb_, aux={"corr24": c24}, corr_stride=corr_d.shape[1])
+    gpu.ws.sync()
+    assert int(flag.cpu()[0]) == 0
+    assert np.array_equal(pa.cpu().numpy().view(np.uint32), pb_.cpu().numpy().view(np.uint32))
+    assert not np.array_equal(pa.cpu().numpy(), p0.cpu().numpy())
+    # layout: groups of 64 entries x three planes of float2; entry E = b * stride + e sits at [E // 64, :, E % 64]
+    stride = corr.shape[1]
+    got = c24.cpu().numpy().transpose(0, 2, 1, 3).reshape(-1, 6)[: len(pbs) * stride].reshape(len(pbs), stride, 6)
+    valid = corr["imgIdx_i"] != 0xFFFFFFFF
+    assert np.array_equal(got[..., :3][valid], corr["pos_i"][valid]) and np.array_equal(got[..., 3:][valid], corr["pos_j"][valid])
+    filled = np.zeros(corr.shape, bool)
+    for b in range(len(pbs)):
+        filled[b, : int(offs[b, -1])] = True
+    assert (got[..., 0].view(np.uint32)[filled & ~valid] == 0xFFFFFFFF).all()
+    # a pair-major array whose entries were swapped between two segments: flagged
+    sw = corr.copy(); sw[0, [0, int(offs[0, 3])]] = sw[0, [int(offs[0, 3]), 0]]
+    _, flag2 = bs.pack_correspondences24(gpu.torch.from_numpy(sw.view(np.uint8).reshape(len(pbs), -1, 32)).to(gpu.dev), offs_d, mx, N, check_order=True)
+    gpu.ws.sync()
+    assert int(flag2.cpu()[0]) == 1
+
+    # the keyed pool (24-byte segments read in place)
+    from bundletrack_amd.optimizer import Workspace
+    pb = small_problem_masked
+    d, n = upload_frames(gpu, pb)
+    plain = gpu.OptimizerGpu(workspace=gpu.ws)
+    ws2 = Workspace()
+    ws2.set_option(_lib.OPT_KEYED_CORR_MIN_BYTES, 0)
+    keyed = gpu.OptimizerGpu(workspace=ws2, keyed_correspondences=True)
+    keys = np.arange(100, 100 + N, dtype=np.uint64)
+
+    def run(opt, corr_in, nm, **kw):
+        poses = pb.poses_init.copy()
+        opt.optimizeFrames(corr_in, nm, N, pb.H, pb.W, d, None, n, poses, pb.K, **kw)
+        return poses, opt.last_stats
+    base, _ = run(plain, pb.corr, pb.n_match_per_pair)
+    k1, st1 = run(keyed, pb.corr, pb.n_match_per_pair, frame_keys=keys)
+    k2, st2 = run(keyed, pb.corr, pb.n_match_per_pair, frame_keys=keys)
+    assert np.array_equal(k1, base) and np.array_equal(k2, base)
+    assert st1["corr_pairs_uploaded"] == N * (N - 1) // 2 and st2["corr_pairs_uploaded"] == 0
+    holes = pb.corr.copy(); holes["imgIdx_i"][::7] = 0xFFFFFFFF
+    kh, _ = run(keyed, holes, pb.n_match_per_pair, frame_keys=keys + 1000)      # other keys: fresh segments with invalid entries in place
+    ph, _ = run(plain, holes, pb.n_match_per_pair)
+    assert np.array_equal(kh, ph)
+    shuffled = pb.corr[np.random.default_rng(5).permutation(len(pb.corr))]
+    ks, sts = run(keyed, shuffled, pb.n_match_per_pair, frame_keys=keys + 2000)  # not pair-major: the packer's flag -> host bucketing, pool dropped
+    ps, _ = run(plain, shuffled, None)
+    assert np.array_equal(ks, ps)
+    k3, st3 = run(keyed, pb.corr, pb.n_match_per_pair, frame_keys=keys)         # ... and the pool works again afterwards
+    assert np.array_equal(k3, base) and st3["corr_pairs_uploaded"] == N * (N - 1) // 2
