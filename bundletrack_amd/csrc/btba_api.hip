@@ -424,7 +424,9 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
 {
     if (!ws || !prm || B < 1 || N < 2 || Hd < 2 || Wd < 2 || !intr || !poses) return BTBA_EINVAL;
     if (prm->n_gn_iters < 1 || prm->n_pcg_iters < 0) return BTBA_EINVAL;   // MLIB_ASSERT, CUDASolverBundling.cpp:194
-    if (prm->reduction_mode != BTBA_REDUCE_DETERMINISTIC) return BTBA_EINVAL;   // the reference's float atomics are not reproduced
+    if (prm->reduction_mode != BTBA_REDUCE_DETERMINISTIC && prm->reduction_mode != BTBA_REDUCE_ATOMIC) return BTBA_EINVAL;
+    const bool atomic_sums = prm->reduction_mode == BTBA_REDUCE_ATOMIC;      // the reference's way of summing (float atomics, order not fixed)
+    if (atomic_sums && trace) return BTBA_EINVAL;                            // the decision traces are defined on the reproducible sums
     if (N > BTBA_MAX_FRAMES) return BTBA_EINVAL;                            // MAX_NUM_IMAGES of the reference (GlobalDefines.h:8) is 85 as well
     const int P = N * (N - 1) / 2;
     const bool use_sparse = prm->weight_sparse > 0.0f && corr && pair_offsets && max_corr_per_pair > 0;
@@ -535,6 +537,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;
     D.order_flag = order_flag;
+    D.atomic_sums = atomic_sums ? 1 : 0;
     D.corr24 = corr24 ? 1 : 0;
     D.pair_lens = pair_lens;
     if (Pd > 0) { D.dense_work = reinterpret_cast<const int4 *>(ws->dense_pairs.as<int32_t>() + ws->dense_work_offset); D.work_formula = ws->work_formula; }      // work position -> (target, source, pair, -)
@@ -601,6 +604,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     }
     size_t reg;
     if ((rc = time_begin(ws, timing || ws->always_time_region, 3, &reg))) return rc;
+    if (atomic_sums) {        // one accumulator record per pair: empty before the first sweep (k_system_solve leaves them empty again)
+        HIP_TRY(hipMemsetAsync(ws->sparse_part.p, 0, sizeof(float) * (size_t)B * P * kSparseVals, ws->stream));
+        HIP_TRY(hipMemsetAsync(ws->dense_part.p, 0, sizeof(float) * (size_t)B * (Pd > 0 ? Pd : 1) * kDenseVals, ws->stream));
+    }
     // Log, Exp, inverse of the incoming matrices
     {
         const int total = B * N;
@@ -678,8 +685,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             const float4 *corr_h = corr ? (corr24 ? reinterpret_cast<const float4 *>(corr) : reinterpret_cast<const float4 *>(corr) + 2 * b0 * (size_t)corr_stride) : nullptr;
             const uint32_t *off_h = pair_offsets ? pair_offsets + b0 * (P + 1) : nullptr;
             float *x_h = ws->x.as<float>() + 6 * b0 * N, *T_h = ws->T.as<float>() + 16 * b0 * N, *Ti_h = ws->Tinv.as<float>() + 16 * b0 * N;
-            float *sp_h = ws->sparse_part.as<float>() + b0 * P * chunks * kSparseVals;
-            float *dp_h = ws->dense_part.as<float>() + b0 * (size_t)(Pd > 0 ? Pd : 1) * tiles * kDenseVals;
+            float *sp_h = ws->sparse_part.as<float>() + b0 * P * (atomic_sums ? 1 : chunks) * kSparseVals;
+            float *dp_h = ws->dense_part.as<float>() + b0 * (size_t)(Pd > 0 ? Pd : 1) * (atomic_sums ? 1 : tiles) * kDenseVals;
             float *ps_h = ws->pairsum.p ? ws->pairsum.as<float>() + b0 * pairsum_floats : nullptr;
             float *tr_h = trace ? trace + b0 * (size_t)D.n_gn * D.trace_record : nullptr;
             size_t slot;
@@ -744,13 +751,15 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             if ((rc = time_begin(ws, timing_it, 2, &slot, H.st))) return rc;
             float *A_h = (a_global || D.pre_assembled) ? ws->big_A.as<float>() + b0 * (n + 2) * ld : nullptr;
             float *out_h = (it == prm->n_gn_iters - 1) ? poses + 16 * b0 * N : nullptr;     // the last iterate's matrices go straight to the caller's buffer
+            SolveDims Ds = D;                                   // the system solve's view: in atomic mode one record per pair
+            if (atomic_sums) { Ds.sparse_chunks = 1; Ds.dense_tiles = 1; }
             if (D.pre_assembled) {
                 const size_t n_sums = (size_t)P * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals;
-                k_big_reduce<<<dim3((unsigned)((n_sums + 255) / 256), (unsigned)H.nb), 256, 0, H.st>>>(D, sp_h, dp_h, ps_h);
+                k_big_reduce<<<dim3((unsigned)((n_sums + 255) / 256), (unsigned)H.nb), 256, 0, H.st>>>(Ds, sp_h, dp_h, ps_h);
                 const BigTasks bt = big_tasks(N, P, (int)ld);
                 k_big_assemble<<<dim3((bt.total + 255u) / 256u, (unsigned)H.nb), 256, 0, H.st>>>(D, ps_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, ws->solve_tab.as<int>(), A_h);
             }
-#define BTBA_SOLVE(LP, AG) k_system_solve<LP, AG><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(D, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h, A_h, out_h, ws->solve_tab.as<int>())
+#define BTBA_SOLVE(LP, AG) k_system_solve<LP, AG><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(Ds, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h, A_h, out_h, ws->solve_tab.as<int>())
             if (a_global) { if (D.pairsum_in_lds) BTBA_SOLVE(true, true); else BTBA_SOLVE(false, true); }
             else { if (D.pairsum_in_lds) BTBA_SOLVE(true, false); else BTBA_SOLVE(false, false); }
 #undef BTBA_SOLVE

@@ -97,8 +97,10 @@ __device__ __forceinline__ void exp_rotation(const float w[3], float r[9])
         A = 1.0f - theta_sq * BTBA_ONE_SIXTH * (1.0f - BTBA_ONE_TWENTIETH * theta_sq);
     } else {
         const float inv_theta = 1.0f / theta;
-        A = sinf(theta) * inv_theta;
-        B = (1.0f - cosf(theta)) * (inv_theta * inv_theta);
+        float sn, cs;
+        sincosf(theta, &sn, &cs);                     // one argument reduction for both (the values of sinf / cosf, bit for bit)
+        A = sn * inv_theta;
+        B = (1.0f - cs) * (inv_theta * inv_theta);
     }
     rodrigues(w, A, B, r);
 }
@@ -178,8 +180,10 @@ __device__ __forceinline__ Mat4 pose_to_matrix(const float rot[3], const float t
             B = 0.5f - 0.25f * BTBA_ONE_SIXTH * theta_sq;
         } else {
             const float inv_theta = 1.0f / theta;
-            A = sinf(theta) * inv_theta;
-            B = (1.0f - cosf(theta)) * (inv_theta * inv_theta);
+            float sn, cs;
+            sincosf(theta, &sn, &cs);
+            A = sn * inv_theta;
+            B = (1.0f - cs) * (inv_theta * inv_theta);
             C = (1.0f - A) * (inv_theta * inv_theta);
         }
         const float wc[3] = { rot[1] * cr[2] - rot[2] * cr[1], rot[2] * cr[0] - rot[0] * cr[2], rot[0] * cr[1] - rot[1] * cr[0] };
@@ -293,8 +297,10 @@ __device__ __forceinline__ void wave_fold_store(const float (&acc)[NV], float *d
 // Reduce NV per-thread registers over a workgroup of NWAVES waves into out[0..NV) (global or LDS).
 // lds_scratch must hold NWAVES*NV floats.  Deterministic: fixed tree inside the wave, fixed
 // wave order across waves.
+// atomic: add the workgroup's sums into out[] with hardware float atomics (global_atomic_add_f32) instead of storing them --
+// BTBA_REDUCE_ATOMIC, the reference's own way of summing (SolverBundlingDenseUtil.h:217-285): the order in which workgroups land is not fixed.
 template <int NV, int NWAVES>
-__device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float *lds_scratch, float *out)
+__device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float *lds_scratch, float *out, bool atomic = false)
 {
     const int tid = (int)item_tid(), wave = tid >> 6;
     wave_fold_store<NV>(acc, lds_scratch + wave * NV);
@@ -303,7 +309,7 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float *lds_
         float s = lds_scratch[k];
 #pragma unroll
         for (int w = 1; w < NWAVES; w++) s += lds_scratch[w * NV + k];
-        out[k] = s;
+        if (atomic) unsafeAtomicAdd(out + k, s); else out[k] = s;
     }
 }
 

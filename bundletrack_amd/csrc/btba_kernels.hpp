@@ -77,6 +77,8 @@ struct SolveDims {
     const float2 *block_ranges;   // per (cache slot, 8 x 8 block): [min, max] valid depth (k_block_ranges); nullptr: no block is skipped
     int tile_major;      // dense work order inside an instance: 1 = (tile, pair) -- all pairs' band t of the images together -- 0 = (pair, tile)
     int *order_flag;     // non-null: the sparse sweep ORs 1 into it when an entry does not belong to the pair of its segment
+    int atomic_sums;     // BTBA_REDUCE_ATOMIC: sweep workgroups ADD their sums into one record per pair (float atomics) instead of storing one record
+                         // per (pair, chunk / tile); k_system_solve reads those records (chunks = tiles = 1 on its side) and clears them for the next iteration
     int corr24;          // the correspondences are 24-byte (pos_i, pos_j) records (k_pack_corr24) instead of EntryJ
     int64_t corr_entry0; // 24-byte layout: entry index of this launch's first instance in the array
     const uint32_t *pair_lens;   // non-null: [B][P] segment lengths (segments not back to back: the keyed pool); else offsets[p + 1] - offsets[p]
@@ -360,8 +362,8 @@ __device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const floa
         }
         if (D.order_flag && misplaced) atomicOr(D.order_flag, 1);
     }
-    float *out = partials + (((size_t)b * D.n_pairs + p) * D.sparse_chunks + chunk) * kSparseVals;
-    block_reduce_store<kSparseVals, 4>(acc, red, out);
+    float *out = partials + (D.atomic_sums ? ((size_t)b * D.n_pairs + p) : (((size_t)b * D.n_pairs + p) * D.sparse_chunks + chunk)) * kSparseVals;
+    block_reduce_store<kSparseVals, 4>(acc, red, out, D.atomic_sums != 0);
 }
 __device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
                                              const float *__restrict__ T, float *__restrict__ partials, int chunk, int p, int b, float *red)
@@ -558,7 +560,7 @@ __device__ __forceinline__ void dense_stage_M(float *red, const float *__restric
 // FLIPPED: the sums were accumulated with a+ = D a, res+ = -res (dense_block_pinhole): S = D S+ D negates the nine entries that couple a
 // translation row with a rotation row, g = -D g+ negates the three rotation entries -- exact.
 template <bool FLIPPED = false>
-__device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *red, float *out)
+__device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *red, float *out, bool atomic = false)
 {
     const unsigned tid = item_tid();
     wave_fold_store<kDenseVals>(acc, red + (tid >> 6) * kDenseVals);
@@ -596,15 +598,15 @@ __device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *
             for (int l = 0; l < 6; l++) u += S[tri21(k2, l)] * Mc[l];
             a += Mr[k2] * u;
         }
-        out[idx] = a;
+        if (atomic) unsafeAtomicAdd(out + idx, a); else out[idx] = a;
     } else if (idx < 27) {
         const int r = idx - 21;
         float a = 0.0f;
 #pragma unroll
         for (int k2 = 0; k2 < 6; k2++) a += Mt[6 * r + k2] * Sp[21 + k2];
-        out[idx] = a;
+        if (atomic) unsafeAtomicAdd(out + idx, a); else out[idx] = a;
     } else if (idx == 27) {
-        out[27] = Sp[27];
+        if (atomic) unsafeAtomicAdd(out + 27, Sp[27]); else out[27] = Sp[27];
     }
 }
 
@@ -647,8 +649,8 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
             pixel_accumulate(C, g, c00, c10, c01, c11, n00, n10, n01, n11, acc);
         }
     }
-    float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
-    dense_epilogue(acc, red, out);
+    float *out = partials + (D.atomic_sums ? ((size_t)b * D.n_dense_pairs + p) : (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile)) * kDenseVals;
+    dense_epilogue(acc, red, out, D.atomic_sums != 0);
 }
 
 // ---- per-block depth ranges of the compact cache ------------------------------------------------------------------
@@ -815,8 +817,8 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
         pixel_accumulate(C, g, make_float4(c00.x, c00.y, c00.z, 1.f), make_float4(c10.x, c10.y, c10.z, 1.f), make_float4(c01.x, c01.y, c01.z, 1.f), make_float4(c11.x, c11.y, c11.z, 1.f),
                          make_float4(z00.y, z00.z, z00.w, 0.f), make_float4(z10.y, z10.z, z10.w, 0.f), make_float4(z01.y, z01.z, z01.w, 0.f), make_float4(z11.y, z11.z, z11.w, 0.f), acc);
     }
-    float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
-    dense_epilogue(acc, red, out);
+    float *out = partials + (D.atomic_sums ? ((size_t)b * D.n_dense_pairs + p) : (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile)) * kDenseVals;
+    dense_epilogue(acc, red, out, D.atomic_sums != 0);
 }
 
 // ---- the dense sweep for pinhole intrinsics on the GATED compact cache --------------------------------------------
@@ -1163,8 +1165,8 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
             pixel(zs, 4u * ox, 4u * oy);                  // 4-byte table offsets -> 16-byte entries (rowB follows colA as the row table follows the column table)
         }
     }
-    float *out = partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile) * kDenseVals;
-    dense_epilogue<true>(acc, red, out);
+    float *out = partials + (D.atomic_sums ? ((size_t)b * D.n_dense_pairs + p) : (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile)) * kDenseVals;
+    dense_epilogue<true>(acc, red, out, D.atomic_sums != 0);
 }
 
 template <bool SIMPLE, bool LISTS>
@@ -1392,11 +1394,13 @@ __global__ void __launch_bounds__(256) k_big_reduce(SolveDims D, const float *__
             const size_t p = e / kSparseVals, v = e - p * kSparseVals;
             const float *q = sparse_partials + (((size_t)b * D.n_pairs + p) * D.sparse_chunks) * kSparseVals + v;
             for (int c = 0; c < D.sparse_chunks; c++) s += q[(size_t)c * kSparseVals];
+            if (D.atomic_sums) const_cast<float *>(q)[0] = 0.0f;
         }
     } else if (D.use_dense) {
         const size_t ed = e - ns, p = ed / kDenseVals, v = ed - p * kDenseVals;
         const float *q = dense_partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles) * kDenseVals + v;
         for (int c = 0; c < D.dense_tiles; c++) s += q[(size_t)c * kDenseVals];
+        if (D.atomic_sums) const_cast<float *>(q)[0] = 0.0f;
     }
     out[e] = s;
 }
@@ -1636,6 +1640,12 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
                 for (int i = 0; i < kItems; i++)
 #pragma unroll
                     for (int u = 0; u < width; u++) sum[i] += v[i][u];
+                if (D.atomic_sums) {                    // the records are accumulators: leave them empty for the next iteration's sweeps
+#pragma unroll
+                    for (int i = 0; i < kItems; i++)
+#pragma unroll
+                        for (int u = 0; u < width; u++) const_cast<float *>(q[i])[(size_t)(c + u) * vals] = 0.0f;
+                }
                 c += width;
             };
             while (c + 8 <= parts) round(std::integral_constant<int, 8>{});
@@ -1824,7 +1834,11 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
         }
         if (live) vd[row] = d_;
     } else if (tid < 64) {
-        constexpr int kMaxRows = 4;                     // n = 6N <= 186 (N <= BTBA_MAX_FRAMES_LDS = 31 on this path)
+        // rows per lane: 2 up to 128 unknowns (windows of <= 21 frames: every tracker-size window), 4 up to 186 (N <= BTBA_MAX_FRAMES_LDS = 31).
+        // One wave alone on its SIMD pays ~8 cycles per instruction, so the two dead rows of a 4-row loop cost real time (the sums only
+        // ever add their exact zeros: same bits either way).
+        auto pcg = [&](auto rows_c) {
+        constexpr int kMaxRows = decltype(rows_c)::value;
         const int lane = tid;
         float r_[kMaxRows], m_[kMaxRows], p_[kMaxRows], d_[kMaxRows];
         float part = 0.0f;
@@ -1855,7 +1869,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             auto lo = [](const float4 &v) { return (f2){ v.x, v.y }; };
             auto hi = [](const float4 &v) { return (f2){ v.z, v.w }; };
             f2 q0a = (f2){ 0.f, 0.f }, q0b = q0a, q1a = q0a, q1b = q0a, q2a = q0a, q2b = q0a, q3a = q0a, q3b = q0a;
-            if (n <= 128) {
+            if (kMaxRows == 2) {
 _Pragma("unroll 8")
                 for (int c = 0; c < nq; c++) {
                     const float4 pc = p4[c], r0 = a0[c], r1 = a1[c];
@@ -1873,7 +1887,7 @@ _Pragma("unroll 4")
                 }
             }
             ap_[0] = (q0a.x + q0a.y) + (q0b.x + q0b.y); ap_[1] = (q1a.x + q1a.y) + (q1b.x + q1b.y);
-            ap_[2] = (q2a.x + q2a.y) + (q2b.x + q2b.y); ap_[3] = (q3a.x + q3a.y) + (q3b.x + q3b.y);
+            if (kMaxRows == 4) { ap_[kMaxRows - 2] = (q2a.x + q2a.y) + (q2b.x + q2b.y); ap_[kMaxRows - 1] = (q3a.x + q3a.y) + (q3b.x + q3b.y); }
             part = 0.0f;
 #pragma unroll
             for (int j = 0; j < kMaxRows; j++) part += (lane + 64 * j < n) ? p_[j] * ap_[j] : 0.0f;
@@ -1901,6 +1915,8 @@ _Pragma("unroll 4")
         }
 #pragma unroll
         for (int j = 0; j < kMaxRows; j++) if (lane + 64 * j < n) vd[lane + 64 * j] = d_[j];
+        };
+        if (n <= 128) pcg(std::integral_constant<int, 2>{}); else pcg(std::integral_constant<int, 4>{});
     }
     __syncthreads();
 

@@ -63,11 +63,14 @@ enum {
                                           the diagonal and erased by FlipJtJ_Kernel (SolverBundling.cu:49-59) */
 };
 
-/* Reduction order of the sweeps' partial sums.  The reference adds with float atomics in whatever order the hardware
- * serialises them (SolverBundlingDenseUtil.h:217-285); only the fixed-order, run-to-run reproducible tree is implemented. */
+/* How the sweeps' sums are reduced.  DETERMINISTIC (default): every workgroup stores its partial record, k_system_solve adds them in a
+ * fixed order -- run-to-run reproducible bits.  ATOMIC: what the reference does (SolverBundlingDenseUtil.h:217-285, SolverBundling.cu
+ * warpReduce + atomicAdd throughout): workgroups add into one record per frame pair with hardware float atomics, in whatever order they
+ * finish -- results move in the last bits from run to run, exactly as the reference's do; no partial arrays, one reduction pass less.
+ * Not available together with BTBA_FLAG_TRACE (the decision traces are defined on the reproducible sums). */
 enum {
     BTBA_REDUCE_DETERMINISTIC = 0,
-    BTBA_REDUCE_ATOMIC        = 1   /* reserved: BTBA_EINVAL */
+    BTBA_REDUCE_ATOMIC        = 1
 };
 
 enum {
@@ -111,7 +114,7 @@ typedef struct btba_params {
     int32_t dense_tiles;          /* workgroups per dense frame pair (0 = auto)                        */
     int32_t sparse_chunks;        /* workgroups per correspondence segment (0 = auto)                  */
     int32_t flags;                /* BTBA_FLAG_*                                                        */
-    int32_t reduction_mode;       /* BTBA_REDUCE_* (deterministic only)                                 */
+    int32_t reduction_mode;       /* BTBA_REDUCE_*                                                      */
 } btba_params;
 
 /* Timing / diagnostics filled by the solve entry points (all times in milliseconds, measured

@@ -22,6 +22,7 @@ def child(lib):
         bs = BatchSolver(ws)
         bs.params.flags |= (0 if os.environ.get("AB_NO_TIMING") else _lib.FLAG_TIME_KERNELS) | (_lib.FLAG_COMPACTION if tag == "masked" else 0) | int(os.environ.get("AB_FLAGS", "0"))
         bs.params.dense_tiles = int(os.environ.get("BTBA_BENCH_TILES", "0"))
+        bs.params.reduction_mode = int(os.environ.get("AB_REDUCTION", "0"))
         corr, offs, mx = bs.pack_correspondences([p["corr"] for p in pick], 15)
         zn_d = torch.from_numpy(np.stack([p["zn"] for p in pick])).to(dev)
         corr_d = torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(dev); offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)

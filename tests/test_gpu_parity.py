@@ -753,3 +753,52 @@ def test_24_byte_correspondences_are_bit_identical(gpu, small_problem_masked, sm
     assert np.array_equal(ks, ps)
     k3, st3 = run(keyed, pb.corr, pb.n_match_per_pair, frame_keys=keys)         # ... and the pool works again afterwards
     assert np.array_equal(k3, base) and st3["corr_pairs_uploaded"] == N * (N - 1) // 2
+
+
+def test_atomic_reduction_mode(gpu, oracle, small_problem_masked):
+    """BTBA_REDUCE_ATOMIC -- the reference's own way of summing (float atomics in arrival order, SolverBundlingDenseUtil.h:217-285): sweep
+    workgroups add into one record per frame pair, k_system_solve reads and clears it.  No trace exists in this mode (BTBA_EINVAL with
+    BTBA_FLAG_TRACE), so the rule is on the poses: against the exactly-summed oracle the atomic result may be off by at most
+    max(1e-4, 3 x the oracle's own spread between its two summation orders) -- what the deterministic mode is held to -- and it must stay
+    within that of the deterministic result; repeated runs may differ in the last bits (reported), never by more than that spread either."""
+    cases = [("masked K=4", small_problem_masked, dict()), ("c3-size", S.make_problem(15, 2000, S.config_seed(5, 3), background=True, full_res=False), dict())]
+    for name, pb, kw in cases:
+        N = pb.n_frames
+        cam, nrm, intr = oracle_cache(oracle, pb)[:3] if pb.depth is not None else S.analytic_cache(pb)
+        ref = oracle.solve(cam, nrm, intr, pb.corr, pb.poses_init)                                   # exactly rounded sums
+        seq = oracle.solve(cam, nrm, intr, pb.corr, pb.poses_init, params=oracle.default_params(accum_mode=0))     # sequential fp32 sums
+        spread = max(max(S.pose_error(ref.poses[k], seq.poses[k])) for k in range(N))
+        bound = max(1e-4, 3.0 * spread)
+        zn = gpu.torch.from_numpy(S.compact_cache(pb)[None]).to(gpu.dev) if pb.depth is None else None
+        outs = {}
+        for mode in (_lib.REDUCE_DETERMINISTIC, _lib.REDUCE_ATOMIC, _lib.REDUCE_ATOMIC, _lib.REDUCE_ATOMIC):
+            bs = gpu.BatchSolver(gpu.ws, reduction_mode=mode)
+            corr, offs, mx = bs.pack_correspondences([pb.corr], N)
+            corr_d = gpu.torch.from_numpy(corr.view(np.uint8).reshape(1, -1, 32)).to(gpu.dev)
+            offs_d = gpu.torch.from_numpy(offs.astype(np.int32)).to(gpu.dev)
+            poses_d = gpu.torch.from_numpy(pb.poses_init[None].copy()).to(gpu.dev)
+            if zn is not None:
+                bs.solve_zn(zn, pb.H, pb.W, pb.K, corr_d, offs_d, mx, poses_d)
+            else:
+                bs.solve(gpu.torch.from_numpy(cam[None]).to(gpu.dev), gpu.torch.from_numpy(nrm[None]).to(gpu.dev), intr, corr_d, offs_d, mx, poses_d)
+            gpu.ws.sync()
+            outs.setdefault(mode, []).append(poses_d.cpu().numpy()[0])
+        det, ato = outs[_lib.REDUCE_DETERMINISTIC][0], outs[_lib.REDUCE_ATOMIC]
+        for a in ato:
+            assert np.isfinite(a).all()
+            e_ref = max(max(S.pose_error(a[k], ref.poses[k])) for k in range(N))
+            e_det = max(max(S.pose_error(a[k], det[k])) for k in range(N))
+            assert e_ref < bound and e_det < bound, (name, e_ref, e_det, bound)
+        run_to_run = max(max(S.pose_error(ato[0][k], a[k])) for k in range(N) for a in ato[1:])
+        print(f"{name}: atomic vs oracle {max(max(S.pose_error(ato[0][k], ref.poses[k])) for k in range(N)):.2e}, vs deterministic "
+              f"{max(max(S.pose_error(ato[0][k], det[k])) for k in range(N)):.2e}, run to run {run_to_run:.2e}; oracle's own summation-order spread {spread:.2e}")
+        assert run_to_run < bound
+    # a trace cannot be asked for in this mode
+    bs = gpu.BatchSolver(gpu.ws, reduction_mode=_lib.REDUCE_ATOMIC)
+    corr, offs, mx = bs.pack_correspondences([small_problem_masked.corr], small_problem_masked.n_frames)
+    cam, nrm, intr = oracle_cache(oracle, small_problem_masked)[:3]
+    with pytest.raises(_lib.BtbaError) as e:
+        bs.solve(gpu.torch.from_numpy(cam[None]).to(gpu.dev), gpu.torch.from_numpy(nrm[None]).to(gpu.dev), intr,
+                 gpu.torch.from_numpy(corr.view(np.uint8).reshape(1, -1, 32)).to(gpu.dev), gpu.torch.from_numpy(offs.astype(np.int32)).to(gpu.dev), mx,
+                 gpu.torch.from_numpy(small_problem_masked.poses_init[None].copy()).to(gpu.dev), trace=True)
+    assert e.value.status == _lib.BTBA_EINVAL
