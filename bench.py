@@ -215,7 +215,7 @@ def spawn_ranks(n):
     import subprocess
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < n and os.environ.get("BTBA_DIST_BACKEND") != "gloo":
+    if have < n and os.environ.get("BTBA_DIST_BACKEND", "") != "gloo":
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node (set BTBA_DIST_BACKEND=gloo to share GPUs in a functional test)")
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -247,6 +247,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--float4-cache", action="store_true", help="reference-layout float4 camPos + float4 normal caches (32 B/pixel) instead of the compact (z, n) cache")
     ap.add_argument("--latency", action="store_true", help="also measure single-instance latency mode (extra field)")
+    ap.add_argument("--same-instances", action="store_true", help="every rank solves the SAME instances (global ids 0 ..): the per-rank pose checksums must then agree -- a consistency check of the sharded run, not a benchmark")
     ap.add_argument("--entryj", action="store_true", help="keep the device-resident correspondences as 32-byte EntryJ instead of packing them to 24-byte records before the timed region")
     ap.add_argument("--corr24", action="store_true", help="24-byte records also with --masked (default there: EntryJ, which measured 4 %% faster on the masked launch: profiles/r03)")
     args = ap.parse_args()
@@ -272,7 +273,7 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before the timed region
     n_distinct = max(1, min(args.distinct, B))
-    ids = [rank * B + i for i in range(n_distinct)]       # global instance ids of this rank's distinct seeds
+    ids = [(0 if args.same_instances else rank * B) + i for i in range(n_distinct)]       # global instance ids of this rank's distinct seeds
     note(f"generating {n_distinct} synthetic instances")
     inst = generate_instances(cfg, ids, args.masked)
     note("instances ready; uploading")

@@ -34,7 +34,7 @@ def init_from_env(backend: str | None = None):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
             if backend is None:
-                backend = os.environ.get("BTBA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+                backend = os.environ.get("BTBA_DIST_BACKEND", "") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
             dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -28,10 +28,11 @@ class ParityOptimizer:
     """Runs the HIP optimiser and the oracle on identical inputs, records the worst pose difference of every call
     and hands the HIP result on (so a whole tracking session is driven by the product path)."""
 
-    def __init__(self, hip_opt, oracle_opt, pose_error, classify=None):
+    def __init__(self, hip_opt, oracle_opt, pose_error, classify=None, classify_above=1e-4):
         self.hip, self.ora, self.pose_error = hip_opt, oracle_opt, pose_error
         self.diffs = []
-        self.classify = classify          # callable(call inputs) -> first differing decision, run on the calls that leave the 1e-4 bar
+        self.classify = classify          # callable(call inputs) -> first differing decision, run on the calls above classify_above
+        self.classify_above = classify_above
         self.divergences = {}
 
     def optimizeFrames(self, global_corres, n_match_per_pair, n_frames, H, W, depths, colors, normals, poses, K):
@@ -40,7 +41,7 @@ class ParityOptimizer:
         self.ora.optimizeFrames(global_corres, n_match_per_pair, n_frames, H, W, depths, colors, normals, ref, K)
         self.hip.optimizeFrames(global_corres, n_match_per_pair, n_frames, H, W, depths, colors, normals, poses, K)
         self.diffs.append(max(max(self.pose_error(poses[k], ref[k])) for k in range(n_frames)))
-        if self.classify and self.diffs[-1] >= 1e-4:
+        if self.classify and self.diffs[-1] >= self.classify_above:
             self.divergences[len(self.diffs) - 1] = self.classify(global_corres, n_frames, H, W, depths, normals, self._start, K)
 
     def _remember(self, poses):

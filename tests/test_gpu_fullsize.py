@@ -97,8 +97,9 @@ def test_c3_realistic_mask_matches_oracle(gpu, oracle):
 def test_dead_block_skip_is_exact(gpu):
     """The dense sweep drops 8 x 8 blocks whose frustum segment provably projects outside the target image before walking them
     (k_block_ranges + the hull test in dense_block_pinhole).  It must never drop a block that holds an accepted pixel: with the
-    skip disabled (BTBA_OPT_BLOCK_SKIP = 0, every block walked) the accepted-pixel counts of every dense pair are IDENTICAL at the
-    first linearisation (same poses), the sums agree to fp32 grouping, and the solves stay within round-off of each other.
+    skip disabled (BTBA_OPT_BLOCK_SKIP = 0, every block walked) the accepted-pixel counts of every dense pair are IDENTICAL -- at the
+    first linearisation on every window, and at all seven iterates on the well-posed and the masked windows --, the sums agree to fp32
+    grouping, and the solves stay within round-off of each other.
     Eight windows, among them ones with poses far from the truth (large relative motion: most blocks dead) and a masked one."""
     pbs = [S.make_problem(15, 2000, S.config_seed(5, 40 + b), background=(b != 7), full_res=False) for b in range(8)]
     rng = np.random.default_rng(5)
@@ -114,6 +115,31 @@ def test_dead_block_skip_is_exact(gpu):
     ca, cb = tv_a.dense_pair[:, 0, :, 27], tv_b.dense_pair[:, 0, :, 27]
     assert np.array_equal(ca, cb)
     assert ca.sum() > 0
+    # ... and at EVERY linearisation point of the solve: after the first iterate the two runs no longer walk bit-identical poses (the live
+    # list decides which wave sums which block, so their sums are grouped differently and a borderline pixel may flip on the last bit),
+    # hence both variants are RESTARTED, one Gauss-Newton iteration each, from the poses run A had after iterates 0 .. 5: at identical
+    # poses the skip may not change a single accepted-pixel count, on any of the eight windows.
+    bs1 = gpu.BatchSolver(gpu.ws, n_gn_iters=1)
+    N = pbs[0].n_frames
+    corr, offs, mx = bs1.pack_correspondences([pb.corr for pb in pbs], N)
+    zn_r = gpu.torch.from_numpy(np.stack([S.compact_cache(pb) for pb in pbs])).to(gpu.dev)
+    corr_r = gpu.torch.from_numpy(corr.view(np.uint8).reshape(len(pbs), -1, 32)).to(gpu.dev)
+    offs_r = gpu.torch.from_numpy(offs.astype(np.int32)).to(gpu.dev)
+    n_checked = 0
+    for it in range(tv_a.T_after.shape[1] - 1):
+        start = np.ascontiguousarray(tv_a.T_after[:, it]).astype(np.float32)
+        counts = []
+        for skip in (1, 0):
+            gpu.ws.set_option(_lib.OPT_BLOCK_SKIP, skip)
+            try:
+                poses_r = gpu.torch.from_numpy(start.copy()).to(gpu.dev)
+                tvr = bs1.trace_view(bs1.solve_zn(zn_r, pbs[0].H, pbs[0].W, pbs[0].K, corr_r, offs_r, mx, poses_r, trace=True))
+            finally:
+                gpu.ws.set_option(_lib.OPT_BLOCK_SKIP, 1)
+            counts.append(tvr.dense_pair[:, 0, :, 27].copy())
+        assert np.array_equal(counts[0], counts[1]), (it, np.argwhere(counts[0] != counts[1])[:5])
+        n_checked += counts[0].size
+    print(f"dead-block skip: {n_checked} (window, iterate, pair) accepted-pixel counts identical with and without it")
     print(f"accepted pixels per pair: min {ca.min():.0f} max {ca.max():.0f}; empty pairs {(ca == 0).sum()} of {ca.size}")
     ref = np.abs(tv_b.dense_pair[:, 0]).max(axis=(1, 2), keepdims=True)
     assert (np.abs(tv_a.dense_pair[:, 0] - tv_b.dense_pair[:, 0]) <= 4e-6 * ref).all()

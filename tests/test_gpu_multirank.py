@@ -50,3 +50,27 @@ def test_one_rank_on_rccl():
     assert d["collective"]["backend"] == "nccl" and d["collective"]["rccl_ranks"] == 1
     assert d["n_gpus"] == 1 and len(d["per_rank"]) == 1 and d["per_rank"][0]["gn_iters"] == 4 * 7 * 3
     assert d["per_rank"][0]["pose_checksum"] > 0
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher: bench.py re-runs itself under torch.distributed.run (one rank per GPU, RCCL on a real
+    node).  On a one-GPU box the two ranks share the device and the gather runs on gloo (BTBA_DIST_BACKEND); without that override the
+    same command must refuse instead of printing an n_gpus: 1 line.  With --same-instances both ranks solve identical seeds: identical pose checksums."""
+    env = dict(os.environ, BTBA_BENCH_NPROC="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--instances", "4", "--distinct", "2", "--no-cpu-baseline",
+           "--same-instances"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        refused = subprocess.run(cmd, env=dict(env, BTBA_DIST_BACKEND=""), cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert refused.returncode != 0 and "only 1 GPU" in (refused.stderr + refused.stdout) and not [l for l in refused.stdout.splitlines() if l.startswith("{")]
+        env["BTBA_DIST_BACKEND"] = "gloo"
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["per_rank"]) == 2 and d["scaling"] == "weak"
+    assert sum(r["gn_iters"] for r in d["per_rank"]) == 2 * 4 * 7 * 3
+    # --same-instances: both ranks solved the same seeds -> the same poses, bit for bit
+    assert d["per_rank"][0]["pose_checksum"] > 0 and d["per_rank"][0]["pose_checksum"] == d["per_rank"][1]["pose_checksum"]

@@ -116,14 +116,26 @@ def test_c1_sliding_window_hip_vs_oracle(oracle, tmp_path):
             return ("round-off", {"oracle_summation_spread": spread, "hip_vs_oracle": err}) if err < 3 * spread else None
         return div
 
-    par = ParityOptimizer(OptimizerGpu(workspace=ws), OracleOptimizer(oracle), S.pose_error, classify=classify)
+    par = ParityOptimizer(OptimizerGpu(workspace=ws), OracleOptimizer(oracle), S.pose_error, classify=classify, classify_above=5e-5)
     seq, bundler, frames, errs = run_session(par, n, tmp_path=str(tmp_path), to_device=lambda a: torch.from_numpy(a).to(dev))
     assert len(par.diffs) == n - 1
     d = np.array(par.diffs)
-    # every call that leaves the 1e-4 bar is explained by a decision the two sides took differently
-    for call in np.nonzero(d >= 1e-4)[0]:
+    # every call above HALF the bar (5e-5) is classified, printed and must be explained by a decision the two sides took differently (or by
+    # the oracle's own summation-order spread): where exactly the largest call lands moves from box to box with the last bits
+    # (1.05e-4 ... 1.37e-4 over round 2's boxes), so the record of this box goes to gpurun_out/ for profiles/
+    for call in np.nonzero(d >= 5e-5)[0]:
         print(f"BA call {call}: diff {d[call]:.2e}, first differing decision {par.divergences.get(int(call))}")
         assert par.divergences.get(int(call)) is not None, f"BA call {call} differs by {d[call]:.2e} with identical accept / guard decisions"
+    try:
+        import json, socket
+        rec = {"host": socket.gethostname(), "calls": int(len(d)), "median": float(np.median(d)), "max": float(d.max()),
+               "above_5e-5": [{"call": int(c), "diff": float(d[c]), "explained_by": str(par.divergences.get(int(c)))[:300]} for c in np.nonzero(d >= 5e-5)[0]]}
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "session_parity_per_box.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
     # A converged window sits on the reference's PCG guard (r.z <= 1e-6 => no step, SolverBundling.cu:728-818): r.z
     # hovers at 0.9-1.1e-6 and last-bit rounding decides whether one more ~1e-4 step is taken in an iteration.  The
     # oracle's own two summation orders disagree on those calls (tests/tools/dbg_session.py); one or two flipped steps move a
