@@ -33,6 +33,7 @@ class FrameRef:
     pose_in_model: np.ndarray            # [4,4] camera -> model
     status: str = "OTHER"                # Frame::Status {FAIL, NO_BA, OTHER}, Frame.h:48-53
     n_keypts: int = 0
+    roi: tuple = (0.0, 1e9, 0.0, 1e9)    # (umin, umax, vmin, vmax) of the segmentation mask, Frame.h:81
     depth_gpu: object = None
     normal_gpu: object = None
     color_gpu: object = None
@@ -230,7 +231,10 @@ class Bundler:
         if last is not None:
             frame.id = last.id + 1
             frame.pose_in_model = np.array(last.pose_in_model, np.float32)             # :78-79
-        if frame.status == "FAIL":
+        if frame.roi[1] - frame.roi[0] < 10 or frame.roi[3] - frame.roi[2] < 10:        # :88-93: empty cloud -> FAIL and a plain return
+            frame.status = "FAIL"
+            return
+        if frame.status == "FAIL":                                                     # :96-101
             self.fm.forget_frame(frame)
             self.need_reinit = True
             return

@@ -321,7 +321,11 @@ void Bundler::processNewFrame(std::shared_ptr<Frame> frame)
         frame->_id = last_frame->_id + 1;
         frame->_pose_in_model = last_frame->_pose_in_model;
     }
-    if (frame->_status == Frame::FAIL) {                                         // :96-101 (an empty mask / cloud marked it)
+    if (frame->_roi[1] - frame->_roi[0] < 10 || frame->_roi[3] - frame->_roi[2] < 10) {      // :88-93: "cloud is empty, marked FAIL" -- a plain return:
+        frame->_status = Frame::FAIL;                                            // no forgetFrame, no re-initialisation request
+        return;
+    }
+    if (frame->_status == Frame::FAIL) {                                         // :96-101 (marked FAIL before it got here)
         _fm->forgetFrame(frame);
         _need_reinit = true;
         return;

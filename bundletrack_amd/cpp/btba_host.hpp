@@ -101,6 +101,7 @@ struct Frame {                                   // the fields of Frame (src/Fra
     Status _status = OTHER;
     Matrix4f _pose_in_model = Matrix4f::Identity();
     int _n_keypts = 0;
+    float _roi[4] = { 0.0f, 1e9f, 0.0f, 1e9f };  // (umin, umax, vmin, vmax) of the segmentation mask (Frame.h:81): a frame whose roi is under 10 px wide or high is FAIL (Bundler.cpp:88-93)
     float *_depth_gpu = nullptr;
     float4 *_normal_gpu = nullptr;
     uchar4 *_color_gpu = nullptr;

@@ -27,7 +27,21 @@ namespace svd3 {
 
 BTBA_HD float f_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 BTBA_HD uint32_t bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-BTBA_HD float rsqrt_rn(float x) { return (float)(1.0 / sqrt((double)x)); }         // __frsqrt_rn: correctly rounded
+// __frsqrt_rn: the CORRECTLY ROUNDED reciprocal square root.  y = 1 / sqrt(x) in double carries two roundings and the cast a third, so
+// (float) y can land on the wrong side when y falls within an ulp(double) of the midpoint of two floats (about one input in 2^29).  Those
+// are settled exactly: at a midpoint m (25 significant bits, m^2 exact in double) the sign of fma(m^2, x, -1) -- ONE rounding of the exact
+// m^2 x - 1 -- says on which side of m the true x^-1/2 lies (it is never ON a midpoint: m^2 x = 1 would make m a power of two).
+BTBA_HD float rsqrt_rn(float x)
+{
+    float r = (float)(1.0 / sqrt((double)x));
+    const uint32_t rb = bits(r);
+    if (!(r > 0.0f) || (rb & 0x7F800000u) == 0x7F800000u || (rb & 0x7F800000u) == 0u) return r;      // 0, inf, NaN, subnormal results: as computed
+    const float up = f_from_bits(rb + 1u), dn = f_from_bits(rb - 1u);
+    const double xd = (double)x, m_hi = 0.5 * ((double)r + (double)up), m_lo = 0.5 * ((double)r + (double)dn);
+    if (fma(m_hi * m_hi, xd, -1.0) < 0.0) r = up;               // x^-1/2 above the upper midpoint
+    else if (fma(m_lo * m_lo, xd, -1.0) > 0.0) r = dn;          // ... below the lower one
+    return r;
+}
 // one Newton step on the reciprocal square root, in the report's operation order: r (1.5 - 0.5 x r^2) as r + r/2 - x r (r (r/2))
 BTBA_HD float rsqrt_refined(float x)
 {

@@ -201,7 +201,19 @@ ORC_API int orc_procrustes(const float *src, const float *dst, int n_pts, float 
  * the CPU (tests/test_oracle_vs_reference.py).  Four sweeps of three approximate Jacobi conjugations, V from the accumulated
  * quaternion, B = A V, columns sorted by norm, Givens QR. */
 typedef struct { float s11, s21, s31, s22, s32, s33, qs, qx, qy, qz; } mc_state;
-static float mc_rsqrt(float x) { return (float)(1.0 / sqrt((double)x)); }
+/* correctly rounded x^-1/2 (__frsqrt_rn): the double result rounded to float, settled exactly at the two neighbouring midpoints by the sign
+ * of fma(m^2, x, -1) (m^2 is exact in double; one rounding) -- see bundletrack_amd/csrc/btba_svd3.hpp::rsqrt_rn, written separately */
+static float mc_rsqrt(float x)
+{
+    float r = (float)(1.0 / sqrt((double)x));
+    uint32_t rb; memcpy(&rb, &r, 4);
+    if (!(r > 0.0f) || (rb & 0x7F800000u) == 0x7F800000u || (rb & 0x7F800000u) == 0u) return r;
+    uint32_t ub = rb + 1u, db = rb - 1u; float up, dn; memcpy(&up, &ub, 4); memcpy(&dn, &db, 4);
+    const double mh = 0.5 * ((double)r + (double)up), ml = 0.5 * ((double)r + (double)dn);
+    if (fma(mh * mh, (double)x, -1.0) < 0.0) return up;
+    if (fma(ml * ml, (double)x, -1.0) > 0.0) return dn;
+    return r;
+}
 static float mc_rsqrt1(float x)                /* one Newton step: r + r/2 - x r (r (r/2)) */
 {
     const float r = mc_rsqrt(x), h = r * 0.5f;

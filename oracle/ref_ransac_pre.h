@@ -11,7 +11,17 @@
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }     // IEEE, never contracted
 static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
-static inline float __frsqrt_rn(float a) { return (float)(1.0 / sqrt((double)a)); }         // correctly rounded, like the intrinsic
+static inline float __frsqrt_rn(float a)                  // correctly rounded, like the intrinsic: double result, settled exactly at the neighbouring float midpoints
+{
+    float r = (float)(1.0 / sqrt((double)a));
+    unsigned rb; memcpy(&rb, &r, 4);
+    if (!(r > 0.0f) || (rb & 0x7F800000u) == 0x7F800000u || (rb & 0x7F800000u) == 0u) return r;
+    unsigned ub = rb + 1u, db = rb - 1u; float up, dn; memcpy(&up, &ub, 4); memcpy(&dn, &db, 4);
+    const double mh = 0.5 * ((double)r + (double)up), ml = 0.5 * ((double)r + (double)dn);
+    if (fma(mh * mh, (double)a, -1.0) < 0.0) return up;
+    if (fma(ml * ml, (double)a, -1.0) > 0.0) return dn;
+    return r;
+}
 // ransacGPU's (empty) signature mentions Eigen::Matrix4f
 namespace Eigen { struct Matrix4f {}; }
 // cuRAND -> oracle/xorwow.h (the published XORWOW algorithm restated; see that header for what pins it)

@@ -210,7 +210,8 @@ static int run_bundler(const char *in, const char *out)
         rd(f, fl, 2);
         rd(f, P, 16);
         fr->_id_str = std::to_string(k);
-        fr->_status = fl[0] ? Frame::FAIL : Frame::OTHER;
+        fr->_status = fl[0] == 1 ? Frame::FAIL : Frame::OTHER;
+        if (fl[0] == 2) { fr->_roi[0] = 10.0f; fr->_roi[1] = 14.0f; fr->_roi[2] = 10.0f; fr->_roi[3] = 200.0f; }      // an empty segmentation roi
         fr->_n_keypts = fl[1];
         fr->_pose_in_model = from_rowmajor(P);
         if (with_images) {

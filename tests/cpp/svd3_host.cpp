@@ -21,3 +21,9 @@ extern "C" __attribute__((visibility("default"))) int procrustes_reference_host(
     pose16[12] = pose16[13] = pose16[14] = 0.0f; pose16[15] = 1.0f;
     return ok ? 1 : 0;
 }
+
+// rsqrt_rn over an array (tests/test_oracle_ransac.py::test_rsqrt_is_correctly_rounded)
+extern "C" __attribute__((visibility("default"))) void rsqrt_rn_host(const float *x, int n, float *out)
+{
+    for (int k = 0; k < n; k++) out[k] = btba::svd3::rsqrt_rn(x[k]);
+}

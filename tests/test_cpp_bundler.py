@@ -56,6 +56,9 @@ class ShiftOptimizer:
             poses[i][0, 3] += np.float32(0.0009765625) * np.float32(i)
 
 
+EMPTY_ROI = set()        # frames (by sequence position) handed over with a degenerate segmentation roi (Bundler.cpp:88-93)
+
+
 def make_scenario(n, seed, corr_per_pair, fail=(), starved=(), images=False):
     seq = S.SyntheticSequence(n_frames=n, seed=seed)
     gen = S.SyntheticFeatureManager(seq, corr_per_pair=corr_per_pair)
@@ -81,7 +84,7 @@ def write_scenario(path, seq, table, imgs, fail, window_size, max_ba, min_edges,
         f.write(np.asarray(seq.K, np.float32).tobytes())
         f.write(np.array([min_rot], np.float32).tobytes())
         for k in range(n):
-            f.write(np.array([int(k in fail), 300], np.int32).tobytes())
+            f.write(np.array([2 if k in EMPTY_ROI else int(k in fail), 300], np.int32).tobytes())      # 2: a frame whose mask roi is empty
             f.write(seq.poses_gt[0].astype(np.float32).tobytes())
             if imgs is not None:
                 f.write(np.ascontiguousarray(imgs[k][0], np.float32).tobytes())
@@ -102,7 +105,9 @@ def python_log(seq, table, imgs, fail, optimizer, window_size, max_ba, min_edges
         fr = FrameRef(id=0, pose_in_model=seq.poses_gt[0].astype(np.float32), n_keypts=300, depth_gpu=d, normal_gpu=nrm)
         fr.seq = k
         fr.id_str = str(k)
-        if k in fail:
+        if k in EMPTY_ROI:
+            fr.roi = (10.0, 14.0, 10.0, 200.0)          # 4 px wide: "cloud is empty, marked FAIL" -- a plain return, no forgetFrame / re-init request
+        elif k in fail:
             fr.status = "FAIL"
         bundler.process_new_frame(fr)
         ran = fr.status != "FAIL" and fr.id >= 1
@@ -129,6 +134,7 @@ def test_cpp_bundler_control_flow_matches_python(tmp_path):
     it never becomes a keyframe), a keyframe pool that outgrows max_BA_frames (greedy subset), window_size 2 (frames and their
     matches forgotten unless they are keyframes): the same decisions and the same poses, frame by frame."""
     for window_size, max_ba in ((2, 5), (5, 15)):
+        EMPTY_ROI.clear(); EMPTY_ROI.add(17)                                              # the second failing frame fails through its empty roi
         seq, table, imgs, fail = make_scenario(26, 401, 60, fail=(6, 17), starved=(11,))
         inp, out = str(tmp_path / "scenario.bin"), str(tmp_path / "log.txt")
         write_scenario(inp, seq, table, None, fail, window_size, max_ba, 5, False)
@@ -143,9 +149,12 @@ def test_cpp_bundler_control_flow_matches_python(tmp_path):
         stat = [r[0][2] for r in py]
         assert stat.count(0) == 2 and stat.count(1) == 1                                  # FAIL, FAIL, NO_BA
         assert [r[0][1] for r in py][7] == 6                                              # the id of the failed frame 6 is used again
+        need_reinit = [r[0][3] for r in py]
+        assert need_reinit[6] == 1 and need_reinit[17] == need_reinit[16]                 # a FAIL frame asks for re-initialisation, an empty roi does not (Bundler.cpp:88-101)
         assert bundler.n_ba_calls == 26 - 1 - 2 - 1 and len(bundler.keyframes) >= 5
         if max_ba == 5:
             assert max(r[0][5] for r in py) == 5 and len(bundler.keyframes) > 5           # the pool did not fit: the greedy subset ran
+    EMPTY_ROI.clear()
 
 
 def test_cpp_pose_file_is_the_inverse_pose_in_the_reference_format(tmp_path):

@@ -1,6 +1,8 @@
 """Pins for the RANSAC oracle (oracle/btba_oracle_ransac.c).  Self-derived: the reference has no vectors for this
 step, its sample generator (cuRAND) and its approximate 3x3 SVD (McAdams) are third-party code absent from the
 checkout -- see the oracle's header."""
+import os
+
 import numpy as np
 import pytest
 
@@ -81,3 +83,41 @@ def test_ransac_recovers_planted_inliers(oracle):
     # nothing to fit
     r = oracle.ransac_pair(P[:2], Q[:2], 50, 0.01, seed=3)
     assert r["best_trial"] == -1 and len(r["inlier_ids"]) == 0
+
+
+def test_rsqrt_is_correctly_rounded():
+    """btba_svd3.hpp::rsqrt_rn (the product's __frsqrt_rn) returns THE float nearest to x^-1/2: checked with exact integer arithmetic -- for
+    a float r with neighbours r-, r+ the claim is  m_lo^2 x < 1 < m_hi^2 x  at the two midpoints, evaluated in Python integers -- on
+    two million random inputs over 60 binades, the perfect squares, and inputs constructed to sit next to a midpoint (where the plain
+    (float)(1 / sqrt((double) x)) of round 2 can round the wrong way)."""
+    import ctypes as C, subprocess
+    from fractions import Fraction
+    here = os.path.dirname(os.path.abspath(__file__))
+    so, src_cpp = os.path.join(here, "cpp", "libsvd3_host.so"), os.path.join(here, "cpp", "svd3_host.cpp")
+    hdr = os.path.join(os.path.dirname(here), "bundletrack_amd", "csrc", "btba_svd3.hpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src_cpp), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-o", so, src_cpp])
+    f = C.CDLL(so).rsqrt_rn_host
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]; f.restype = None
+    rng = np.random.default_rng(11)
+    x = np.concatenate([
+        (rng.uniform(1.0, 4.0, 2_000_000) * 2.0 ** rng.integers(-30, 30, 2_000_000)).astype(np.float32),
+        (np.arange(1, 4097, dtype=np.float32) ** 2),
+        # x = nearest float to 1 / m^2 for float midpoints m: x^-1/2 lies within ~1e-8 relative of m, the hard neighbourhood
+        (1.0 / ((np.float32(1.0) + np.arange(1, 200001, 7, dtype=np.float64) * 2.0 ** -23 + 2.0 ** -24) ** 2)).astype(np.float32),
+    ])
+    out = np.zeros_like(x)
+    f(x.ctypes.data, len(x), out.ctypes.data)
+    # vectorised screen in extended precision, then the exact check on the closest calls
+    ld = np.longdouble
+    y = 1.0 / np.sqrt(x.astype(ld))
+    up, dn = np.nextafter(out, np.float32(np.inf)), np.nextafter(out, np.float32(0))
+    m_hi, m_lo = (out.astype(ld) + up.astype(ld)) / 2, (out.astype(ld) + dn.astype(ld)) / 2
+    assert (y < m_hi).all() and (y > m_lo).all()
+    margin = np.minimum((m_hi - y) / y, (y - m_lo) / y).astype(np.float64)
+    for k in np.argsort(margin)[:2000]:
+        X = Fraction(float(x[k]))
+        mh, ml = (Fraction(float(out[k])) + Fraction(float(up[k]))) / 2, (Fraction(float(out[k])) + Fraction(float(dn[k]))) / 2
+        assert ml * ml * X < 1 < mh * mh * X, (float(x[k]), float(out[k]))
+    naive = (1.0 / np.sqrt(x.astype(np.float64))).astype(np.float32)
+    print(f"rsqrt_rn: {len(x)} inputs correctly rounded; the plain double-then-float form differs on {(naive != out).sum()} of them; smallest midpoint margin {margin.min():.2e}")
