@@ -24,7 +24,7 @@ RANSAC_REFERENCE_SVD, RANSAC_HORN = 0, 1
 RANSAC_DRAW_HASH = 0x100      # ORed into `hypothesis`: counter-hash sample triples instead of the reference's cuRAND XORWOW stream
 FLAG_TRACE, FLAG_TIME_KERNELS = 1, 2
 FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_KEYED_CORR, FLAG_FLOAT4_CACHE, FLAG_NO_COMPACTION, FLAG_COMPACTION, FLAG_TIME_SAMPLED = 32, 64, 4096, 256, 512, 1024, 2048
-OPT_DENSE_ORDER, OPT_TILE_MAJOR, OPT_BLOCK_WALK, OPT_BLOCK_SKIP, OPT_BIG_ASSEMBLY, OPT_OVERLAP_GROUPS, OPT_OVERLAP_EQUAL_PRIO, OPT_KEYED_CORR_MIN_BYTES = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_DENSE_ORDER, OPT_TILE_MAJOR, OPT_BLOCK_WALK, OPT_BLOCK_SKIP, OPT_BIG_ASSEMBLY, OPT_OVERLAP_GROUPS, OPT_OVERLAP_EQUAL_PRIO, OPT_KEYED_CORR_MIN_BYTES, OPT_SPARSE_TAIL = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 ENTRYJ_DTYPE = np.dtype(
     [("imgIdx_i", "<u4"), ("imgIdx_j", "<u4"), ("pos_i", "<f4", (3,)), ("pos_j", "<f4", (3,))]

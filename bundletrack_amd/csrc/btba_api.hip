@@ -73,6 +73,7 @@ struct btba_workspace {
         bool tile_major = true;        // BTBA_OPT_TILE_MAJOR    (env BTBA_PAIR_MAJOR=1 turns it off): (band, pair) instead of (pair, band) work order
         bool block_walk = true;        // BTBA_OPT_BLOCK_WALK    (env BTBA_NO_BLOCK_WALK=1): waves walk 8 x 8 blocks instead of 64 x 1 strips
         bool block_skip = true;        // BTBA_OPT_BLOCK_SKIP    (env BTBA_NO_BLOCK_SKIP=1): provably dead blocks are not walked
+        int sparse_tail_256 = -1;      // BTBA_OPT_SPARSE_TAIL   (env BTBA_SPARSE_TAIL): share (x / 256) of the sparse items that close the fused launch; -1 = the library's choice
         bool big_assembly = true;      // BTBA_OPT_BIG_ASSEMBLY  (env BTBA_NO_BIG_ASSEMBLY=1): many-workgroup reduction / assembly from 24 frames on
         int overlap_groups = 2;        // BTBA_OPT_OVERLAP_GROUPS (env BTBA_GROUPS): instance groups of BTBA_FLAG_OVERLAP
         bool overlap_equal_prio = false;   // BTBA_OPT_OVERLAP_EQUAL_PRIO (env BTBA_GROUP_PRIO=e...)
@@ -198,6 +199,7 @@ static int workspace_create(btba_workspace **out, void *stream, bool use_given)
         t.block_walk = !on("BTBA_NO_BLOCK_WALK");
         t.block_skip = !on("BTBA_NO_BLOCK_SKIP");
         t.big_assembly = !on("BTBA_NO_BIG_ASSEMBLY");
+        if (const char *e = std::getenv("BTBA_SPARSE_TAIL")) t.sparse_tail_256 = std::max(0, std::min(256, std::atoi(e)));
         if (const char *e = std::getenv("BTBA_GROUPS")) t.overlap_groups = std::atoi(e);
         if (const char *e = std::getenv("BTBA_GROUP_PRIO")) t.overlap_equal_prio = e[0] == 'e';
         if (const char *e = std::getenv("BTBA_KEYED_CORR_MIN_BYTES")) t.keyed_corr_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
@@ -243,6 +245,7 @@ int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
     case BTBA_OPT_BLOCK_WALK: t.block_walk = value != 0; break;
     case BTBA_OPT_BLOCK_SKIP: t.block_skip = value != 0; break;
     case BTBA_OPT_BIG_ASSEMBLY: t.big_assembly = value != 0; break;
+    case BTBA_OPT_SPARSE_TAIL: if (value < -1 || value > 256) return BTBA_EINVAL; t.sparse_tail_256 = (int)value; break;
     case BTBA_OPT_OVERLAP_GROUPS: if (value < 1 || value > btba_workspace::kMaxGroups) return BTBA_EINVAL; t.overlap_groups = (int)value; break;
     case BTBA_OPT_OVERLAP_EQUAL_PRIO: t.overlap_equal_prio = value != 0; break;
     case BTBA_OPT_KEYED_CORR_MIN_BYTES: if (value < 0) return BTBA_EINVAL; t.keyed_corr_min_bytes = (size_t)value; break;
@@ -542,6 +545,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.pair_lens = pair_lens;
     if (Pd > 0) { D.dense_work = reinterpret_cast<const int4 *>(ws->dense_pairs.as<int32_t>() + ws->dense_work_offset); D.work_formula = ws->work_formula; }      // work position -> (target, source, pair, -)
     D.tile_major = ws->tune.tile_major ? 1 : 0;
+    D.sparse_tail_256 = 0;             // set below, once the dense layout is known
     D.walk_blocks = (Wd % 8 == 0 && Hd % 8 == 0 && Wd + Hd <= 1024 && ws->tune.block_walk) ? 1 : 0;
     D.n_gn = prm->n_gn_iters;
     int zn_layout = 0;
@@ -629,6 +633,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // block walk of the pinhole sweep: per-block depth ranges for its dead-block test, and the LDS it needs for the list of live blocks
     size_t blist_bytes = 0;
     if (!(zn_layout == 1 && use_dense && !compaction)) D.walk_blocks = 0;
+    // where the sparse items go in the fused launch: all of them at the END when the dense items are the long, VALU-bound walks over full
+    // frames (c3 x 32: 176.4 -> 170.5 us per launch, gpurun_out/r03_24: they fill the launch's drain); interleaved when the dense items are
+    // the short list walks of object-masked frames (49.7 interleaved against 53.3 us)
+    D.sparse_tail_256 = ws->tune.sparse_tail_256 >= 0 ? ws->tune.sparse_tail_256 : ((use_dense && !compaction) ? 256 : 0);
     if (D.walk_blocks) {
         const int bw = Wd / 8, bh = Hd / 8;
         const size_t band_blocks = (size_t)((bh + tiles - 1) / tiles) * bw;

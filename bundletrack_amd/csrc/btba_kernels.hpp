@@ -75,6 +75,7 @@ struct SolveDims {
     int work_formula;             // 1 / 2: the table is the closed form "all pairs by ascending |i - j|, then ascending i" with target = lower / higher
                                   // frame -- the pinhole sweeps then compute their item instead of loading it (one memory round trip less)
     const float2 *block_ranges;   // per (cache slot, 8 x 8 block): [min, max] valid depth (k_block_ranges); nullptr: no block is skipped
+    int sparse_tail_256; // fused sweep: share (in 1/256) of the sparse items placed at the END of each XCD's item sequence instead of interleaved
     int tile_major;      // dense work order inside an instance: 1 = (tile, pair) -- all pairs' band t of the images together -- 0 = (pair, tile)
     int *order_flag;     // non-null: the sparse sweep ORs 1 into it when an entry does not belong to the pair of its segment
     int atomic_sums;     // BTBA_REDUCE_ATOMIC: sweep workgroups ADD their sums into one record per pair (float atomics) instead of storing one record
@@ -1220,19 +1221,29 @@ __device__ __forceinline__ void fused_item(const SolveDims &D, unsigned n_d, uns
     const unsigned Gx = (G - xcd + 7u) >> 3, ndx = qd + (xcd < rd ? 1u : 0u), nsx = Gx - ndx;
     unsigned sparse_base = 0;                                   // sparse items owned by lower XCDs
     for (unsigned y = 0; y < xcd; y++) sparse_base += ((G - y + 7u) >> 3) - (qd + (y < rd ? 1u : 0u));
-    const unsigned Rx = nsx ? Gx / nsx : 0xFFFFFFFFu;
-    const bool is_sparse = nsx && (slot % Rx == 0u) && (slot / Rx < nsx);
+    // Sparse items: a share of them (D.sparse_tail_256 / 256) is HELD BACK to the end of the XCD's sequence, the rest is interleaved evenly
+    // among the dense items.  A launch ends with its occupancy falling for ~30 us while the last long dense items finish (12-15 % of its
+    // span); short, HBM-streaming sparse items fill those emptying slots, and the dense items start that much earlier.
+    const unsigned nst = (nsx * (unsigned)D.sparse_tail_256) >> 8, nsi = nsx - nst, Gi = ndx + nsi;
+    // (an even interleave period from 4 on is lowered to the odd one below it: with periods 4 and 6 the sparse items of an XCD kept landing on
+    // the same compute units of the dispatcher's round robin -- 196 and 182 us per launch against 171 us at period 5, gpurun_out/r03_24;
+    // period 2, the masked launch's plain alternation, measured fine)
+    const unsigned Rx0 = nsi ? Gi / nsi : 0xFFFFFFFFu;
+    const unsigned Rx = (nsi && Rx0 >= 4u && !(Rx0 & 1u)) ? Rx0 - 1u : Rx0;
+    const bool in_tail = slot >= Gi;
+    const bool is_sparse = in_tail || (nsi && (slot % Rx == 0u) && (slot / Rx < nsi));
+    const unsigned sparse_local = in_tail ? nsi + (slot - Gi) : slot / Rx;
 #ifdef BTBA_WG_TRACE
     const unsigned long long wg_t0 = wall_clock64();
 #endif
     if (is_sparse) {
-        const unsigned i = sparse_base + slot / Rx;              // (chunk fastest, then pair, then instance)
+        const unsigned i = sparse_base + sparse_local;           // (chunk fastest, then pair, then instance)
         const int chunk = (int)(i % (unsigned)D.sparse_chunks);
         const int p = (int)((i / (unsigned)D.sparse_chunks) % (unsigned)D.n_pairs);
         const int b = (int)(i / ((unsigned)D.sparse_chunks * (unsigned)D.n_pairs));
         sparse_block(D, corr, pair_offsets, T, sparse_partials, chunk, p, b, red);
     } else {
-        const unsigned before = nsx ? min(nsx, (slot + Rx - 1u) / Rx) : 0u;     // sparse slots of this XCD before `slot`
+        const unsigned before = nsi ? min(nsi, (slot + Rx - 1u) / Rx) : 0u;     // sparse slots of this XCD before `slot`
         const unsigned dl = slot - before;                                      // dense item local to the XCD
         const unsigned L = (xcd < rd ? xcd * (qd + 1u) : rd * (qd + 1u) + (xcd - rd) * qd) + dl;
         const int b = (int)(L / ((unsigned)D.dense_tiles * (unsigned)D.n_dense_pairs));

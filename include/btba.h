@@ -194,6 +194,7 @@ enum {
     BTBA_OPT_BIG_ASSEMBLY         = 5,  /* 1 (default): many-workgroup reduction / assembly from 24 frames on; 0: one workgroup. env BTBA_NO_BIG_ASSEMBLY */
     BTBA_OPT_OVERLAP_GROUPS       = 6,  /* instance groups of BTBA_FLAG_OVERLAP, 1 .. 8 (default 2).                            env BTBA_GROUPS         */
     BTBA_OPT_OVERLAP_EQUAL_PRIO   = 7,  /* 1: the groups' streams get equal priority (default 0: lowest for groups >= 1).        env BTBA_GROUP_PRIO=e   */
+    BTBA_OPT_SPARSE_TAIL          = 9,  /* 0 .. 256: share (x / 256) of the sparse items that close the fused sweep instead of being interleaved (fills the launch's drain); -1 (default): 256 on full frames, 0 on object-masked ones. env BTBA_SPARSE_TAIL */
     BTBA_OPT_KEYED_CORR_MIN_BYTES = 8   /* BTBA_FLAG_KEYED_CORR is ignored below this many bytes of correspondences (default 1 MiB). env of the same name */
 };
 BTBA_API int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value);
