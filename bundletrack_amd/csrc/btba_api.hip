@@ -536,6 +536,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.fx = intr[0]; D.fy = intr[1]; D.cx = intr[2]; D.cy = intr[3];
     D.robust_delta = prm->robust_delta; D.dist_thresh = prm->dense_dist_thresh; D.normal_thresh = prm->dense_normal_thresh;
     D.dist2_thresh = prm->dense_dist_thresh * prm->dense_dist_thresh;
+    D.wm1 = (float)(Wd - 1); D.hm1 = (float)(Hd - 1); D.wm2 = (float)(Wd - 2); D.hm2 = (float)(Hd - 2);
     D.depth_min = prm->depth_min; D.depth_max = prm->depth_max;
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;

@@ -219,7 +219,7 @@ typedef int btba_i4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld_const_f4(const void *p) { const btba_f4v v = *as_const(reinterpret_cast<const btba_f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ int4 ld_const_i4(const void *p) { const btba_i4v v = *as_const(reinterpret_cast<const btba_i4v *>(p)); return make_int4(v.x, v.y, v.z, v.w); }
 
-// threadIdx.x through an opaque copy.  Inside the item loop of the persistent sweep (k_fused_persist) everything derived from the thread
+// threadIdx.x through an opaque copy.  Inside the item loop of the persistent sweep (k_fused_sweeps) everything derived from the thread
 // index is loop-invariant to the compiler, which hoists it all out of the loop and then spills it (52 vector spills); taken through this
 // function at the top of each per-item block, the values live only as long as the item.
 __device__ __forceinline__ unsigned item_tid() { unsigned t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }

@@ -59,6 +59,7 @@ struct SolveDims {
     float fx, fy, cx, cy;
     float robust_delta, dist_thresh, normal_thresh, depth_min, depth_max;
     float dist2_thresh;  // dist_thresh^2 (fp32 product, formed once on the host)
+    float wm1, hm1, wm2, hm2;     // (float)(width - 1), (height - 1), (width - 2), (height - 2): the dense sweep's clamp bounds -- from the host, so that they arrive in SCALAR registers
     float w_sparse, w_dense;
     int64_t corr_stride; // EntryJ per instance block
     int trace_on;
@@ -845,7 +846,7 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
 //     values, zeros and NaN fall outside after the subtraction wraps;
 //   * wave-uniform operands of 2-cycle operations (relative pose, intrinsics) live in VGPRs.
 #ifdef BTBA_WG_TRACE
-__shared__ unsigned long long wg_dbg[4];       // developer build: (end of prologue, end of pixel loop, live blocks) of the workgroup's dense item
+__shared__ unsigned long long wg_dbg[12];       // developer build: (end of prologue, end of pixel loop, live blocks) of the workgroup's dense item
 #endif
 struct PinholeCtx {
     float R[9], t[3];                 // relative pose source camera -> target camera (scalar registers)
@@ -862,6 +863,14 @@ __device__ __forceinline__ unsigned opaque_vgpr(unsigned x) { asm volatile("" : 
 // v_min_f32 as the hardware does it: fminf() makes the compiler canonicalise its operands first (v_max_f32 x, x, x -- a half-rate
 // instruction per operand, repeated in the loop even for loop invariants); the operands here are never signalling NaNs
 __device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// a * b + c as a v_fma_f32 whose destination is none of its sources.  An FMA that overwrites one of its own sources (v_fmac_f32, or v_fma_f32 with
+// D = C) issues at HALF rate when its other two sources sit in VGPRs of the same parity or are the same register (profiles/r02/valu_calibration.md,
+// rows `x:`); which registers they get is the allocator's business.  With the destination elsewhere the instruction is full rate whatever it does.
+__device__ __forceinline__ float fma_nd(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// ... with a wave-uniform bound held in a SCALAR register: v_min / v_med3 are half-rate whatever their operands, so the scalar operand costs
+// no issue slot and the bound does not occupy a VGPR of a kernel that spills (left alone, the compiler keeps such loop invariants in VGPRs)
+__device__ __forceinline__ float min_raw_s(float a, float bound) { float r; asm("v_min_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(bound)); return r; }
+__device__ __forceinline__ float clamp0_s(float a, float bound) { float r; asm("v_med3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(bound)); return r; }     // med3(a, bound, 0); NaN -> 0
 __device__ __forceinline__ float sgpr(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
 
 // column / row term of the back-projection of cache column / row e (e >= width: row e - width): K^-1[0][0] x_full(e) + K^-1[0][2] resp.
@@ -1010,7 +1019,9 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         }
     } else __syncthreads();
     C.fx = D.fx; C.fy = D.fy; C.cx = D.cx; C.cy = D.cy;
-    C.wm1 = (float)(D.width - 1); C.hm1 = (float)(D.height - 1); C.wm2 = (float)(D.width - 2); C.hm2 = (float)(D.height - 2);
+    // the clamp bounds come from the host: a float the kernel makes itself (v_cvt_f32_i32) lives in a VGPR for the whole loop; as kernel arguments
+    // they are scalar operands of clamp0_s / min_raw_s
+    C.wm1 = D.wm1; C.hm1 = D.hm1; C.wm2 = D.wm2; C.hm2 = D.hm2;
     C.w16 = 16.0f * (float)D.width; C.row16 = 16u * (unsigned)D.width;
     C.ybase4 = 4.0f * (float)D.width;                     // LDS byte offset of the row table
     C.normal_thresh = D.normal_thresh; C.dist2_thresh = D.dist2_thresh;
@@ -1023,7 +1034,14 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     for (int k = 0; k < kDenseVals; k++) acc[k] = 0.0f;
 
     // one source pixel: zs = its (gated depth, normal), ox / oy = LDS byte offsets of its column / row entries in the ray tables (from colA)
+#ifdef BTBA_TRIP_TRACE
+    unsigned long long tt_a = 0, tt_b = 0, tt_c = 0, tt_live = 0, tt_dead = 0;       // shader-clock sums of this wave: top of the trip / taps in flight / blend + accumulate
+    auto stamp_after = [](float dep) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory"); return t; };
+#endif
     auto pixel = [&](const float4 &zs, unsigned ox, unsigned oy) {
+#ifdef BTBA_TRIP_TRACE
+        unsigned long long tt0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt0) :: "memory");
+#endif
         // source pixel -> camera space (gated depth: 0 where invalid), depth-range test on the bit pattern
         const float d = zs.x;
         const bool src_ok = (__float_as_uint(d) - C.zmin_bits) < C.zrange_bits;
@@ -1032,34 +1050,51 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const float qx = (ra.x + rb.x) * d + C.t[0], qy = (ra.y + rb.y) * d + C.t[1], qz = (ra.z + rb.z) * d + C.t[2];
         const float rqz = fast_rcp(qz);
         const float u = qx * C.fx * rqz + C.cx, v = qy * C.fy * rqz + C.cy;
-        const float uc = __builtin_amdgcn_fmed3f(u, 0.0f, C.wm1), vc = __builtin_amdgcn_fmed3f(v, 0.0f, C.hm1);      // NaN -> 0: addresses stay in the frame
+        const float uc = clamp0_s(u, C.wm1), vc = clamp0_s(v, C.hm1);      // NaN -> 0: addresses stay in the frame
         const bool valid = src_ok & (fabsf(u - uc) < 0.5f) & (fabsf(v - vc) < 0.5f);
+#ifdef BTBA_TRIP_TRACE
+        const unsigned long long tt1 = stamp_after(valid ? uc : vc);
+        tt_a += tt1 - tt0;
+        if (__builtin_amdgcn_ballot_w64(valid) == 0ull) { tt_dead++; return; }
+#else
         if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
+#endif
         // rotate the normal (only the waves that go on need it: half of the block trips end above)
         const float nqx = C.R[0] * zs.y + C.R[1] * zs.z + C.R[2] * zs.w;
         const float nqy = C.R[3] * zs.y + C.R[4] * zs.z + C.R[5] * zs.w;
         const float nqz = C.R[6] * zs.y + C.R[7] * zs.z + C.R[8] * zs.w;
         // taps (x0, x0 + 1) x (y0, y0 + 1) with x0 = min(floor(uc), W - 2): at the right / bottom edge (uc = W - 1) the weights are (0, 1)
         // instead of (1, -) -- the same blend, and the four taps are always the 2 x 2 block at ONE computed address
-        const float fx0 = min_raw(floorf(uc), C.wm2), fy0 = min_raw(floorf(vc), C.hm2);
+        const float fx0 = min_raw_s(floorf(uc), C.wm2), fy0 = min_raw_s(floorf(vc), C.hm2);
         const float alpha = uc - fx0, beta = vc - fy0;
         const unsigned o00 = (unsigned)(fy0 * C.w16 + 16.0f * fx0), o01 = o00 + C.row16;      // byte offsets, fp32-exact below 2^24
         const float4 z00 = gather16(zn_t, o00), z10 = gather16(zn_t, o00 + 16u), z01 = gather16(zn_t, o01), z11 = gather16(zn_t, o01 + 16u);
         const float2 xi2 = lds_f32x2_at(lut, (unsigned)(4.0f * fx0)), yi2 = lds_f32x2_at(lut, (unsigned)(4.0f * fy0 + C.ybase4));
         const float a0 = 1.0f - alpha, b0 = 1.0f - beta;
         // blend of the taps' camera-space points (x = column term * z, y = row term * z, z = gated depth) and normals; the
-        // column / row terms are shared by the taps of a column / row, so they multiply the partial sums
-        const float t00 = (b0 * a0) * z00.x, t10 = (b0 * alpha) * z10.x, t01 = (beta * a0) * z01.x, t11 = (beta * alpha) * z11.x;
+        // column / row terms are shared by the taps of a column / row, so they multiply the partial sums:
+        //     cix = xi2.x (t00 + t01) + xi2.y (t10 + t11),  ciy = yi2.x (t00 + t10) + yi2.y (t01 + t11),  ciz = (t00 + t01) + (t10 + t11),  t = c z
+        //     ni  = c00 z00.n + c10 z10.n + c01 z01.n + c11 z11.n
+        // written out as the fused multiply-adds the compiler contracts these expressions to (x y + z w -> fma(x, y, z w), left to right --
+        // the bits of every build since round 1), each as fma_nd: 13 of the 20 were v_fmac whose two multiplicands happened to sit in VGPRs
+        // of the same parity, which issue at half rate (26 of a trip's ~400 issue cycles).
         const float c00 = b0 * a0, c10 = b0 * alpha, c01 = beta * a0, c11 = beta * alpha;
-        const float cix = xi2.x * (t00 + t01) + xi2.y * (t10 + t11);
-        const float ciy = yi2.x * (t00 + t10) + yi2.y * (t01 + t11);
-        const float ciz = (t00 + t01) + (t10 + t11);
-        const float nix = c00 * z00.y + c10 * z10.y + c01 * z01.y + c11 * z11.y;
-        const float niy = c00 * z00.z + c10 * z10.z + c01 * z01.z + c11 * z11.z;
-        const float niz = c00 * z00.w + c10 * z10.w + c01 * z01.w + c11 * z11.w;
+        const float t10 = c10 * z10.x, t01 = c01 * z01.x, t11 = c11 * z11.x;
+        const float s0x = fma_nd(c00, z00.x, t01), s0y = fma_nd(c00, z00.x, t10);       // t00 + t01, t00 + t10
+        const float s1x = fma_nd(c10, z10.x, t11), s1y = fma_nd(c01, z01.x, t11);       // t10 + t11, t01 + t11
+        const float cix = fma_nd(xi2.x, s0x, xi2.y * s1x);
+        const float ciy = fma_nd(yi2.x, s0y, yi2.y * s1y);
+        const float ciz = s0x + s1x;
+        const float nix = fma_nd(c11, z11.y, fma_nd(c01, z01.y, fma_nd(c00, z00.y, c10 * z10.y)));
+        const float niy = fma_nd(c11, z11.z, fma_nd(c01, z01.z, fma_nd(c00, z00.z, c10 * z10.z)));
+        const float niz = fma_nd(c11, z11.w, fma_nd(c01, z01.w, fma_nd(c00, z00.w, c10 * z10.w)));
+#ifdef BTBA_TRIP_TRACE
+        const unsigned long long tt3 = stamp_after(z00.x + z10.x + z01.x + z11.x);
+        tt_b += tt3 - tt1;
+#endif
         const float dx = qx - cix, dy = qy - ciy, dz = qz - ciz;
-        const float dist2 = dx * dx + dy * dy + dz * dz;
-        const float dn = nqx * nix + nqy * niy + nqz * niz;
+        const float dist2 = fma_nd(dz, dz, fma_nd(dx, dx, dy * dy));
+        const float dn = fma_nd(nqz, niz, fma_nd(nqx, nix, nqy * niy));
         const bool ok = valid & ((__float_as_uint(ciz) - C.zmin_bits) < C.zrange_bits) & (dn >= C.normal_thresh) & (dist2 <= C.dist2_thresh);
         // rejected pixels contribute exact zeros: AND with 0 / ~0 (one select, then 2-cycle v_and_b32; NaN-safe, unlike a multiply)
         const unsigned keep = opaque_vgpr(ok ? 0xFFFFFFFFu : 0u);
@@ -1067,10 +1102,10 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         // SIGNS: the row is accumulated as a+ = [n_i ; n_i x q] and the residual as res+ = (q - c_i) . n_i, i.e. a = D a+ with
         // D = diag(-1, -1, -1, 1, 1, 1) and res = -res+ (SolverBundlingDenseUtil.h:78-110, LieDerivUtil.h:228-273).  Then S = D S+ D and
         // g = -D g+ : exact sign changes of whole sums, applied once per workgroup in the epilogue instead of four negations per pixel.
-        const float res = masked(dx * nix + dy * niy + dz * niz);
+        const float res = masked(fma_nd(dz, niz, fma_nd(dx, nix, dy * niy)));
         // Huber (SolverBundlingUtil.h:24-40) times the dense weight: rho' = 1 for e <= delta^2, delta / sqrt(e) above  <=>  min(1, delta rsq(e)).
         // Not masked: a rejected pixel has res = 0, rsq(0) = inf, min(w, inf) = w -- finite, and it multiplies a masked (zero) row.
-        const float wgt = min_raw(C.w_dense, C.wdelta * fast_rsq(res * res));
+        const float wgt = min_raw_s(C.wdelta * fast_rsq(res * res), C.w_dense);
         const float mx = masked(nix), my = masked(niy), mz = masked(niz);
         const float a[6] = { mx, my, mz, my * qz - mz * qy, mz * qx - mx * qz, mx * qy - my * qx };
         int k = 0;
@@ -1090,6 +1125,9 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
             acc[21 + r] += pr[r].x * rr.y;
         }
         acc[27] += masked(1.0f);
+#ifdef BTBA_TRIP_TRACE
+        tt_c += stamp_after(acc[27] + acc[0] + acc[20] + acc[26]) - tt3; tt_live++;
+#endif
     };
 
     if (WALK == 2) {
@@ -1105,34 +1143,38 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const unsigned lane_px = ly * (unsigned)D.width + lx;          // pixel offset of the lane inside its block
         const unsigned ox_l = 16u * lx, oy_l = 16u * ly + 16u * (unsigned)D.width;
         constexpr unsigned kBlockStep = 128u;            // 8 entries of 16 bytes
-        // this wave's current and next block (scalar registers), the next block's pixels in flight while the current one is worked on.
+        // This wave's blocks: list entries wave, wave + 4, ... -- nt of them.  While block i is worked on, block i + 1's pixels are in flight.
+        // The prefetch is UNCONDITIONAL (the last trip re-reads its own block): with a conditional one the number of loads in flight behind it
+        // depended on the path taken and the compiler had to wait for ALL of them (`s_waitcnt vmcnt(0)` right behind the prefetch it had just
+        // issued: the stream latency was paid in full on every trip, 2 % of the launch); now the wait for the current block's pixels is `vmcnt(1)`.
+        // (Reading the list entry one more trip ahead, so that the prefetch is issued from a scalar register without an LDS round trip in
+        // front of it: no change, r03 call 40.)
         // Two trips per loop iteration with the two register sets swapping roles: a single-trip loop rotates (next -> current) through
         // eight v_mov per trip, 5 % of its instructions.
-        auto fetch = [&](int kk, unsigned &code, float4 &zs) {
-            code = (unsigned)__builtin_amdgcn_readfirstlane((int)blist[kk]);
+        const int nt = (n_live > wave) ? (n_live - wave + kBlock / 64 - 1) / (kBlock / 64) : 0;
+        auto fetch = [&](int i, unsigned &code, float4 &zs) {
+            code = (unsigned)__builtin_amdgcn_readfirstlane((int)blist[wave + (kBlock / 64) * min(i, nt - 1)]);
             zs = gather16(zn_s, 16u * ((code >> 16) * 8u * (unsigned)D.width + (code & 0xFFFFu) * 8u + lane_px));
         };
         auto work = [&](const float4 &zs, unsigned code) { pixel(zs, ox_l + kBlockStep * (code & 0xFFFFu), oy_l + kBlockStep * (code >> 16)); };
-        int k = wave;
-        if (k < n_live) {
+        if (nt > 0) {
             unsigned code_a, code_b = 0u;
             float4 zs_a, zs_b = make_float4(0.f, 0.f, 0.f, 0.f);
-            fetch(k, code_a, zs_a);
-            for (;;) {
-                k += kBlock / 64;
-                const bool more_b = k < n_live;
-                if (more_b) fetch(k, code_b, zs_b);
+            fetch(0, code_a, zs_a);
+            for (int i = 0;;) {
+                fetch(i + 1, code_b, zs_b);
                 work(zs_a, code_a);
-                if (!more_b) break;
-                k += kBlock / 64;
-                const bool more_a = k < n_live;
-                if (more_a) fetch(k, code_a, zs_a);
+                if (++i >= nt) break;
+                fetch(i + 1, code_a, zs_a);
                 work(zs_b, code_b);
-                if (!more_a) break;
+                if (++i >= nt) break;
             }
         }
 #ifdef BTBA_WG_TRACE
         if (tid == 0) wg_dbg[1] = wall_clock64();
+#endif
+#ifdef BTBA_TRIP_TRACE
+        if (tid == 0) { wg_dbg[4] = tt_a; wg_dbg[5] = tt_b; wg_dbg[6] = tt_c; wg_dbg[7] = tt_live | (tt_dead << 32); }
 #endif
     } else {
         const int n_src = LISTS ? valid_counts[slot_s] : D.npix;
@@ -1152,7 +1194,10 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         for (; t < hi; t += kBlock) {
             const float4 zs = zs_n;
             const int s = s_n;
-            if (t + kBlock < hi) { s_n = LISTS ? (int)list[t + kBlock] : t + kBlock; zs_n = zn_s[s_n]; }      // next pixel's stream loads
+            // next pixel's stream loads, UNCONDITIONAL like the block walk's (the last trip re-reads the lane's last pixel): the wait for
+            // this trip's taps then does not have to cover a load that only some paths issue
+            const int tn = min(t + (int)kBlock, hi - 1);
+            s_n = LISTS ? (int)list[tn] : tn; zs_n = zn_s[s_n];
             unsigned ox, oy;
             if (!LISTS) {
                 ox = px4; oy = py4;
@@ -1271,6 +1316,9 @@ __device__ __forceinline__ void fused_item(const SolveDims &D, unsigned n_d, uns
         unsigned long long *q = D.wg_trace + 4 * (size_t)g;
         q[0] = wg_t0; q[1] = wall_clock64(); q[2] = (unsigned long long)(hw & 0xFFFFu) | ((unsigned long long)(xcc & 0xFu) << 16) | ((is_sparse ? 0ull : (wg_dbg[2] & 0xFFFFull)) << 32);
         q[3] = is_sparse ? 1ull : (((wg_dbg[0] - wg_t0) & 0xFFFFFFull) << 8) | (((wg_dbg[1] - wg_t0) & 0xFFFFFFull) << 32);      // kind | prologue end | loop end (ticks from start)
+#ifdef BTBA_TRIP_TRACE
+        if (!is_sparse) { q[0] = wg_dbg[4]; q[1] = wg_dbg[5]; q[3] = wg_dbg[6] << 8; q[2] = (q[2] & 0xFFFFFFFFull) | (wg_dbg[7] << 32); }       // wave 0's phase sums instead of the timeline (scripts/trip_trace.py)
+#endif
     }
 #endif
 }
@@ -1667,7 +1715,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             for (int i = 0; i < kItems; i++) { const int e = e0 + i * nthr; if (e < total) dst[e] = sum[i]; }
         }
     };
-    // items per lane per trip: one trip covers the c3 window (105 pairs: 4 620 sparse / 2 940 dense sums over 1 024 lanes)
+    // items per lane per trip: one trip covers the c3 window (105 pairs: 4 620 sparse / 2 940 dense sums over 1 024 lanes).  (Reducing both kinds at
+    // the same time on disjoint groups of waves -- one round of fabric-latency loads instead of two -- measured 0.5 us SLOWER per launch, r03 call 39.)
     if (D.use_sparse) reduce_partials(std::integral_constant<int, kSparseVals>{}, std::integral_constant<int, 5>{}, sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals, ps, D.n_pairs, D.sparse_chunks);
     else for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) ps[e] = 0.0f;
     if (D.use_dense) reduce_partials(std::integral_constant<int, kDenseVals>{}, std::integral_constant<int, 3>{}, dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals, pd, D.n_dense_pairs, D.dense_tiles);
