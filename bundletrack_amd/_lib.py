@@ -135,6 +135,13 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{path} is missing: the HIP extension has not been built. "
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+        # torch first: libbtba.so is linked against /opt/rocm's libamdhip64, torch brings its own copy under the same soname.  Whichever is
+        # loaded first becomes THE HIP runtime of the process; with libbtba.so first, torch's kernels and ours meet a runtime torch was not
+        # built for and the first launch fails with hipErrorNoDevice (seen with build() followed by smoke() in one process).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         L.btba_strerror.restype = C.c_char_p
         L.btba_strerror.argtypes = [C.c_int]
