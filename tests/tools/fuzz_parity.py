@@ -1,0 +1,79 @@
+"""Randomised parity sweep of the drop-in boundary against the CPU oracle (GPU box; developer tool, not collected by pytest).
+    python tests/tools/fuzz_parity.py [n_cases] > gpurun_out/fuzz_parity.jsonl
+Window sizes 2 ... 9, 0 ... 500 correspondences per pair with ragged pairs (some emptied, some thinned by invalidated entries),
+object-masked and fully valid frames, different initial perturbations.  Prints one line per case: the worst pose difference of the
+final iterate, rad and m.  A case above 1e-4 is not necessarily a failure (one flipped accept decision changes the trajectory:
+tests/helpers.py explains a case by its decision trace); this tool only finds candidates."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from bundletrack_amd import synthetic as S
+from bundletrack_amd.optimizer import BatchSolver, OptimizerGpu, Workspace
+from oracle import oracle as O
+
+
+def run_cases(n_cases, explain_always=False):
+    """Yields one record per case (see the module docstring)."""
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(20260925)
+    opt = OptimizerGpu()
+    ws = Workspace()
+    for case in range(n_cases):
+        K = int(rng.integers(2, 10))
+        m = int(rng.choice([0, 5, 60, 200, 500]))
+        background = bool(rng.integers(0, 2))
+        perturb = float(rng.choice([0.5, 2.0, 4.0]))
+        pb = S.make_problem(K, m, seed=9000 + case, background=background, perturb_deg=perturb)
+        corr = pb.corr.copy()
+        counts = np.array(pb.n_match_per_pair, np.int64).copy()
+        # ragged pairs: empty a pair, thin another by invalidating entries (EntryJ::isValid: imgIdx_i == 0xFFFFFFFF)
+        if m and len(counts) > 1:
+            off = np.concatenate([[0], np.cumsum(counts)])
+            kill = int(rng.integers(0, len(counts)))
+            corr["imgIdx_i"][off[kill]:off[kill + 1]] = 0xFFFFFFFF
+            thin = int(rng.integers(0, len(counts)))
+            sel = off[thin] + rng.choice(max(1, counts[thin]), size=max(1, counts[thin] // 3), replace=False)
+            corr["imgIdx_i"][sel[sel < off[thin + 1]]] = 0xFFFFFFFF
+        depths = [torch.from_numpy(pb.depth[k]).to(dev) for k in range(K)]
+        normals = [torch.from_numpy(pb.normals[k]).to(dev) for k in range(K)]
+        poses = pb.poses_init.copy()
+        opt.optimizeFrames(corr, pb.n_match_per_pair, K, pb.H, pb.W, depths, None, normals, poses, pb.K)
+        caches = [O.build_cache(pb.depth[k], pb.normals[k], pb.K) for k in range(K)]
+        ref = O.solve(np.stack([c["campos"] for c in caches]), np.stack([c["normals"] for c in caches]), caches[0]["intr"], corr, pb.poses_init)
+        dr = max(S.pose_error(poses[k], ref.poses[k])[0] for k in range(K)); dt = max(S.pose_error(poses[k], ref.poses[k])[1] for k in range(K))
+        rec = {"case": case, "K": K, "corr_per_pair": m, "background": background, "perturb_deg": perturb, "rot": float(dr), "trans": float(dt),
+               "finite": bool(np.isfinite(poses).all())}
+        if explain_always or max(dr, dt) >= 1e-4:
+            # explain it (tests/helpers.py): per-iterate traces of both sides, the first differing decision, the oracle's own summation-order spread
+            from helpers import first_decision_divergence
+            campos, nrm = np.stack([c["campos"] for c in caches]), np.stack([c["normals"] for c in caches])
+            seq = O.solve(campos, nrm, caches[0]["intr"], corr, pb.poses_init, params=O.default_params(accum_mode=0))
+            bs = BatchSolver(ws)
+            cpk, offs, mx = bs.pack_correspondences([corr], K)
+            corr_d = torch.from_numpy(cpk.view(np.uint8).reshape(1, -1, 32)).to(dev); offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
+            poses_d = torch.from_numpy(pb.poses_init[None].astype(np.float32)).to(dev)
+            tv = bs.trace_view(bs.solve(torch.from_numpy(campos[None]).to(dev), torch.from_numpy(nrm[None]).to(dev), caches[0]["intr"], corr_d, offs_d, mx, poses_d, trace=True))
+            div = first_decision_divergence(tv.pcg_scalars[0], tv.dense_pair[0][..., 27], ref.pcg_scalars, ref.dense_count)
+            G = ref.T_after.shape[0]
+            per_it = [max(max(S.pose_error(tv.T_after[0, it, k], ref.T_after[it, k])) for k in range(K)) for it in range(G)]
+            spread = [max(max(S.pose_error(seq.T_after[it, k], ref.T_after[it, k])) for k in range(K)) for it in range(G)]
+            first = div[0] if div is not None else G
+            unexplained = [it for it in range(G) if it < first and per_it[it] >= max(1e-4, 3.0 * max(spread[:it + 1]))]
+            rec.update({"first_divergence": None if div is None else [int(div[0]), div[1]], "per_iterate": [float(f"{x:.3g}") for x in per_it],
+                        "oracle_own_spread": [float(f"{x:.3g}") for x in spread], "unexplained_iterates": unexplained})
+        yield rec
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    worst = 0.0
+    for rec in run_cases(n_cases):
+        worst = max(worst, rec["rot"], rec["trans"])
+        print(json.dumps(rec), flush=True)
+    print(json.dumps({"cases": n_cases, "worst": worst}))
+
+
+if __name__ == "__main__":
+    main()
