@@ -375,7 +375,9 @@ static int pick_chunks(const btba_params *prm, int B, int P, uint32_t max_corr_p
     if (max_corr_per_pair == 0) return 1;
     const long blocks = (long)B * P;
     int want = (int)((512 + blocks - 1) / blocks);
-    const int cap = (int)((max_corr_per_pair + kBlock - 1) / kBlock);
+    // a chunk is at least one full trip of its workgroup (two entries per lane): a single c3 window measured 0.2191 / 0.2145 / 0.2143 / 0.2283 ms
+    // per solve for 5 / 4 / 2 / 8 chunks of its 2 000-entry segments (scripts/latency_tiles.py, r03 call 58)
+    const int cap = (int)((max_corr_per_pair + 2 * kBlock - 1) / (2 * kBlock));
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     if (want > 16) want = 16;
