@@ -14,8 +14,9 @@ from bundletrack_amd.optimizer import BatchSolver, OptimizerGpu, Workspace
 from oracle import oracle as O
 
 
-def run_cases(n_cases, explain_always=False):
-    """Yields one record per case (see the module docstring)."""
+def run_cases(n_cases, explain_always=False, only=None, hook=None):
+    """Yields one record per case (see the module docstring).  only: solve just that case (the others still draw their random numbers);
+    hook(rec, pb, corr, caches, ref, tv): called for explained cases with the problem and both traces."""
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(20260925)
     opt = OptimizerGpu()
@@ -36,6 +37,8 @@ def run_cases(n_cases, explain_always=False):
             thin = int(rng.integers(0, len(counts)))
             sel = off[thin] + rng.choice(max(1, counts[thin]), size=max(1, counts[thin] // 3), replace=False)
             corr["imgIdx_i"][sel[sel < off[thin + 1]]] = 0xFFFFFFFF
+        if only is not None and case != only:
+            continue
         depths = [torch.from_numpy(pb.depth[k]).to(dev) for k in range(K)]
         normals = [torch.from_numpy(pb.normals[k]).to(dev) for k in range(K)]
         poses = pb.poses_init.copy()
@@ -61,6 +64,7 @@ def run_cases(n_cases, explain_always=False):
             spread = [max(max(S.pose_error(seq.T_after[it, k], ref.T_after[it, k])) for k in range(K)) for it in range(G)]
             first = div[0] if div is not None else G
             unexplained = [it for it in range(G) if it < first and per_it[it] >= max(1e-4, 3.0 * max(spread[:it + 1]))]
+            if hook: hook(rec, pb, corr, caches, ref, tv)
             rec.update({"first_divergence": None if div is None else [int(div[0]), div[1]], "per_iterate": [float(f"{x:.3g}") for x in per_it],
                         "oracle_own_spread": [float(f"{x:.3g}") for x in spread], "unexplained_iterates": unexplained})
         yield rec
@@ -68,8 +72,27 @@ def run_cases(n_cases, explain_always=False):
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    only = int(sys.argv[2]) if len(sys.argv) > 2 else None
     worst = 0.0
-    for rec in run_cases(n_cases):
+
+    def against_fp64(rec, pb, corr, caches, ref, tv):
+        # how far is EITHER fp32 evaluation from the fp64 restatement of the same iterate?  (oracle/oracle_np.py)
+        from oracle import oracle_np as ON
+        campos, nrm = np.stack([c["campos"] for c in caches]), np.stack([c["normals"] for c in caches])
+        r64 = ON.solve(campos.astype(np.float64), nrm.astype(np.float64), caches[0]["intr"], corr, pb.poses_init.astype(np.float64))
+        T64 = np.asarray(r64["T_after"])
+        K = pb.n_frames
+        rec["oracle32_vs_fp64"] = [float(f"{max(max(S.pose_error(ref.T_after[it, k], T64[it, k])) for k in range(K)):.3g}") for it in range(T64.shape[0])]
+        # iterate 0 (identical inputs): right-hand sides and PCG scalars side by side, conditioning of the system the HIP path assembled
+        A_h = tv.A[0, 0].astype(np.float64)[6:, 6:]               # frames 1 ..: [trans, rot] per frame
+        b_h, b_o = tv.rhs[0, 0].astype(np.float64), np.asarray(ref.rhs[0], np.float64)
+        w = np.linalg.eigvalsh(A_h)
+        rec["iterate0"] = {"rhs_rel_diff": float(np.abs(b_h - b_o).max() / max(np.abs(b_o).max(), 1e-30)), "eig_min": float(w.min()), "eig_max": float(w.max()),
+                           "cond_A_jacobi": float(np.linalg.cond(A_h / np.sqrt(np.outer(np.diag(A_h), np.diag(A_h))))),
+                           "pcg_hip": [[float(f"{x:.6g}") for x in r] for r in tv.pcg_scalars[0, 0]], "pcg_oracle": [[float(f"{x:.6g}") for x in r] for r in np.asarray(ref.pcg_scalars[0])]}
+        rec["hip_vs_fp64"] = [float(f"{max(max(S.pose_error(tv.T_after[0, it, k], T64[it, k])) for k in range(K)):.3g}") for it in range(T64.shape[0])]
+
+    for rec in run_cases(n_cases, only=only, hook=against_fp64 if only is not None else None):
         worst = max(worst, rec["rot"], rec["trans"])
         print(json.dumps(rec), flush=True)
     print(json.dumps({"cases": n_cases, "worst": worst}))
