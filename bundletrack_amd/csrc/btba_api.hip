@@ -1352,7 +1352,9 @@ int btba_process_depth(btba_workspace *ws, int H, int W, const float *depth_in_d
     DepthFilterParams P{ W, H, erode_radius, erode_diff, erode_ratio, bf_radius, sigma_d, sigma_r };
     const int h = erode_radius + 2 * bf_radius;
     const size_t lds = 2 * sizeof(float) * (size_t)(kTileW + 2 * h) * (kTileH + 2 * h);
-    k_process_depth<<<dim3((W + kTileW - 1) / kTileW, (H + kTileH - 1) / kTileH), 256, lds, ws->stream>>>(P, depth_in_dev, depth_out_dev);
+    const dim3 grid((W + kTileW - 1) / kTileW, (H + kTileH - 1) / kTileH);
+    if (erode_radius == 1 && bf_radius == 2) k_process_depth<1, 2><<<grid, 256, lds, ws->stream>>>(P, depth_in_dev, depth_out_dev);        // the tracker's stencils, unrolled
+    else k_process_depth<-1, -1><<<grid, 256, lds, ws->stream>>>(P, depth_in_dev, depth_out_dev);
     HIP_TRY(hipGetLastError());
     return BTBA_OK;
 }

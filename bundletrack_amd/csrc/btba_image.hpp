@@ -22,19 +22,27 @@ struct DepthFilterParams {
     int bf_radius; float sigma_d, sigma_r;
 };
 
-// dynamic LDS: two float planes of (kTileW + 2h) x (kTileH + 2h), h = erode_radius + 2 bf_radius
-__global__ void __launch_bounds__(256) k_process_depth(DepthFilterParams P, const float *__restrict__ in, float *__restrict__ out)
+// dynamic LDS: two float planes of (kTileW + 2h) x (kTileH + 2h), h = erode_radius + 2 bf_radius.
+// RE / RF: the radii at compile time (the tracker's 1 and 2: 3 x 3 and 5 x 5 windows fully unrolled, LDS reads at immediate offsets), or -1 for
+// radii read from P.  A workgroup whose whole LDS tile lies inside the image (INTERIOR: all but the frame's rim) drops the four coordinate
+// tests per tap.  The arithmetic per tap, for every variant:
+//   * the mean gate `(double)|c - mean| < 0.01` of the reference is decided as `|c - mean| <= 0.01f`: the float nearest 0.01 lies below
+//     the double 0.01 and its successor above, so the two tests accept the same floats;
+//   * the weight is exp(s(dx, dy) - (centre - c)^2 / (2 sigma_r^2)) with the spatial term s = -(dx^2 + dy^2) / (2 sigma_d^2) divided once per
+//     thread (it takes six values for a 5 x 5 window) instead of once per tap, and the range term multiplied by 1 / (2 sigma_r^2).
+template <int RE, int RF, bool INTERIOR>
+__device__ __forceinline__ void process_depth_tile(const DepthFilterParams &P, const float *__restrict__ in, float *__restrict__ out, float *tile)
 {
-    extern __shared__ __attribute__((aligned(16))) float tile[];
-    const int re = P.erode_radius, rf = P.bf_radius, h = re + 2 * rf;
+    const int re = RE >= 0 ? RE : P.erode_radius, rf = RF >= 0 ? RF : P.bf_radius, h = re + 2 * rf;
     const int LW = kTileW + 2 * h, LH = kTileH + 2 * h;
     float *b0 = tile, *b1 = tile + LW * LH;
     const int x0 = blockIdx.x * kTileW - h, y0 = blockIdx.y * kTileH - h;       // image coords of LDS (0,0)
     const int tid = threadIdx.x;
+    auto inside = [&](int gx, int gy) { return INTERIOR || (gx >= 0 && gx < P.W && gy >= 0 && gy < P.H); };
     // stage 0: raw depth (anything for out-of-image cells: consumers test coordinates, not values)
     for (int e = tid; e < LW * LH; e += 256) {
         const int lx = e % LW, ly = e / LW, gx = x0 + lx, gy = y0 + ly;
-        b0[e] = (gx >= 0 && gx < P.W && gy >= 0 && gy < P.H) ? in[(size_t)gy * P.W + gx] : 0.0f;
+        b0[e] = inside(gx, gy) ? in[(size_t)gy * P.W + gx] : 0.0f;
     }
     __syncthreads();
     // stage 1: erode on the region that the two filter passes will read (margin re)
@@ -44,13 +52,15 @@ __global__ void __launch_bounds__(256) k_process_depth(DepthFilterParams P, cons
         for (int e = tid; e < RW * RH; e += 256) {
             const int lx = m + e % RW, ly = m + e / RW, gx = x0 + lx, gy = y0 + ly;
             float o = 0.0f;
-            if (gx >= 0 && gx < P.W && gy >= 0 && gy < P.H) {
+            if (inside(gx, gy)) {
                 const float old = b0[ly * LW + lx];
                 if (!(old <= 0.1f)) {
                     unsigned count = 0;
+#pragma unroll
                     for (int i = -re; i <= re; i++)
+#pragma unroll
                         for (int j = -re; j <= re; j++)
-                            if (gx + j >= 0 && gx + j < P.W && gy + i >= 0 && gy + i < P.H) {
+                            if (inside(gx + j, gy + i)) {
                                 const float d = b0[(ly + i) * LW + lx + j];
                                 if (d == -INFINITY || d < 0.1f || fabsf(d - old) > P.erode_diff) count++;
                             }
@@ -64,32 +74,39 @@ __global__ void __launch_bounds__(256) k_process_depth(DepthFilterParams P, cons
     // stages 2 and 3: the mean-gated bilateral filter, twice
     const float two_sd2 = 2.0f * P.sigma_d * P.sigma_d, two_sr2 = 2 * P.sigma_r * P.sigma_r;
     const float num_total = (float)((2 * rf + 1) * (2 * rf + 1));
+    const float inv_two_sr2 = 1.0f / two_sr2;             // (the reference divides per tap: one rounding of a term that is <= 0.5 and usually ~1e-15)
     for (int pass = 0; pass < 2; pass++) {
         const float *src = pass == 0 ? b1 : b0;
         float *dst = pass == 0 ? b0 : nullptr;
         const int m = re + rf * (pass + 1), RW = LW - 2 * m, RH = LH - 2 * m;
         for (int e = tid; e < RW * RH; e += 256) {
             const int lx = m + e % RW, ly = m + e / RW, gx = x0 + lx, gy = y0 + ly;
-            if (!(gx >= 0 && gx < P.W && gy >= 0 && gy < P.H)) continue;
+            if (!inside(gx, gy)) continue;
             float o = 0.0f;
-            const float centre = src[ly * LW + lx];
+            const float *ctr = src + ly * LW + lx;
+            const float centre = ctr[0];
             float mean = 0.0f;
             int nvalid = 0;
+#pragma unroll
             for (int dx = -rf; dx <= rf; dx++)                 // same nesting as the reference: x outer, y inner
+#pragma unroll
                 for (int dy = -rf; dy <= rf; dy++)
-                    if (gx + dx >= 0 && gy + dy >= 0 && gx + dx < P.W && gy + dy < P.H) {
-                        const float c = src[(ly + dy) * LW + lx + dx];
+                    if (inside(gx + dx, gy + dy)) {
+                        const float c = ctr[dy * LW + dx];
                         if (c >= 0.1f) { nvalid++; mean += c; }
                     }
             if (nvalid > 0) {
                 mean /= (float)nvalid;
                 float sum = 0.0f, sw = 0.0f;
+#pragma unroll
                 for (int dx = -rf; dx <= rf; dx++)
+#pragma unroll
                     for (int dy = -rf; dy <= rf; dy++)
-                        if (gx + dx >= 0 && gy + dy >= 0 && gx + dx < P.W && gy + dy < P.H) {
-                            const float c = src[(ly + dy) * LW + lx + dx];
-                            if (c >= 0.1f && (double)fabsf(c - mean) < 0.01) {
-                                const float wgt = expf(-(dx * dx + dy * dy) / two_sd2 - (centre - c) * (centre - c) / two_sr2);
+                        if (inside(gx + dx, gy + dy)) {
+                            const float c = ctr[dy * LW + dx];
+                            if (c >= 0.1f && fabsf(c - mean) <= 0.01f) {
+                                const float spatial = -(float)(dx * dx + dy * dy) / two_sd2;          // (compile-time dx, dy: hoisted out of the pixel loop)
+                                const float wgt = __expf(spatial - (centre - c) * (centre - c) * inv_two_sr2);       // arguments in [-(2 rf^2) / (2 sigma_d^2) - ..., 0]: no range handling needed
                                 sw += wgt;
                                 sum += wgt * c;
                             }
@@ -101,6 +118,17 @@ __global__ void __launch_bounds__(256) k_process_depth(DepthFilterParams P, cons
         }
         __syncthreads();
     }
+}
+
+template <int RE, int RF>
+__global__ void __launch_bounds__(256) k_process_depth(DepthFilterParams P, const float *__restrict__ in, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int h = (RE >= 0 ? RE : P.erode_radius) + 2 * (RF >= 0 ? RF : P.bf_radius);
+    const int x0 = blockIdx.x * kTileW - h, y0 = blockIdx.y * kTileH - h;
+    const bool interior = x0 >= 0 && y0 >= 0 && x0 + kTileW + 2 * h <= P.W && y0 + kTileH + 2 * h <= P.H;      // (uniform)
+    if (interior) process_depth_tile<RE, RF, true>(P, in, out, tile);
+    else process_depth_tile<RE, RF, false>(P, in, out, tile);
 }
 
 // camera-space point of pixel (x, y): intrinsicsInv * (x d, y d, d, d), z = d, zeros when d < 0.1
