@@ -322,6 +322,8 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if os.environ.get("BTBA_BENCH_SKIP_AFTER_WARMUP"):      # developer timing experiment (wrong results by construction): ChainDims::debug_skip from here on
+        ws.set_option(1000, int(os.environ["BTBA_BENCH_SKIP_AFTER_WARMUP"]))
     if not args.no_kernel_timing:
         ws.collect_stats()                                  # drop warm-up events
     sharding.barrier(dev)
@@ -369,11 +371,15 @@ def main():
             # reuse of a frame by its 14 pairs) is kept as context with the measured traffic next to it.
             avg_ms = st["ms_dense_sweep"] / st["n_dense_launches"]
             fused = bool(st.get("fused_sweeps", 0))
+            # chained launch (k_chain): ONE launch per solve carries the sweeps of all Gauss-Newton iterations (and the system solves of all
+            # but the last): per launch it does `chained` times the algorithmic work of a fused sweep launch
+            chained = int(st.get("chain_iterations", 0))
+            sweeps_per_launch = chained if chained else 1
             depth = np.stack([p["zn"][..., 0] for p in pick]) if not args.float4_cache else np.stack([p["campos"][..., 2] for p in pick])
             nvalid = (depth >= 0.1).reshape(B, K, -1).sum(-1)                        # valid source pixels per frame
             pair_pixels = int((nvalid * np.arange(K)[None, :]).sum())                # frame j is the source of its j pairs (i < j)
-            flops_alg = 200.0 * pair_pixels + (120.0 * n_corr if fused else 0.0)
-            bytes_alg = 64 * pair_pixels + (32 * n_corr if fused else 0)
+            flops_alg = sweeps_per_launch * (200.0 * pair_pixels + (120.0 * n_corr if fused else 0.0))
+            bytes_alg = sweeps_per_launch * (64 * pair_pixels + (32 * n_corr if fused else 0))
             tflops = flops_alg / (avg_ms * 1e-3) / 1e12
             pc = profiled_counters(args.config, B, args.masked, args.float4_cache, fused, n_distinct, not use_c24)
             traffic = pc.get("hbm_bytes_per_launch") if pc else None
@@ -392,9 +398,10 @@ def main():
                                    "valu_context": {"achieved_TFLOPs": round(tflops, 2), "frac_of_vector_peak": round(tflops / VALU_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": flops_alg},
                                    "note": "HBM roofline: (32 B x correspondences + 16 B x valid cached pixels) / launch time against 8 TB/s; durations from hipEvents on the workspace stream inside the timed region"}
             else:
-                res["roofline"] = {"bound": "valu", "kernel": "k_fused_sweeps (dense + sparse workgroups)" if fused else "k_dense_sweep",
+                res["roofline"] = {"bound": "valu", "kernel": (f"k_chain (ONE launch per solve: the dense + sparse sweep items of all {chained} Gauss-Newton iterations and {chained - 1} in-launch system solves)" if chained
+                                                              else "k_fused_sweeps (dense + sparse workgroups)" if fused else "k_dense_sweep"),
                                    "achieved": round(tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
-                                   "traffic": traffic, "algorithmic_flops_per_launch": flops_alg, "pair_pixels_per_launch": pair_pixels,
+                                   "traffic": traffic, "algorithmic_flops_per_launch": flops_alg, "pair_pixels_per_launch": sweeps_per_launch * pair_pixels, "sweeps_per_launch": sweeps_per_launch,
                                    "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_dense_launches"],
                                    "note": "fp32 vector (VALU) roofline: algorithmic flops / launch time against 157.3 TFLOP/s (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz = the "
                                            "dense f32 MFMA peak); durations from hipEvents on the workspace stream inside the timed region"}
@@ -419,14 +426,15 @@ def main():
                 res["roofline"]["hbm_algorithmic"]["peak_measured_copy_GBps"] = round(copy_bw, 1)
             # per-step kernel time = average timed launch x launches per step (one iteration of every solve is timed)
             n_it = int(bs.params.n_gn_iters)
-            per_step = lambda ms, n: ms / max(n, 1) * n_it
+            per_step = lambda ms, n: ms / max(n, 1) * (1 if chained else n_it)      # chained: one sweep launch (all iterations) and one stand-alone system solve (the last) per step
             res["kernels_ms_per_step"] = {
                 "fused_sweeps": fused,            # fused: ONE launch per iteration carries both sweeps
                 "sweeps": round(per_step(st["ms_dense_sweep"], st["n_dense_launches"]) + per_step(st["ms_sparse_sweep"], st["n_sparse_launches"]), 4),
                 "dense_sweep": None if fused else round(per_step(st["ms_dense_sweep"], st["n_dense_launches"]), 4),
                 "sparse_sweep": None if fused else round(per_step(st["ms_sparse_sweep"], st["n_sparse_launches"]), 4),
                 "system_solve": round(per_step(st["ms_system_solve"], st["n_solve_launches"]), 4), "solve_region": round(st["ms_solve"] / args.steps, 4),
-                "launches_timed": {"sweep": st["n_dense_launches"], "system_solve": st["n_solve_launches"], "of_per_step": n_it},
+                "launches_timed": {"sweep": st["n_dense_launches"], "system_solve": st["n_solve_launches"], "of_per_step": 1 if chained else n_it},
+                "chained_iterations": chained,
                 "sparse_alg_GBps": (round(32 * n_corr / max(st["ms_sparse_sweep"] / max(st["n_sparse_launches"], 1), 1e-9) / 1e6, 1) if st["n_sparse_launches"] else None)}
         elif cfg["w_dense"] == 0.0 and not args.no_kernel_timing and st["n_sparse_launches"] > 0:
             avg_ms = st["ms_sparse_sweep"] / st["n_sparse_launches"]

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_PKG, "libbtba.so")
 SRC_DIR = os.path.join(_PKG, "csrc")
 HEADER = os.path.join(_ROOT, "include", "btba.h")
 
-BTBA_OK, BTBA_EINVAL, BTBA_EHIP, BTBA_ENUMERIC, BTBA_ENOMEM = 0, 1, 2, 3, 4
+BTBA_OK, BTBA_EINVAL, BTBA_EHIP, BTBA_ENUMERIC, BTBA_ENOMEM, BTBA_ESCHED = 0, 1, 2, 3, 4, 5
 PAIRS_TARGET_LOWER, PAIRS_TARGET_MORE_VALID, PAIRS_EXPLICIT, PAIRS_TARGET_HIGHER = 0, 1, 2, 3
 REDUCE_DETERMINISTIC, REDUCE_ATOMIC = 0, 1
 RANSAC_REFERENCE_SVD, RANSAC_HORN = 0, 1
@@ -25,6 +25,7 @@ RANSAC_DRAW_HASH = 0x100      # ORed into `hypothesis`: counter-hash sample trip
 FLAG_TRACE, FLAG_TIME_KERNELS = 1, 2
 FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_KEYED_CORR, FLAG_FLOAT4_CACHE, FLAG_NO_COMPACTION, FLAG_COMPACTION, FLAG_TIME_SAMPLED = 32, 64, 4096, 256, 512, 1024, 2048
 OPT_DENSE_ORDER, OPT_TILE_MAJOR, OPT_BLOCK_WALK, OPT_BLOCK_SKIP, OPT_BIG_ASSEMBLY, OPT_OVERLAP_GROUPS, OPT_OVERLAP_EQUAL_PRIO, OPT_KEYED_CORR_MIN_BYTES, OPT_SPARSE_TAIL = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_CHAIN, OPT_CHAIN_SPARSE_PERIOD, OPT_CHAIN_TIMEOUT_MS = 10, 11, 12
 
 ENTRYJ_DTYPE = np.dtype(
     [("imgIdx_i", "<u4"), ("imgIdx_j", "<u4"), ("pos_i", "<f4", (3,)), ("pos_j", "<f4", (3,))]
@@ -62,6 +63,7 @@ class Stats(C.Structure):
         ("n_dense_launches", C.c_int32), ("n_sparse_launches", C.c_int32), ("n_solve_launches", C.c_int32),
         ("bytes_dense_alg", C.c_int64), ("bytes_sparse_alg", C.c_int64),
         ("fused_sweeps", C.c_int32), ("cache_frames_built", C.c_int32), ("corr_pairs_uploaded", C.c_int32),
+        ("chain_iterations", C.c_int32),
     ]
 
     def as_dict(self):
@@ -143,6 +145,11 @@ def lib() -> C.CDLL:
         except ImportError:
             pass
         L = C.CDLL(path)
+        # the structs below mirror ONE version of include/btba.h: a library built from another one must not be called (btba.h: BTBA_VERSION)
+        import re
+        header_version = int(re.search(r"#define BTBA_VERSION (\d+)", open(HEADER).read()).group(1))
+        if "BTBA_LIB_PATH" not in os.environ and L.btba_version() != header_version:
+            raise ImportError(f"{path} is version {L.btba_version()}, include/btba.h is {header_version}: rebuild (python -c 'import __graft_entry__ as g; g.build()')")
         L.btba_strerror.restype = C.c_char_p
         L.btba_strerror.argtypes = [C.c_int]
         for name in EXPORTED_SYMBOLS:

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <new>
+#include <string>
 #include <map>
 #include <memory>
 #include <vector>
@@ -66,6 +67,11 @@ struct btba_workspace {
     DevBuf corr, offsets, poses, campos, normals, nvalid;   // optimize_frames staging
     DevBuf valid_lists, valid_counts;                       // per-frame lists of pixels with a depth (compact cache)
     DevBuf block_ranges;                                    // per (frame, 8 x 8 block) usable depth range: dead-block test of the dense sweep
+    DevBuf chain_sync;                                      // chained launch: flags[B] + arrivals[n_gn][B] (zeroed before every launch), optional timeline
+    DevBuf chain_trace;
+    int *chain_error = nullptr;                             // pinned host word the chained launch's watchdog raises (checked at every host synchronisation)
+    bool chain_failed = false;                              // a watchdog fired on this workspace: chaining stays off from then on
+    uint64_t chain_launches = 0;
     // Developer / tuning switches.  Read from the environment ONCE, when the workspace is created (never on the solve path), and settable
     // per workspace through btba_workspace_set_option (include/btba.h: BTBA_OPT_*).  None of them changes what is computed.
     struct Tuning {
@@ -78,6 +84,13 @@ struct btba_workspace {
         int overlap_groups = 2;        // BTBA_OPT_OVERLAP_GROUPS (env BTBA_GROUPS): instance groups of BTBA_FLAG_OVERLAP
         bool overlap_equal_prio = false;   // BTBA_OPT_OVERLAP_EQUAL_PRIO (env BTBA_GROUP_PRIO=e...)
         size_t keyed_corr_min_bytes = (size_t)1 << 20;   // BTBA_OPT_KEYED_CORR_MIN_BYTES (env of the same name): below it the keyed correspondence cache is not used
+        int chain = -1;                // BTBA_OPT_CHAIN         (env BTBA_CHAIN): all Gauss-Newton iterations of a batch in ONE launch (k_chain); -1 = from 16 instances on, 0 = never, 1 = whenever the launch supports the solve
+        int chain_sparse_period = 0;   // BTBA_OPT_CHAIN_SPARSE_PERIOD (env BTBA_CHAIN_PERIOD): 0 = an instance's sparse items follow its dense items, R >= 2 = every R-th item is a sparse one
+        int chain_timeout_ms = 500;    // BTBA_OPT_CHAIN_TIMEOUT_MS (env BTBA_CHAIN_TIMEOUT_MS): watchdog of the waits inside the chained launch
+        int chain_solve_prio = 0;      // env BTBA_CHAIN_SOLVE_PRIO (developer A/B): s_setprio of the solve items' waves
+        int chain_debug_skip = 0;      // env BTBA_CHAIN_DEBUG_SKIP (developer TIMING experiments, wrong results): ChainDims::debug_skip
+        int debug_lds_pad = 0;         // env BTBA_DEBUG_LDS_PAD (developer): extra dynamic LDS bytes per sweep workgroup -- what a larger LDS footprint costs the fused sweep
+        std::string chain_trace_file;  // env BTBA_CHAIN_TRACE_FILE (developer, scripts/chain_trace.py): every chained solve synchronises and dumps its workgroup timeline there
     } tune;
     std::vector<int32_t> dense_pairs_host;                  // what dense_pairs currently holds
     int dense_pairs_frames = -1;
@@ -169,6 +182,7 @@ const char *btba_strerror(int status)
     case BTBA_EHIP: return "HIP runtime error (see btba_last_hip_error)";
     case BTBA_ENUMERIC: return "non-finite value in the output poses";
     case BTBA_ENOMEM: return "out of device memory";
+    case BTBA_ESCHED: return "a wait inside the chained launch timed out (workgroups did not start in grid order): the solve's poses are invalid; the workspace now solves unchained";
     default: return "unknown status";
     }
 }
@@ -203,6 +217,13 @@ static int workspace_create(btba_workspace **out, void *stream, bool use_given)
         if (const char *e = std::getenv("BTBA_GROUPS")) t.overlap_groups = std::atoi(e);
         if (const char *e = std::getenv("BTBA_GROUP_PRIO")) t.overlap_equal_prio = e[0] == 'e';
         if (const char *e = std::getenv("BTBA_KEYED_CORR_MIN_BYTES")) t.keyed_corr_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
+        if (const char *e = std::getenv("BTBA_CHAIN")) t.chain = std::max(-1, std::min(1, std::atoi(e)));
+        if (const char *e = std::getenv("BTBA_CHAIN_PERIOD")) t.chain_sparse_period = std::max(0, std::atoi(e));
+        if (const char *e = std::getenv("BTBA_CHAIN_TIMEOUT_MS")) t.chain_timeout_ms = std::max(1, std::atoi(e));
+        if (const char *e = std::getenv("BTBA_CHAIN_TRACE_FILE")) t.chain_trace_file = e;
+        if (const char *e = std::getenv("BTBA_CHAIN_SOLVE_PRIO")) t.chain_solve_prio = std::max(0, std::min(3, std::atoi(e)));
+        if (const char *e = std::getenv("BTBA_CHAIN_DEBUG_SKIP")) t.chain_debug_skip = std::atoi(e);
+        if (const char *e = std::getenv("BTBA_DEBUG_LDS_PAD")) t.debug_lds_pad = std::max(0, std::min(60000, std::atoi(e)));
     }
     if (use_given) {
         ws->stream = reinterpret_cast<hipStream_t>(stream);       // may be the NULL stream
@@ -224,9 +245,10 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A, &ws->solve_tab,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts, &ws->block_ranges,
-                       &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc, &ws->corr_stage_dev, &ws->corr_lens };
+                       &ws->chain_sync, &ws->chain_trace, &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc, &ws->corr_stage_dev, &ws->corr_lens };
     for (auto b : bufs) b->release();
     if (ws->corr_stage) (void)hipHostFree(ws->corr_stage);
+    if (ws->chain_error) (void)hipHostFree(ws->chain_error);
     for (auto st : ws->aux_streams) if (st) (void)hipStreamDestroy(st);
     if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
     for (auto e : ws->ev_join) if (e) (void)hipEventDestroy(e);
@@ -249,9 +271,23 @@ int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
     case BTBA_OPT_OVERLAP_GROUPS: if (value < 1 || value > btba_workspace::kMaxGroups) return BTBA_EINVAL; t.overlap_groups = (int)value; break;
     case BTBA_OPT_OVERLAP_EQUAL_PRIO: t.overlap_equal_prio = value != 0; break;
     case BTBA_OPT_KEYED_CORR_MIN_BYTES: if (value < 0) return BTBA_EINVAL; t.keyed_corr_min_bytes = (size_t)value; break;
+    case BTBA_OPT_CHAIN: if (value < -1 || value > 1) return BTBA_EINVAL; t.chain = (int)value; break;
+    case BTBA_OPT_CHAIN_SPARSE_PERIOD: if (value < 0 || value == 1 || value > 64) return BTBA_EINVAL; t.chain_sparse_period = (int)value; break;
+    case BTBA_OPT_CHAIN_TIMEOUT_MS: if (value < 1 || value > 60000) return BTBA_EINVAL; t.chain_timeout_ms = (int)value; break;
+    case 1000: t.chain_debug_skip = (int)value; break;      // developer timing experiments (ChainDims::debug_skip): not part of the ABI
     default: return BTBA_EINVAL;
     }
     return BTBA_OK;
+}
+
+// After a host synchronisation: did a wait inside a chained launch run into its watchdog?  The poses of that solve are then unusable; the
+// call reports BTBA_ESCHED once and the workspace solves unchained from then on.
+static int chain_check(btba_workspace *ws)
+{
+    if (!ws->chain_error || !*ws->chain_error) return BTBA_OK;
+    *ws->chain_error = 0;
+    ws->chain_failed = true;
+    return BTBA_ESCHED;
 }
 
 int btba_workspace_sync(btba_workspace *ws)
@@ -259,7 +295,7 @@ int btba_workspace_sync(btba_workspace *ws)
     DeviceGuard device_guard(ws);
     if (!ws) return BTBA_EINVAL;
     HIP_TRY(hipStreamSynchronize(ws->stream));
-    return BTBA_OK;
+    return chain_check(ws);
 }
 
 static int order_streams(btba_workspace *ws, hipStream_t from, hipStream_t to)
@@ -543,6 +579,9 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;
     D.order_flag = order_flag;
+    D.pose_stride = 16 * N; D.x_stride = 6 * N;                      // instances back to back (the chained launch pads them, below)
+    D.sp_stride = (int64_t)P * (atomic_sums ? 1 : chunks) * kSparseVals;
+    D.dp_stride = (int64_t)(Pd > 0 ? Pd : 1) * (atomic_sums ? 1 : tiles) * kDenseVals;
     D.atomic_sums = atomic_sums ? 1 : 0;
     D.corr24 = corr24 ? 1 : 0;
     D.pair_lens = pair_lens;
@@ -615,13 +654,64 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         HIP_TRY(hipMemsetAsync(ws->sparse_part.p, 0, sizeof(float) * (size_t)B * P * kSparseVals, ws->stream));
         HIP_TRY(hipMemsetAsync(ws->dense_part.p, 0, sizeof(float) * (size_t)B * (Pd > 0 ? Pd : 1) * kDenseVals, ws->stream));
     }
+    const bool compaction = use_zn && use_dense && (prm->flags & BTBA_FLAG_COMPACTION);
+    // The chained launch (btba_kernels.hpp: k_chain): all Gauss-Newton iterations in ONE launch, the system solves handed over inside it.
+    // Same sums in the same order as the plain schedule; taken for the batches it pays for and the configurations it is written for.
+    const int chain_lay = zn_layout == 1 ? (compaction ? 3 : 1) : 0;
+    // (the library's own choice, chain = -1: batches of full frames from 16 instances on.  Object-masked frames walked through their valid-pixel lists
+    // have sweeps so short -- 53 us per iteration at c3 x 32 -- that an instance's next items come up before its 60 us in-launch solve is done:
+    // measured 0.74 against 0.52 ms per step, profiles/r04/chain_experiments.json; they keep the plain schedule unless chain = 1 asks)
+    const bool chain = chain_lay != 0 && !ws->chain_failed && ws->tune.chain != 0 && (ws->tune.chain > 0 || (B >= 16 && !compaction)) && use_sparse && use_dense
+                       && !trace && !atomic_sums && !a_global && !D.pre_assembled && N <= kChainMaxFrames && chunks <= kChainMaxParts && tiles <= kChainMaxParts
+                       && !(prm->flags & (BTBA_FLAG_NO_FUSE | BTBA_FLAG_OVERLAP)) && !Z.frame_slot
+                       && lds_rest + 16 + sizeof(float) * chain_region_floats(N) <= kChainLdsBytes;      // (c3's 15 frames are the largest window whose solve fits a sweep workgroup's LDS share)
+    ChainDims Cn{};
+    int plain_pairsum_in_lds = 0;
+    auto pad32 = [](size_t floats) { return (floats + 31) & ~(size_t)31; };      // whole 128-byte lines
+    if (chain) {
+        const int n_it = prm->n_gn_iters;
+        D.pose_stride = (int)pad32(16 * (size_t)N); D.x_stride = (int)pad32(6 * (size_t)N);
+        D.sp_stride = (int64_t)pad32((size_t)P * chunks * kSparseVals); D.dp_stride = (int64_t)pad32((size_t)Pd * tiles * kDenseVals);
+        D.publish = 1;
+        plain_pairsum_in_lds = D.pairsum_in_lds;
+        D.pairsum_in_lds = 0;
+        Cn.last_solve_external = 1;
+        Cn.n_iter = n_it; Cn.n_inst = B; Cn.inst_per_xcd = (unsigned)((B + 7) / 8);
+        Cn.items_d = (unsigned)tiles * (unsigned)D.n_dense_pairs; Cn.items_s = (unsigned)chunks * (unsigned)P;
+        Cn.sparse_period = (unsigned)ws->tune.chain_sparse_period;
+        if (Cn.sparse_period >= 2u && Cn.sparse_period * Cn.items_s > Cn.items_d + Cn.items_s) Cn.sparse_period = (Cn.items_d + Cn.items_s) / Cn.items_s;      // all sparse items must find a slot
+        if (Cn.sparse_period < 2u) Cn.sparse_period = 0u;
+        Cn.timeout_ticks = (long long)ws->tune.chain_timeout_ms * 100000ll;
+        Cn.solve_prio = ws->tune.chain_solve_prio;
+        Cn.debug_skip = ws->tune.chain_debug_skip;
+        if (Cn.debug_skip & 16) D.publish = 0;             // (timing experiment: plain record stores)
+        Cn.pose_ring = (size_t)B * D.pose_stride; Cn.x_ring = (size_t)B * D.x_stride;
+        Cn.sp_ring = (size_t)B * (size_t)D.sp_stride; Cn.dp_ring = (size_t)B * (size_t)D.dp_stride;
+        Cn.ps_size = pad32((size_t)D.n_dense_pairs * kDenseVals); Cn.A_size = pad32((n + 2) * ld);      // (global scratch: the reduced DENSE pair sums; the matrix before it is packed into LDS)
+        if ((rc = ws->x.ensure(sizeof(float) * (n_it + 1) * Cn.x_ring))) return rc;
+        if ((rc = ws->T.ensure(sizeof(float) * (n_it + 1) * Cn.pose_ring))) return rc;
+        if ((rc = ws->Tinv.ensure(sizeof(float) * (n_it + 1) * Cn.pose_ring))) return rc;
+        if ((rc = ws->sparse_part.ensure(sizeof(float) * n_it * Cn.sp_ring))) return rc;
+        if ((rc = ws->dense_part.ensure(sizeof(float) * n_it * Cn.dp_ring))) return rc;
+        if ((rc = ws->pairsum.ensure(sizeof(float) * (size_t)n_it * B * Cn.ps_size))) return rc;
+        if ((rc = ws->big_A.ensure(sizeof(float) * (size_t)n_it * B * Cn.A_size))) return rc;
+        const size_t sync_head = ((size_t)B * (n_it + 1) + 15) & ~(size_t)15;               // flags[B], arrivals[n_it][B], padded to a 64-byte line
+        const size_t sync_ints = sync_head + (size_t)16 * B * (n_it + 1);                  // ... published[n_it + 1][B][16]
+        if ((rc = ws->chain_sync.ensure(sizeof(int) * sync_ints))) return rc;
+        if (!ws->chain_error) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ws->chain_error), 64, hipHostMallocDefault));
+            *ws->chain_error = 0;
+        }
+        HIP_TRY(hipMemsetAsync(ws->chain_sync.p, 0, sizeof(int) * sync_ints, ws->stream));      // flags and arrival counters: zero before EVERY launch
+        Cn.flags = ws->chain_sync.as<int>(); Cn.arrivals = Cn.flags + B; Cn.published = Cn.flags + sync_head; Cn.error = ws->chain_error;
+    }
     // Log, Exp, inverse of the incoming matrices
     {
         const int total = B * N;
-        k_prepare<<<(total + 63) / 64, 64, 0, ws->stream>>>(total, poses, ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>());
+        if (chain) k_prepare_strided<<<(total + 63) / 64, 64, 0, ws->stream>>>(total, N, D.pose_stride, D.x_stride, poses, ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>());
+        else k_prepare<<<(total + 63) / 64, 64, 0, ws->stream>>>(total, poses, ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>());
     }
     // per-frame valid-pixel lists for the compact dense sweep (once per solve; the frames do not change across iterations)
-    const bool compaction = use_zn && use_dense && (prm->flags & BTBA_FLAG_COMPACTION);
     const uint32_t *lists_base = Z.lists;
     const int *counts_base = Z.counts;
     if (compaction && !lists_base) {
@@ -682,7 +772,81 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         for (int g = 1; g < n_halves; g++) HIP_TRY(hipStreamWaitEvent(ws->aux_streams[g - 1], ws->ev_fork, 0));
     }
     const size_t pairsum_floats = lds_pairs / sizeof(float);
-    const size_t lut_bytes = sizeof(float) * (size_t)((Wd + Hd + 3) & ~3) + (zn_layout == 1 ? sizeof(float4) * (size_t)(Wd + Hd) : 0) + blist_bytes;         // coordinate look-up tables of the compact dense sweep (+ its list of live blocks)
+    S.chain_iterations = 0;
+    const size_t lut_bytes = sizeof(float) * (size_t)((Wd + Hd + 3) & ~3) + (zn_layout == 1 ? sizeof(float4) * (size_t)(Wd + Hd) : 0) + blist_bytes + (size_t)ws->tune.debug_lds_pad;         // coordinate look-up tables of the compact dense sweep (+ its list of live blocks)
+    if (chain) {
+        // ONE launch: 8 XCD sequences x n_gn iterations x (instances of the XCD) x (sweep items + 1 solve item)
+        const size_t chain_lds = std::max(lut_bytes, lds_rest + 16 + sizeof(float) * chain_region_floats(N));
+        const unsigned per_inst = Cn.items_d + Cn.items_s + 1u;
+        const unsigned grid = 8u * (unsigned)prm->n_gn_iters * Cn.inst_per_xcd * per_inst;
+        if (!ws->tune.chain_trace_file.empty()) {          // developer: timeline of the launch (scripts/chain_trace.py)
+            const size_t trace_bytes = 32 * (size_t)grid + 64 * (size_t)prm->n_gn_iters * B;
+            if ((rc = ws->chain_trace.ensure(trace_bytes))) return rc;
+            HIP_TRY(hipMemsetAsync(ws->chain_trace.p, 0, trace_bytes, ws->stream));
+            Cn.trace = ws->chain_trace.as<unsigned long long>();
+            Cn.stamps = Cn.trace + 4 * (size_t)grid;
+        }
+        const float4 *corr_c = reinterpret_cast<const float4 *>(corr);
+        size_t slot;
+        if (Cn.debug_skip & 32) {
+            // developer TIMING experiment: the chain kernel as a plain per-iteration sweep launch (its solve items return at once) followed by
+            // k_system_solve on ring slot 0 -- what the sweep items cost in THIS kernel binary without the in-launch schedule
+            ChainDims C1 = Cn;
+            C1.n_iter = 1; C1.debug_skip |= 8; C1.trace = nullptr; C1.stamps = nullptr;
+            const unsigned grid1 = 8u * Cn.inst_per_xcd * per_inst;
+            if ((rc = ws->pairsum.ensure(sizeof(float) * (size_t)B * ((size_t)P * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals + 64)))) return rc;
+            for (int it = 0; it < prm->n_gn_iters; it++) {
+                if ((rc = time_begin(ws, timing, 0, &slot))) return rc;
+#define BTBA_CHAIN_ARGS1 D, C1, reinterpret_cast<const float4 *>(Z.zn), ws->T.as<float>(), ws->Tinv.as<float>(), ws->x.as<float>(), ws->dense_part.as<float>(), corr_c, pair_offsets, \
+                        ws->sparse_part.as<float>(), compaction ? lists_base : nullptr, compaction ? counts_base : nullptr, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, ws->solve_tab.as<int>(), \
+                        ws->pairsum.as<float>(), ws->big_A.as<float>(), poses
+                if (chain_lay == 1) k_chain<1><<<dim3(grid1), kBlock, chain_lds, ws->stream>>>(BTBA_CHAIN_ARGS1);
+                else k_chain<3><<<dim3(grid1), kBlock, chain_lds, ws->stream>>>(BTBA_CHAIN_ARGS1);
+#undef BTBA_CHAIN_ARGS1
+                if ((rc = time_end(ws, slot))) return rc;
+                if ((rc = time_begin(ws, timing, 2, &slot))) return rc;
+                k_system_solve<false, false><<<B, kSolveBlock, lds_core, ws->stream>>>(D, it, ws->sparse_part.as<float>(), ws->dense_part.as<float>(), ws->dense_pairs.as<int2>(), d_adj_off, d_adj,
+                    ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>(), ws->pairsum.as<float>(), nullptr, nullptr, it == prm->n_gn_iters - 1 ? poses : nullptr, ws->solve_tab.as<int>());
+                if ((rc = time_end(ws, slot))) return rc;
+            }
+            S.fused_sweeps = 1;
+        } else {
+        if ((rc = time_begin(ws, timing, 0, &slot))) return rc;
+#define BTBA_CHAIN_ARGS D, Cn, reinterpret_cast<const float4 *>(Z.zn), ws->T.as<float>(), ws->Tinv.as<float>(), ws->x.as<float>(), ws->dense_part.as<float>(), corr_c, pair_offsets, \
+                        ws->sparse_part.as<float>(), compaction ? lists_base : nullptr, compaction ? counts_base : nullptr, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, ws->solve_tab.as<int>(), \
+                        ws->pairsum.as<float>(), ws->big_A.as<float>(), poses
+        if (chain_lay == 1) k_chain<1><<<dim3(grid), kBlock, chain_lds, ws->stream>>>(BTBA_CHAIN_ARGS);
+        else k_chain<3><<<dim3(grid), kBlock, chain_lds, ws->stream>>>(BTBA_CHAIN_ARGS);
+#undef BTBA_CHAIN_ARGS
+        if ((rc = time_end(ws, slot))) return rc;
+        if (Cn.last_solve_external) {
+            // the last iteration's system solve as its own launch on the last ring slot: the launch above has drained, 16 waves per instance
+            const int il = prm->n_gn_iters - 1;
+            SolveDims Dl = D;
+            Dl.pairsum_in_lds = plain_pairsum_in_lds; Dl.publish = 0;
+            if (!Dl.pairsum_in_lds) { if ((rc = ws->pairsum.ensure(std::max(sizeof(float) * (size_t)prm->n_gn_iters * B * Cn.ps_size, (size_t)B * lds_pairs + 16)))) return rc; }
+            if ((rc = time_begin(ws, timing, 2, &slot))) return rc;
+#define BTBA_LAST_SOLVE(LP) k_system_solve<LP, false><<<B, kSolveBlock, lds_bytes, ws->stream>>>(Dl, il, ws->sparse_part.as<float>() + il * Cn.sp_ring, ws->dense_part.as<float>() + il * Cn.dp_ring, \
+                ws->dense_pairs.as<int2>(), d_adj_off, d_adj, ws->x.as<float>() + il * Cn.x_ring, ws->T.as<float>() + il * Cn.pose_ring, ws->Tinv.as<float>() + il * Cn.pose_ring, \
+                ws->pairsum.as<float>(), nullptr, nullptr, poses, ws->solve_tab.as<int>())
+            if (Dl.pairsum_in_lds) BTBA_LAST_SOLVE(true); else BTBA_LAST_SOLVE(false);
+#undef BTBA_LAST_SOLVE
+            if ((rc = time_end(ws, slot))) return rc;
+        }
+        S.chain_iterations = prm->n_gn_iters;
+        S.fused_sweeps = 1;
+        ws->chain_launches++;
+        if (Cn.trace) {
+            HIP_TRY(hipStreamSynchronize(ws->stream));
+            std::vector<unsigned long long> host(4 * (size_t)grid + 8 * (size_t)prm->n_gn_iters * B);
+            HIP_TRY(hipMemcpy(host.data(), ws->chain_trace.p, 8 * host.size(), hipMemcpyDeviceToHost));
+            if (FILE *f = std::fopen(ws->tune.chain_trace_file.c_str(), "wb")) {       // [0] = number of block records, then the records, then the solve items' phase stamps
+                const unsigned long long nrec = grid;
+                std::fwrite(&nrec, 8, 1, f); std::fwrite(host.data(), 8, host.size(), f); std::fclose(f);
+            }
+        }
+        }
+    } else
     for (int it = 0; it < prm->n_gn_iters; it++) {
         const bool timing_it = timing && (timed_iteration < 0 || timed_iteration == it);
         for (int h = 0; h < n_halves; h++) {
@@ -814,7 +978,7 @@ int btba_collect_stats(btba_workspace *ws, btba_stats *stats)
     if (stats) *stats = S;
     S.ms_dense_sweep = S.ms_sparse_sweep = S.ms_system_solve = S.ms_solve = S.ms_cache = 0.0f;
     S.n_dense_launches = S.n_sparse_launches = S.n_solve_launches = 0;
-    return BTBA_OK;
+    return chain_check(ws);
 }
 
 int btba_solve_batch(btba_workspace *ws, const btba_params *params, int n_instances, int n_frames, int Hd, int Wd, const float *intr,

@@ -299,8 +299,9 @@ __device__ __forceinline__ void wave_fold_store(const float (&acc)[NV], float *d
 // wave order across waves.
 // atomic: add the workgroup's sums into out[] with hardware float atomics (global_atomic_add_f32) instead of storing them --
 // BTBA_REDUCE_ATOMIC, the reference's own way of summing (SolverBundlingDenseUtil.h:217-285): the order in which workgroups land is not fixed.
+// mode: 0 store, 1 float atomics, 2 write-through store at agent scope (the record is read by another workgroup of the same launch: k_chain)
 template <int NV, int NWAVES>
-__device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float *lds_scratch, float *out, bool atomic = false)
+__device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float *lds_scratch, float *out, int mode = 0)
 {
     const int tid = (int)item_tid(), wave = tid >> 6;
     wave_fold_store<NV>(acc, lds_scratch + wave * NV);
@@ -309,7 +310,9 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NV], float *lds_
         float s = lds_scratch[k];
 #pragma unroll
         for (int w = 1; w < NWAVES; w++) s += lds_scratch[w * NV + k];
-        if (atomic) unsafeAtomicAdd(out + k, s); else out[k] = s;
+        if (mode == 1) unsafeAtomicAdd(out + k, s);
+        else if (mode == 2) __hip_atomic_store(out + k, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[k] = s;
     }
 }
 

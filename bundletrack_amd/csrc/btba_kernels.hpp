@@ -90,6 +90,12 @@ struct SolveDims {
     int zn_simple;       // 1: zero skew and affine last row (ki[1]=ki[3]=ki[4]=ki[7]=ki[12]=ki[13]=ki[14]=0)
     // persistent frame cache: frame f of the solve lives in pool slot frame_slot[f] (nullptr: slot == f, contiguous cache)
     const int *frame_slot;
+    // floats per INSTANCE in the pose arrays (T, Tinv: >= 16 N), the state array (x: >= 6 N) and the sweep partials.  The plain launches keep
+    // the instances back to back; the chained launch (k_chain) pads every instance's region to whole 128-byte lines, so that no cache line is
+    // shared by two regions that different workgroups publish at different times.
+    int pose_stride, x_stride;
+    int64_t sp_stride, dp_stride;
+    int publish;         // k_chain: sweep workgroups store their partial records write-through (agent scope) -- another workgroup of the SAME launch reads them
 };
 
 __device__ __forceinline__ size_t frame_slot_of(const SolveDims &D, size_t f) { return D.frame_slot ? (size_t)D.frame_slot[f] : f; }
@@ -297,8 +303,8 @@ __device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const floa
     const uint32_t len = D.pair_lens ? as_const(D.pair_lens)[(size_t)b * D.n_pairs + p] : off[p + 1] - seg0;       // (pool segments are not back to back)
     const uint32_t per = (len + D.sparse_chunks - 1) / D.sparse_chunks;
     const uint32_t lo = seg0 + min(len, per * chunk), hi = seg0 + min(len, per * (chunk + 1));
-    const Mat4 Ti = load_mat4_uniform(T + 16 * ((size_t)b * D.n_frames + fi));
-    const Mat4 Tj = load_mat4_uniform(T + 16 * ((size_t)b * D.n_frames + fj));
+    const Mat4 Ti = load_mat4_uniform(T + (size_t)b * D.pose_stride + 16 * fi);
+    const Mat4 Tj = load_mat4_uniform(T + (size_t)b * D.pose_stride + 16 * fj);
     float acc[kSparseVals];
 #pragma unroll
     for (int k = 0; k < kSparseVals; k++) acc[k] = 0.0f;
@@ -364,8 +370,8 @@ __device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const floa
         }
         if (D.order_flag && misplaced) atomicOr(D.order_flag, 1);
     }
-    float *out = partials + (D.atomic_sums ? ((size_t)b * D.n_pairs + p) : (((size_t)b * D.n_pairs + p) * D.sparse_chunks + chunk)) * kSparseVals;
-    block_reduce_store<kSparseVals, 4>(acc, red, out, D.atomic_sums != 0);
+    float *out = partials + (size_t)b * D.sp_stride + (D.atomic_sums ? (size_t)p : (size_t)p * D.sparse_chunks + chunk) * kSparseVals;
+    block_reduce_store<kSparseVals, 4>(acc, red, out, D.atomic_sums ? 1 : D.publish ? 2 : 0);
 }
 __device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
                                              const float *__restrict__ T, float *__restrict__ partials, int chunk, int p, int b, float *red)
@@ -561,8 +567,16 @@ __device__ __forceinline__ void dense_stage_M(float *red, const float *__restric
 
 // FLIPPED: the sums were accumulated with a+ = D a, res+ = -res (dense_block_pinhole): S = D S+ D negates the nine entries that couple a
 // translation row with a rotation row, g = -D g+ negates the three rotation entries -- exact.
+// mode: 0 store the record, 1 add it to the record with float atomics (BTBA_REDUCE_ATOMIC), 2 store it WRITE-THROUGH at agent scope (k_chain:
+// the record is read by another workgroup of the same launch, MI355X_MICROARCH.md "inter-workgroup visibility")
+__device__ __forceinline__ void store_sum(float *p, float v, int mode)
+{
+    if (mode == 1) unsafeAtomicAdd(p, v);
+    else if (mode == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 template <bool FLIPPED = false>
-__device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *red, float *out, bool atomic = false)
+__device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *red, float *out, int mode = 0)
 {
     const unsigned tid = item_tid();
     wave_fold_store<kDenseVals>(acc, red + (tid >> 6) * kDenseVals);
@@ -600,15 +614,15 @@ __device__ __forceinline__ void dense_epilogue(float (&acc)[kDenseVals], float *
             for (int l = 0; l < 6; l++) u += S[tri21(k2, l)] * Mc[l];
             a += Mr[k2] * u;
         }
-        if (atomic) unsafeAtomicAdd(out + idx, a); else out[idx] = a;
+        store_sum(out + idx, a, mode);
     } else if (idx < 27) {
         const int r = idx - 21;
         float a = 0.0f;
 #pragma unroll
         for (int k2 = 0; k2 < 6; k2++) a += Mt[6 * r + k2] * Sp[21 + k2];
-        if (atomic) unsafeAtomicAdd(out + idx, a); else out[idx] = a;
+        store_sum(out + idx, a, mode);
     } else if (idx == 27) {
-        if (atomic) unsafeAtomicAdd(out + 27, Sp[27]); else out[27] = Sp[27];
+        store_sum(out + 27, Sp[27], mode);
     }
 }
 
@@ -621,9 +635,10 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
 {
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
-    dense_stage_M(red, T + 16 * (fb + fi));
+    const size_t pb = (size_t)b * D.pose_stride;
+    dense_stage_M(red, T + pb + 16 * fi);
     DenseCtx C;
-    C.Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), load_mat4(T + 16 * (fb + fj)));      // source camera -> target camera
+    C.Tij = mat_mul(load_mat4(Tinv + pb + 16 * fi), load_mat4(T + pb + 16 * fj));      // source camera -> target camera
     C.cam_t = campos + (fb + fi) * (size_t)D.npix; C.nrm_t = normals + (fb + fi) * (size_t)D.npix;
     C.fx = D.fx; C.fy = D.fy; C.cx = D.cx; C.cy = D.cy; C.depth_min = D.depth_min; C.depth_max = D.depth_max;
     C.normal_thresh = D.normal_thresh; C.dist2_thresh = D.dist_thresh * D.dist_thresh;
@@ -651,8 +666,8 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
             pixel_accumulate(C, g, c00, c10, c01, c11, n00, n10, n01, n11, acc);
         }
     }
-    float *out = partials + (D.atomic_sums ? ((size_t)b * D.n_dense_pairs + p) : (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile)) * kDenseVals;
-    dense_epilogue(acc, red, out, D.atomic_sums != 0);
+    float *out = partials + (size_t)b * D.dp_stride + (D.atomic_sums ? (size_t)p : (size_t)p * D.dense_tiles + tile) * kDenseVals;
+    dense_epilogue(acc, red, out, D.atomic_sums ? 1 : D.publish ? 2 : 0);
 }
 
 // ---- per-block depth ranges of the compact cache ------------------------------------------------------------------
@@ -757,9 +772,10 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
     const float *lut_x = lut, *lut_y = lut + D.width;
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
-    dense_stage_M(red, T + 16 * (fb + fi));
+    const size_t pb = (size_t)b * D.pose_stride;
+    dense_stage_M(red, T + pb + 16 * fi);
     DenseCtx C;
-    C.Tij = mat_mul(load_mat4(Tinv + 16 * (fb + fi)), load_mat4(T + 16 * (fb + fj)));
+    C.Tij = mat_mul(load_mat4(Tinv + pb + 16 * fi), load_mat4(T + pb + 16 * fj));
     // the relative pose is the same in every lane: keep it in scalar registers (12 VGPRs back)
 #pragma unroll
     for (int e = 0; e < 12; e++) C.Tij.m[e] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, C.Tij.m[e])));
@@ -819,8 +835,8 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
         pixel_accumulate(C, g, make_float4(c00.x, c00.y, c00.z, 1.f), make_float4(c10.x, c10.y, c10.z, 1.f), make_float4(c01.x, c01.y, c01.z, 1.f), make_float4(c11.x, c11.y, c11.z, 1.f),
                          make_float4(z00.y, z00.z, z00.w, 0.f), make_float4(z10.y, z10.z, z10.w, 0.f), make_float4(z01.y, z01.z, z01.w, 0.f), make_float4(z11.y, z11.z, z11.w, 0.f), acc);
     }
-    float *out = partials + (D.atomic_sums ? ((size_t)b * D.n_dense_pairs + p) : (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile)) * kDenseVals;
-    dense_epilogue(acc, red, out, D.atomic_sums != 0);
+    float *out = partials + (size_t)b * D.dp_stride + (D.atomic_sums ? (size_t)p : (size_t)p * D.dense_tiles + tile) * kDenseVals;
+    dense_epilogue(acc, red, out, D.atomic_sums ? 1 : D.publish ? 2 : 0);
 }
 
 // ---- the dense sweep for pinhole intrinsics on the GATED compact cache --------------------------------------------
@@ -952,10 +968,11 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     const size_t fb = (size_t)b * D.n_frames;
     const size_t slot_t = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fi));
     const size_t slot_s = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fj));
-    const Mat4 Tinv_i = load_mat4_uniform(Tinv + 16 * (fb + fi)), T_j = load_mat4_uniform(T + 16 * (fb + fj));
+    const size_t pb = (size_t)b * D.pose_stride;
+    const Mat4 Tinv_i = load_mat4_uniform(Tinv + pb + 16 * fi), T_j = load_mat4_uniform(T + pb + 16 * fj);
     float m_stage = 0.0f;                                 // M of the epilogue's congruence, from the target frame's pose (see dense_stage_M)
     if (tid >= 64 && tid < 64 + 36) {
-        const float *T_target = T + 16 * (fb + fi);
+        const float *T_target = T + pb + 16 * fi;
         const int e = (int)tid - 64, r = e / 6, c = e % 6;
         if (r < 3) m_stage = (c < 3) ? T_target[4 * r + c] : 0.0f;
         else {
@@ -1211,8 +1228,8 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
             pixel(zs, 4u * ox, 4u * oy);                  // 4-byte table offsets -> 16-byte entries (rowB follows colA as the row table follows the column table)
         }
     }
-    float *out = partials + (D.atomic_sums ? ((size_t)b * D.n_dense_pairs + p) : (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles + tile)) * kDenseVals;
-    dense_epilogue<true>(acc, red, out, D.atomic_sums != 0);
+    float *out = partials + (size_t)b * D.dp_stride + (D.atomic_sums ? (size_t)p : (size_t)p * D.dense_tiles + tile) * kDenseVals;
+    dense_epilogue<true>(acc, red, out, D.atomic_sums ? 1 : D.publish ? 2 : 0);
 }
 
 template <bool SIMPLE, bool LISTS>
@@ -1439,7 +1456,7 @@ __device__ __forceinline__ float strided_sum(const float *__restrict__ q, int co
 //                   eighth of the frame's pairs in fixed order, fixed shuffle tree), plus the zero-fill of what nobody writes
 // k_system_solve then starts at the PCG (D.pre_assembled).  Same formulas as phases A and B of k_system_solve; the sums over a
 // frame's pairs are grouped in eighths instead of halves / quarters.  System layout per instance: A[n][ld], rhs[ld], prec[ld].
-__global__ void __launch_bounds__(256) k_big_reduce(SolveDims D, const float *__restrict__ sparse_partials, const float *__restrict__ dense_partials,
+__global__ void __launch_bounds__(256) k_big_reduce(SolveDims D, float *sparse_partials, float *dense_partials,       // (not const: accumulators in BTBA_REDUCE_ATOMIC mode, cleared here)
                                                     float *__restrict__ pairsum_global)
 {
     const int b = blockIdx.y;
@@ -1451,15 +1468,15 @@ __global__ void __launch_bounds__(256) k_big_reduce(SolveDims D, const float *__
     if (e < ns) {
         if (D.use_sparse) {
             const size_t p = e / kSparseVals, v = e - p * kSparseVals;
-            const float *q = sparse_partials + (((size_t)b * D.n_pairs + p) * D.sparse_chunks) * kSparseVals + v;
+            float *q = sparse_partials + (size_t)b * D.sp_stride + (p * D.sparse_chunks) * kSparseVals + v;
             for (int c = 0; c < D.sparse_chunks; c++) s += q[(size_t)c * kSparseVals];
-            if (D.atomic_sums) const_cast<float *>(q)[0] = 0.0f;
+            if (D.atomic_sums) q[0] = 0.0f;
         }
     } else if (D.use_dense) {
         const size_t ed = e - ns, p = ed / kDenseVals, v = ed - p * kDenseVals;
-        const float *q = dense_partials + (((size_t)b * D.n_dense_pairs + p) * D.dense_tiles) * kDenseVals + v;
+        float *q = dense_partials + (size_t)b * D.dp_stride + (p * D.dense_tiles) * kDenseVals + v;
         for (int c = 0; c < D.dense_tiles; c++) s += q[(size_t)c * kDenseVals];
-        if (D.atomic_sums) const_cast<float *>(q)[0] = 0.0f;
+        if (D.atomic_sums) q[0] = 0.0f;
     }
     out[e] = s;
 }
@@ -1597,23 +1614,40 @@ __global__ void __launch_bounds__(256) k_big_assemble(SolveDims D, const float *
     }
 }
 
-// grid (B); dynamic LDS: A[n*ld] + 7 vectors[n] + scratch + (optionally) reduced pair sums.
-// cross_ok[p] (dense) = 1 when the dense cross block survives FlipJtJ (target < source).
-template <bool LDS_PAIRS, bool A_GLOBAL = false>
-__global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int iter,
-                                                        const float *__restrict__ sparse_partials, const float *__restrict__ dense_partials,
-                                                        const int2 *__restrict__ dense_pairs, const int *__restrict__ adj_off, const int *__restrict__ adj,
-                                                        float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv,
-                                                        float *__restrict__ pairsum_global, float *__restrict__ trace, float *__restrict__ A_scratch = nullptr,
-                                                        float *__restrict__ poses_out = nullptr, const int *__restrict__ solve_tab = nullptr)
+// What one instance's system solve reads and writes, every pointer already at THIS instance.  The plain launch (k_system_solve) updates x, T
+// and T^-1 in place; the chained launch (k_chain) reads iterate `it` and writes iterate `it + 1` into the next slot of a ring, because the
+// sweep workgroups of other instances -- and of this instance's next iteration -- are running at the same time.
+struct SolveIO {
+    float *sparse_partials, *dense_partials;            // this iteration's sweep partials (not const: in BTBA_REDUCE_ATOMIC mode they are accumulators that the solve clears)
+    const float *x_in, *T_in;                           // this iterate
+    float *x_out, *T_out, *Tinv_out;                    // the next one
+    float *poses_out;                                   // last iteration: the caller's pose buffer (or nullptr)
+    float *pairsum_global;                              // reduced pair sums when they are not staged in LDS
+    float *A_scratch;                                   // A_GLOBAL / pre_assembled / CHAIN: A[n][ld], rhs[ld], prec[ld]
+    float *trace;                                       // this instance's trace records (or nullptr)
+    unsigned long long *stamps;                         // developer (scripts/chain_trace.py): 8 wall-clock stamps of the phases of this solve (or nullptr)
+};
+
+// The system solve of ONE instance by the calling workgroup (all of its threads must call; dynamic LDS: A[n*ld] (unless A_GLOBAL / CHAIN)
+// + 7 vectors[n] + scratch + tables + (optionally) reduced pair sums).
+//   CHAIN = false: k_system_solve's body, a workgroup of 1 024 threads, one-wave PCG on the LDS-resident matrix (or the 16-wave PCG of A_GLOBAL).
+//   CHAIN = true : the same sums in the same order run by a 256-thread workgroup of k_chain that shares its compute unit with five sweep
+//                  workgroups and may only use a sweep workgroup's share of the LDS: the matrix lives in an L2-resident global scratch, the
+//                  mat-vec of the PCG is spread over all four waves (two lanes per row, each the two partial sums of the one-wave version
+//                  that belong to its half of the 16-byte chunks), everything else of a PCG step is the one-wave code, bit for bit.
+template <bool LDS_PAIRS, bool A_GLOBAL, bool CHAIN>
+__device__ __forceinline__ void system_solve_body(const SolveDims &D, int iter, const int tid, const int nthr, float *lds, const SolveIO &io,
+                                                  const int2 *__restrict__ dense_pairs, const int *__restrict__ adj_off, const int *__restrict__ adj,
+                                                  const int *__restrict__ solve_tab)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    float *sparse_partials = io.sparse_partials, *dense_partials = io.dense_partials;
+    float *A_scratch = io.A_scratch;
     const int N = D.n_frames, n = 6 * N, ld = 4 * (((n + 3) / 4) | 1);   // odd multiple of 4: 16-B rows, conflict-free ds_read_b128
     // windows of more than BTBA_MAX_FRAMES_LDS frames: the matrix does not fit the CU's LDS and lives in an L2-resident
     // global scratch (A_GLOBAL); everything else keeps its place
-    float *A = A_GLOBAL ? A_scratch + (size_t)blockIdx.x * (size_t)(n + 2) * ld : lds;      // global layout per instance: A[n][ld], rhs[ld], prec[ld]
-    float *vb = A_GLOBAL ? lds : A + (size_t)n * ld;       // rhs / residual r   (A's pad columns n..ld-1 stay 0)
+    constexpr bool A_IN_GLOBAL = A_GLOBAL || CHAIN;
+    float *A = A_IN_GLOBAL ? A_scratch : lds;      // global layout per instance: A[n][ld], rhs[ld], prec[ld]
+    float *vb = A_IN_GLOBAL ? lds : A + (size_t)n * ld;       // rhs / residual r   (A's pad columns n..ld-1 stay 0)
     float *vM = vb + ld, *vz = vM + ld, *vp = vz + ld, *vAp = vp + ld, *vd = vAp + ld;     // vector stride ld (16-B aligned, zero padded)
     float *scratch = vd + ld;             // 16 floats
     float *vT = scratch + 16;             // this iterate's T[N][16]
@@ -1628,25 +1662,32 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     float *ps;
     int *cross_l = entry_lut + 288;                                // canonical pair -> the dense pair whose cross block it carries (or -1): P ints, padded to 16 bytes
     float *x_l = reinterpret_cast<float *>(cross_l + ((D.n_pairs + 3) & ~3));       // this iterate's x (6 N floats, padded to 16 bytes): phase D would otherwise start with a fabric-latency load
-    if (LDS_PAIRS) ps = x_l + ((6 * N + 3) & ~3);
-    else ps = pairsum_global + (size_t)b * ((size_t)D.n_pairs * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals);
-    float *pd = ps + (size_t)D.n_pairs * kSparseVals;          // model-frame dense pair sums (S, g, count)
-    float *tr = D.trace_on ? trace + ((size_t)b * D.n_gn + iter) * D.trace_record : nullptr;
+    // CHAIN: a workgroup of k_chain owns a sweep workgroup's share of the LDS (a sixth of the compute unit's 160 KB).  What is left of it behind
+    // the tables and vectors -- region R -- holds the reduced SPARSE pair sums while the system is assembled (two of their values go into every
+    // matrix entry per pair; the dense sums, one value per entry and pair, stay in the global scratch and are fetched in batches) and afterwards
+    // the assembled matrix, packed: the lower triangle of its (n - 6) x (n - 6) non-zero part.  The host checks that both fit (chain_lds_floats).
+    float *region_R = lds + ((((x_l + ((6 * N + 3) & ~3)) - lds) + 3) & ~3);      // 16-byte aligned (the tables in front of it are not multiples of four words)
+    if (CHAIN) ps = region_R;
+    else if (LDS_PAIRS) ps = x_l + ((6 * N + 3) & ~3);
+    else ps = io.pairsum_global;
+    float *pd = CHAIN ? io.pairsum_global : ps + (size_t)D.n_pairs * kSparseVals;          // model-frame dense pair sums (S, g, count)
+    float *tr = (D.trace_on && io.trace) ? io.trace + (size_t)iter * D.trace_record : nullptr;
 
     const long long clk0 = tr ? (long long)clock64() : 0;
-#define BTBA_STAMP(slot) do { if (tr && tid == 0) tr[D.tr_clk + (slot)] = (float)((long long)clock64() - clk0); } while (0)
+#define BTBA_STAMP(slot) do { if (tr && tid == 0) tr[D.tr_clk + (slot)] = (float)((long long)clock64() - clk0); \
+                              if (CHAIN && io.stamps && tid == 0) io.stamps[slot] = (unsigned long long)wall_clock64(); } while (0)
     if (D.pre_assembled) {
         // larger windows: k_big_reduce + k_big_assemble have built A, the right-hand side and the Jacobi diagonal in the global scratch;
         // a matrix that fits LDS is loaded back for the one-wave PCG (coalesced, once)
-        const float *Ag = A_scratch + (size_t)blockIdx.x * (size_t)(n + 2) * ld;
+        const float *Ag = A_scratch;
         const float *rhs_g = Ag + (size_t)n * ld, *prec_g = rhs_g + ld;
-        if (!A_GLOBAL) {
+        if (!A_IN_GLOBAL) {
             const float4 *src = reinterpret_cast<const float4 *>(Ag);
             float4 *dst = reinterpret_cast<float4 *>(A);
             for (int e = tid; e < (n * ld) / 4; e += nthr) dst[e] = src[e];
         }
-        for (int e = tid; e < 16 * N; e += nthr) vT[e] = T[16 * (size_t)b * N + e];
-        for (int e = tid; e < 6 * N; e += nthr) x_l[e] = x[6 * (size_t)b * N + e];
+        for (int e = tid; e < 16 * N; e += nthr) vT[e] = io.T_in[e];
+        for (int e = tid; e < 6 * N; e += nthr) x_l[e] = io.x_in[e];
         for (int e = tid; e < n; e += nthr) { vb[e] = rhs_g[e]; vM[e] = prec_g[e]; vd[e] = 0.0f; }
         for (int e = n + tid; e < ld; e += nthr) vp[e] = 0.0f;
         __syncthreads();
@@ -1657,8 +1698,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     // loaded into registers here, the partial sums' loads are issued behind them, and the LDS stores happen after
     // the reduction -- the staging latency hides behind the first round of partial loads.
     const int n_dp = D.n_dense_pairs, n_adj = D.use_dense ? 2 * D.n_dense_pairs : 0, n_ao = D.use_dense ? N + 1 : 0;
-    const float st_T = tid < 16 * N ? T[16 * (size_t)b * N + tid] : 0.0f;
-    const float st_x = tid < 6 * N ? x[6 * (size_t)b * N + tid] : 0.0f;
+    const float st_T = tid < 16 * N ? io.T_in[tid] : 0.0f;
+    const float st_x = tid < 6 * N ? io.x_in[tid] : 0.0f;
     const int2 st_dp = tid < n_dp ? dense_pairs[tid] : make_int2(0, 0);
     const int st_ao = tid < n_ao ? adj_off[tid] : 0;
     const int st_adj = tid < n_adj ? adj[tid] : 0;
@@ -1673,17 +1714,19 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     // partials were written by other XCDs' workgroups, every load comes from the fabric side of this XCD's L2 at ~1-2 k
     // cycles, so the phase costs (number of dependent load rounds) x (that latency) -- 6 rounds at B = 1 (10 tiles,
     // 5 chunks) instead of the 14 of a 2-item x 4-partial scheme.  Sums in partial order (fixed), whatever the grouping.
-    auto reduce_partials = [&](auto vals_c, auto items_c, const float *src, float *dst, int n_items_pairs, int parts) {
+    auto reduce_partials = [&](auto vals_c, auto items_c, float *src, float *dst, int n_items_pairs, int parts) {
         constexpr int vals = decltype(vals_c)::value;
         constexpr int kItems = decltype(items_c)::value;
         const int total = n_items_pairs * vals;
         for (int e0 = tid; e0 < total; e0 += kItems * nthr) {
-            const float *q[kItems];
+            float *q[kItems];
             float sum[kItems];
+            bool own[kItems];                                              // dead slots re-read the lane's first item (and must not clear it twice)
 #pragma unroll
             for (int i = 0; i < kItems; i++) {
                 const int e = e0 + i * nthr;
-                const int ec = e < total ? e : e0;                         // dead slots re-read the lane's first item
+                const int ec = e < total ? e : e0;
+                own[i] = e < total;
                 q[i] = src + (size_t)(ec / vals) * parts * vals + (ec % vals);
                 sum[i] = 0.0f;
             }
@@ -1703,12 +1746,14 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
 #pragma unroll
                     for (int i = 0; i < kItems; i++)
 #pragma unroll
-                        for (int u = 0; u < width; u++) const_cast<float *>(q[i])[(size_t)(c + u) * vals] = 0.0f;
+                        for (int u = 0; u < width; u++) if (own[i]) q[i][(size_t)(c + u) * vals] = 0.0f;
                 }
                 c += width;
             };
-            while (c + 8 <= parts) round(std::integral_constant<int, 8>{});
-            if (c + 4 <= parts) round(std::integral_constant<int, 4>{});
+            if (!CHAIN) {                               // (the chained launch runs with <= 2 chunks / tiles: kChainMaxParts, checked by the host)
+                while (c + 8 <= parts) round(std::integral_constant<int, 8>{});
+                if (c + 4 <= parts) round(std::integral_constant<int, 4>{});
+            }
             if (c + 2 <= parts) round(std::integral_constant<int, 2>{});
             if (c < parts) round(std::integral_constant<int, 1>{});
 #pragma unroll
@@ -1717,29 +1762,67 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     };
     // items per lane per trip: one trip covers the c3 window (105 pairs: 4 620 sparse / 2 940 dense sums over 1 024 lanes).  (Reducing both kinds at
     // the same time on disjoint groups of waves -- one round of fabric-latency loads instead of two -- measured 0.5 us SLOWER per launch, r03 call 39.)
-    if (D.use_sparse) reduce_partials(std::integral_constant<int, kSparseVals>{}, std::integral_constant<int, 5>{}, sparse_partials + (size_t)b * D.n_pairs * D.sparse_chunks * kSparseVals, ps, D.n_pairs, D.sparse_chunks);
+    // (k_chain: 256 lanes under the sweep's 80-register budget and at most two partials per sum -- more items per lane, narrower rounds)
+    if (CHAIN) {
+        // 256 lanes, at most two partials per sum (kChainMaxParts): 16-byte loads, and ALL of a lane's loads -- sparse and dense records -- issued before
+        // the first add: one round of fabric latency instead of the four of the scalar scheme above (6.4 -> ~2.5 us).  The same sums: 0 + first (+ second).
+        constexpr int kS4 = kSparseVals / 4, kD4 = kDenseVals / 4, kRounds = 6;          // a lane holds up to 6 sums of four: covers 15 frames (1 155 + 735 sums of four over 256 lanes = 7.4 -> two passes)
+        const int ns4 = D.use_sparse ? D.n_pairs * kS4 : 0, nd4 = D.use_dense ? D.n_dense_pairs * kD4 : 0;
+        if (!D.use_sparse) for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) ps[e] = 0.0f;
+        for (int e0 = tid; e0 < ns4 + nd4; e0 += kRounds * nthr) {
+            float4 v0[kRounds], v1[kRounds];
+            bool two[kRounds];
+#pragma unroll
+            for (int u = 0; u < kRounds; u++) {
+                const int e = min(e0 + u * nthr, ns4 + nd4 - 1);
+                const bool sp = e < ns4;
+                const int q = sp ? e : e - ns4, per = sp ? kS4 : kD4, parts = sp ? D.sparse_chunks : D.dense_tiles;
+                const int rec = q / per, k = q - rec * per;
+                const float4 *src = reinterpret_cast<const float4 *>(sp ? sparse_partials : dense_partials) + ((size_t)rec * parts) * per + k;
+                two[u] = parts > 1;
+                v0[u] = src[0];
+                v1[u] = src[two[u] ? per : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < kRounds; u++) {
+                const int e = e0 + u * nthr;
+                if (e >= ns4 + nd4) continue;
+                float4 sum = make_float4(0.0f + v0[u].x, 0.0f + v0[u].y, 0.0f + v0[u].z, 0.0f + v0[u].w);
+                if (two[u]) { sum.x += v1[u].x; sum.y += v1[u].y; sum.z += v1[u].z; sum.w += v1[u].w; }
+                float4 *dst = e < ns4 ? reinterpret_cast<float4 *>(ps) + e : reinterpret_cast<float4 *>(pd) + (e - ns4);
+                *dst = sum;
+            }
+        }
+    } else {
+    if (D.use_sparse) reduce_partials(std::integral_constant<int, kSparseVals>{}, std::integral_constant<int, 5>{}, sparse_partials, ps, D.n_pairs, D.sparse_chunks);
     else for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) ps[e] = 0.0f;
-    if (D.use_dense) reduce_partials(std::integral_constant<int, kDenseVals>{}, std::integral_constant<int, 3>{}, dense_partials + (size_t)b * D.n_dense_pairs * D.dense_tiles * kDenseVals, pd, D.n_dense_pairs, D.dense_tiles);
+    if (D.use_dense) reduce_partials(std::integral_constant<int, kDenseVals>{}, std::integral_constant<int, 3>{}, dense_partials, pd, D.n_dense_pairs, D.dense_tiles);
+    }
     BTBA_STAMP(7);
     // the staged values: first trip from the registers loaded above, the rest (windows beyond 64 frames / 1 024 pairs) by loops
     if (tid < 16 * N) vT[tid] = st_T;
-    if (tid < 6 * N) x_l[tid] = st_x;                    // 6 N <= 510 < 1 024: one trip
+    if (tid < 6 * N) x_l[tid] = st_x;
+    for (int e = tid + nthr; e < 6 * N; e += nthr) x_l[e] = io.x_in[e];
     if (tid < D.n_pairs) pair_ij_l[tid] = st_pij;
     if (tid < 288) entry_lut[tid] = st_lut;
+    for (int e = tid + nthr; e < 288; e += nthr) entry_lut[e] = solve_tab[D.n_pairs + e];
     if (tid < D.n_pairs) cross_l[tid] = st_cross;
     for (int e = tid + nthr; e < D.n_pairs; e += nthr) { pair_ij_l[e] = solve_tab[e]; cross_l[e] = D.use_dense ? cross_tab[e] : -1; }
     if (tid < n_dp) { dense_pairs_lds[2 * tid] = st_dp.x; dense_pairs_lds[2 * tid + 1] = st_dp.y; }
     if (tid < n_ao) adj_off_l[tid] = st_ao;
+    for (int e = tid + nthr; e < n_ao; e += nthr) adj_off_l[e] = adj_off[e];
     if (tid < n_adj) adj_l[tid] = st_adj;
-    for (int e = tid + nthr; e < 16 * N; e += nthr) vT[e] = T[16 * (size_t)b * N + e];
+    for (int e = tid + nthr; e < 16 * N; e += nthr) vT[e] = io.T_in[e];
     for (int e = tid + nthr; e < n_dp; e += nthr) { const int2 ij = dense_pairs[e]; dense_pairs_lds[2 * e] = ij.x; dense_pairs_lds[2 * e + 1] = ij.y; }
     for (int e = tid + nthr; e < n_adj; e += nthr) adj_l[e] = adj[e];
     // zero what the assembly below does not write: frame 0's rows and columns (it stays fixed) and the pad columns n .. ld-1 that the
     // 16-byte mat-vec chunks read; every other entry is assigned by phase B (all canonical pairs with i >= 1, all diagonal blocks k >= 1)
-    for (int e = tid; e < 6 * ld; e += nthr) A[e] = 0.0f;
-    for (int e = tid; e < (n - 6) * (6 + ld - n); e += nthr) {
-        const int row = 6 + e / (6 + ld - n), q = e % (6 + ld - n);
-        A[row * ld + (q < 6 ? q : n + q - 6)] = 0.0f;
+    if (!CHAIN) {                                       // (the chained solve packs the non-zero part of the matrix and never reads the rest)
+        for (int e = tid; e < 6 * ld; e += nthr) A[e] = 0.0f;
+        for (int e = tid; e < (n - 6) * (6 + ld - n); e += nthr) {
+            const int row = 6 + e / (6 + ld - n), q = e % (6 + ld - n);
+            A[row * ld + (q < 6 ? q : n + q - 6)] = 0.0f;
+        }
     }
     __syncthreads();
     BTBA_STAMP(0);
@@ -1751,6 +1834,55 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     // dense pair listed as (target i, source j) for this canonical pair, if any (cross_l; a pair listed the other way round is erased
     // by the reference's FlipJtJ, duplicates of a pair in an explicit list are not supported -- documented): ONE pass, no
     // read-modify-write, no barrier before the diagonal blocks.
+    // CHAIN: the dense pair sums come from the global scratch -- an L2 round trip each, and a store to A between two of them keeps the compiler
+    // from issuing the next before the previous has returned (61 us for this phase, profiles/r04/chain_experiments.json).  So the loads of a
+    // batch of entries are issued first and consumed afterwards: the same values enter the same sums in the same order.
+    // sum of the dense pair sums `off` of adjacency entries [qa, qb) of a frame, signed by the frame's role in the pair when `by_role`
+    auto dense_adj_sum = [&](int qa, int qb, int off, bool by_role) {
+        float acc = 0.0f;
+        for (int q = qa; q < qb; q += 8) {
+            float v[8];
+            int a[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a[u] = adj_l[min(q + u, qb - 1)]; v[u] = pd[(size_t)(a[u] >> 1) * kDenseVals + off]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (q + u < qb) acc += by_role ? ((a[u] & 1) ? v[u] : -v[u]) : v[u];
+        }
+        return acc;
+    };
+    if (CHAIN) {
+        constexpr int kB = 4;                             // entries per lane and batch
+        const int total = D.n_pairs * 36;
+        for (int e0 = tid; e0 < total; e0 += kB * nthr) {
+            int pp[kB], rcv[kB], ij[kB];
+            float dv[kB];
+            bool has[kB];
+#pragma unroll
+            for (int u = 0; u < kB; u++) {
+                const int e = e0 + u * nthr, ec = min(e, total - 1);
+                pp[u] = ec / 36; rcv[u] = ec - 36 * pp[u];
+                const int pij = pair_ij_l[pp[u]];
+                ij[u] = (e < total && (pij >> 8) != 0) ? pij : 0;             // 0: nothing to do (beyond the end, or frame 0's rows / columns)
+                const int dp = ij[u] ? cross_l[pp[u]] : -1;
+                has[u] = dp >= 0;
+                dv[u] = has[u] ? pd[(size_t)dp * kDenseVals + tri21(rcv[u] / 6, rcv[u] % 6)] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < kB; u++) {
+                if (!ij[u]) continue;
+                const int p = pp[u], rc = rcv[u], r = rc / 6, c = rc - 6 * r, i = ij[u] >> 8, j = ij[u] & 255;
+                float v = 0.0f;
+                if (D.use_sparse) {
+                    const int *dl = entry_lut + 4 * (36 + rc);
+                    const int4 d = make_int4(dl[0], dl[1], dl[2], dl[3]);
+                    const float *rec = ps + (size_t)p * kSparseVals;
+                    v = -D.w_sparse * (__int_as_float(d.z) * rec[d.x & 255] + __int_as_float(d.w) * rec[d.y & 255]);
+                }
+                if (has[u]) v -= dv[u];
+                A[(6 * j + c) * ld + 6 * i + r] = v;       // (the lower-triangle copy is the one the packing reads)
+            }
+        }
+    } else
     for (int e = tid; e < D.n_pairs * 36; e += nthr) {
         const int p = e / 36, rc = e - 36 * p, r = rc / 6, c = rc - 6 * r;
         const int pij = pair_ij_l[p];
@@ -1792,7 +1924,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             const int t21 = tri21(r, c);
             const int q0 = adj_off_l[k], q1 = adj_off_l[k + 1], qm = q0 + (q1 - q0) / 2;
             float acc = 0.0f;
-            for (int q = half ? qm : q0; q < (half ? q1 : qm); q++) acc += pd[(size_t)(adj_l[q] >> 1) * kDenseVals + t21];
+            if (CHAIN) acc = dense_adj_sum(half ? qm : q0, half ? q1 : qm, t21, false);
+            else for (int q = half ? qm : q0; q < (half ? q1 : qm); q++) acc += pd[(size_t)(adj_l[q] >> 1) * kDenseVals + t21];
             v += acc;
         }
         v += __shfl_xor(v, 1, 64);                       // partner lane = same entry, other half (t and t^1 share a wave)
@@ -1822,7 +1955,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             if (D.use_dense) {
                 const int q0 = adj_off_l[k], nq = adj_off_l[k + 1] - q0;
                 float jtr = 0.0f;
-                for (int q = q0 + (nq * part) / 4; q < q0 + (nq * (part + 1)) / 4; q++) {
+                if (CHAIN) jtr = dense_adj_sum(q0 + (nq * part) / 4, q0 + (nq * (part + 1)) / 4, 21 + r, true);
+                else for (int q = q0 + (nq * part) / 4; q < q0 + (nq * (part + 1)) / 4; q++) {
                     const int a = adj_l[q];
                     const float g = pd[(size_t)(a >> 1) * kDenseVals + 21 + r];
                     jtr += (a & 1) ? g : -g;            // source frame: row_j = a;  target frame: row_i = -a
@@ -1842,6 +1976,27 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     __syncthreads();
     }
     BTBA_STAMP(2);
+    if (CHAIN) {
+        // the matrix into region R (the sparse pair sums are spent): entry (a, c), c <= a, of its non-zero (n - 6) x (n - 6) part at a (a + 1) / 2 + c.
+        // A is symmetric bit for bit (off-diagonal blocks are one value for both positions; a diagonal block's entries (r, c) and (c, r) are the
+        // same sums of the same values), so the packed lower triangle holds every value a row of the mat-vec reads.
+        const int na = n - 6, n_tri = na * (na + 1) / 2;
+        for (int e0 = tid; e0 < n_tri; e0 += 8 * nthr) {       // eight loads per lane in flight (the copy used to run one L2 round trip per element: 17 us)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = min(e0 + u * nthr, n_tri - 1);
+                int a = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);       // row of packed index e, fixed up for the rounding of the root
+                a -= (a * (a + 1) / 2 > e) ? 1 : 0;
+                a += ((a + 1) * (a + 2) / 2 <= e) ? 1 : 0;
+                const int c = e - a * (a + 1) / 2;
+                v[u] = A[(size_t)(6 + a) * ld + 6 + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (e0 + u * nthr < n_tri) region_R[e0 + u * nthr] = v[u];
+        }
+        __syncthreads();
+    }
     if (tr) {
         for (int e = tid; e < n; e += nthr) {
             const int k = e / 6, r = e % 6;           // trace order (rot, trans); internal [trans, rot]
@@ -1893,29 +2048,69 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
             __syncthreads();
         }
         if (live) vd[row] = d_;
-    } else if (tid < 64) {
+    } else if (CHAIN || tid < 64) {
         // rows per lane: 2 up to 128 unknowns (windows of <= 21 frames: every tracker-size window), 4 up to 186 (N <= BTBA_MAX_FRAMES_LDS = 31).
         // One wave alone on its SIMD pays ~8 cycles per instruction, so the two dead rows of a 4-row loop cost real time (the sums only
         // ever add their exact zeros: same bits either way).
         auto pcg = [&](auto rows_c) {
         constexpr int kMaxRows = decltype(rows_c)::value;
-        const int lane = tid;
+        // CHAIN: wave 0 runs this code as it stands, except that the matrix-vector product of a step is computed by all four waves (the
+        // matrix is in the global scratch: two rounds of L2-latency loads spread over 256 lanes instead of 23 chunks x 2 rows on one wave)
+        const int lane = tid & 63;
+        const bool w0 = tid < 64;
         float r_[kMaxRows], m_[kMaxRows], p_[kMaxRows], d_[kMaxRows];
-        float part = 0.0f;
+        float part = 0.0f, rz = 0.0f;
+        if (w0) {
 #pragma unroll
-        for (int j = 0; j < kMaxRows; j++) {
-            const int row = lane + 64 * j;
-            const bool live = row < n;
-            r_[j] = live ? vb[row] : 0.0f; m_[j] = live ? vM[row] : 0.0f; d_[j] = 0.0f;
-            p_[j] = m_[j] * r_[j];
-            part += r_[j] * p_[j];
-            if (live) vp[row] = p_[j];
+            for (int j = 0; j < kMaxRows; j++) {
+                const int row = lane + 64 * j;
+                const bool live = row < n;
+                r_[j] = live ? vb[row] : 0.0f; m_[j] = live ? vM[row] : 0.0f; d_[j] = 0.0f;
+                p_[j] = m_[j] * r_[j];
+                part += r_[j] * p_[j];
+                if (live) vp[row] = p_[j];
+            }
+            rz = wave_sum_all(part);
         }
-        float rz = wave_sum_all(part);
         for (int li = 0; li < D.n_pcg; li++) {
             float ap_[kMaxRows];
 #pragma unroll
             for (int j = 0; j < kMaxRows; j++) ap_[j] = 0.0f;
+            if (CHAIN) {
+                // Row r of A p in the one-wave code below: four partial sums over the x, y, z, w lanes of its 16-byte chunks, fused multiply-adds
+                // in chunk order, then (x + y) + (z + w).  Here lane pair (2 q, 2 q + 1) owns row 6 + q (frame 0's rows are zero: their product is
+                // an exact +0), lane h of the pair runs the two sums of its half of every chunk, and one exchange adds the halves: the same
+                // operations on the same operands in the same order.
+                // The matrix is the packed triangle in region R: A[row][k] = L[a (a + 1) / 2 + c] for c <= a, L[c (c + 1) / 2 + a] above the diagonal
+                // (a = row - 6, c = k - 6).  Columns 0 .. 5 (frame 0) and the pad columns hold exact zeros and zeros of p: skipped, their
+                // fused multiply-adds leave the sums as they are.
+                __syncthreads();                              // this step's p is in LDS
+                const int h = tid & 1, na = n - 6;
+                const float *L = region_R;
+                for (int pr = tid >> 1; pr < na; pr += nthr >> 1) {
+                    const int row = 6 + pr, a = pr, row_base = a * (a + 1) / 2;
+                    float sa = 0.0f, sb = 0.0f;
+                    // chunk cc covers columns 4 cc .. 4 cc + 3; this lane its columns k0 = 4 cc + 2 h and k0 + 1
+                    int c0 = 4 + 2 * h - 6;                                 // active column of k0 in chunk 1 (chunk 0 lies inside frame 0's zero columns)
+                    int tri0 = c0 * (c0 + 1) / 2, tri1 = (c0 + 1) * (c0 + 2) / 2;      // c (c + 1) / 2 of the two columns, advanced by 4 c + 10 per chunk
+                    for (int k0 = 4 + 2 * h; k0 < n; k0 += 4) {
+                        const float2 q = *reinterpret_cast<const float2 *>(vp + k0);
+                        if (c0 >= 0) sa = __builtin_fmaf(L[c0 <= a ? row_base + c0 : tri0 + a], q.x, sa);
+                        if (c0 + 1 >= 0 && c0 + 1 < na) sb = __builtin_fmaf(L[c0 + 1 <= a ? row_base + c0 + 1 : tri1 + a], q.y, sb);
+                        tri0 += 4 * c0 + 10; tri1 += 4 * c0 + 14;
+                        c0 += 4;
+                    }
+                    const float th = sa + sb;
+                    const float ap = th + __shfl_xor(th, 1, 64);
+                    if (h == 0) vAp[row] = ap;
+                }
+                if (tid < 6) vAp[tid] = 0.0f;
+                __syncthreads();
+                if (w0) {
+#pragma unroll
+                    for (int j = 0; j < kMaxRows; j++) ap_[j] = vAp[min(lane + 64 * j, n - 1)];
+                }
+            } else {
             const float4 *a0 = reinterpret_cast<const float4 *>(A + (size_t)min(lane, n - 1) * ld), *a1 = reinterpret_cast<const float4 *>(A + (size_t)min(lane + 64, n - 1) * ld);
             const float4 *a2 = reinterpret_cast<const float4 *>(A + (size_t)min(lane + 128, n - 1) * ld), *a3 = reinterpret_cast<const float4 *>(A + (size_t)min(lane + 192, n - 1) * ld);
             const float4 *p4 = reinterpret_cast<const float4 *>(vp);
@@ -1948,6 +2143,8 @@ _Pragma("unroll 4")
             }
             ap_[0] = (q0a.x + q0a.y) + (q0b.x + q0b.y); ap_[1] = (q1a.x + q1a.y) + (q1b.x + q1b.y);
             if (kMaxRows == 4) { ap_[kMaxRows - 2] = (q2a.x + q2a.y) + (q2b.x + q2b.y); ap_[kMaxRows - 1] = (q3a.x + q3a.y) + (q3b.x + q3b.y); }
+            }
+            if (!w0) continue;
             part = 0.0f;
 #pragma unroll
             for (int j = 0; j < kMaxRows; j++) part += (lane + 64 * j < n) ? p_[j] * ap_[j] : 0.0f;
@@ -1973,8 +2170,10 @@ _Pragma("unroll 4")
                 if (lane + 64 * j < n) vp[lane + 64 * j] = p_[j];
             }
         }
+        if (w0) {
 #pragma unroll
-        for (int j = 0; j < kMaxRows; j++) if (lane + 64 * j < n) vd[lane + 64 * j] = d_[j];
+            for (int j = 0; j < kMaxRows; j++) if (lane + 64 * j < n) vd[lane + 64 * j] = d_[j];
+        }
         };
         if (n <= 128) pcg(std::integral_constant<int, 2>{}); else pcg(std::integral_constant<int, 4>{});
     }
@@ -1983,7 +2182,7 @@ _Pragma("unroll 4")
     BTBA_STAMP(3);
     // Phase D: x_k <- Log(Exp(delta_k) Exp(x_k)); next iterate's T, T^-1  (SolverBundling.cu:805-815, 890-897)
     for (int k = tid; k < N; k += nthr) {
-        float *xk = x + 6 * ((size_t)b * N + k);
+        float *xk = io.x_out + 6 * k;
         const float *xl = x_l + 6 * k;
         float rot[3] = { xl[0], xl[1], xl[2] }, trans[3] = { xl[3], xl[4], xl[5] };
         if (k > 0) {
@@ -1991,12 +2190,12 @@ _Pragma("unroll 4")
             const Mat4 U = pose_to_matrix(dW, dT);
             const Mat4 C = load_mat4(vT + 16 * k);      // = Exp(x_k): this iterate's T, computed from the same x_k by the previous launch
             matrix_to_pose(mat_mul(U, C), rot, trans);
-            xk[0] = rot[0]; xk[1] = rot[1]; xk[2] = rot[2]; xk[3] = trans[0]; xk[4] = trans[1]; xk[5] = trans[2];
         }
+        if (k > 0 || CHAIN) { xk[0] = rot[0]; xk[1] = rot[1]; xk[2] = rot[2]; xk[3] = trans[0]; xk[4] = trans[1]; xk[5] = trans[2]; }      // (in place: frame 0 keeps its x)
         const Mat4 E = pose_to_matrix(rot, trans);
-        store_mat4(T + 16 * ((size_t)b * N + k), E);
-        if (poses_out) store_mat4(poses_out + 16 * ((size_t)b * N + k), E);      // last iterate: convertPosesToMatricesCU (SBA.cpp:115), no separate copy
-        store_mat4(Tinv + 16 * ((size_t)b * N + k), mat_inverse(E));
+        store_mat4(io.T_out + 16 * k, E);
+        if (io.poses_out) store_mat4(io.poses_out + 16 * k, E);      // last iterate: convertPosesToMatricesCU (SBA.cpp:115), no separate copy
+        store_mat4(io.Tinv_out + 16 * k, mat_inverse(E));
         if (tr) {
             for (int q = 0; q < 3; q++) { tr[D.tr_x + 6 * k + q] = rot[q]; tr[D.tr_x + 6 * k + 3 + q] = trans[q]; }
             for (int q = 0; q < 16; q++) tr[D.tr_T + 16 * k + q] = E.m[q];
@@ -2005,6 +2204,234 @@ _Pragma("unroll 4")
     }
     BTBA_STAMP(4);
 #undef BTBA_STAMP
+}
+
+// grid (B) x 1 024: one workgroup per instance, x / T / T^-1 updated in place.
+template <bool LDS_PAIRS, bool A_GLOBAL = false>
+__global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int iter,
+                                                        float *sparse_partials, float *dense_partials,
+                                                        const int2 *__restrict__ dense_pairs, const int *__restrict__ adj_off, const int *__restrict__ adj,
+                                                        float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv,
+                                                        float *__restrict__ pairsum_global, float *__restrict__ trace, float *__restrict__ A_scratch = nullptr,
+                                                        float *__restrict__ poses_out = nullptr, const int *__restrict__ solve_tab = nullptr)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const size_t b = blockIdx.x;
+    const int N = D.n_frames, n = 6 * N, ld = 4 * (((n + 3) / 4) | 1);
+    SolveIO io;
+    io.sparse_partials = sparse_partials + b * D.sp_stride; io.dense_partials = dense_partials + b * D.dp_stride;
+    io.x_in = io.x_out = x + b * D.x_stride;
+    io.T_in = io.T_out = T + b * D.pose_stride; io.Tinv_out = Tinv + b * D.pose_stride;
+    io.poses_out = poses_out ? poses_out + 16 * b * N : nullptr;
+    io.pairsum_global = pairsum_global ? pairsum_global + b * ((size_t)D.n_pairs * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals) : nullptr;
+    io.A_scratch = A_scratch ? A_scratch + b * (size_t)(n + 2) * ld : nullptr;
+    io.trace = trace ? trace + b * (size_t)D.n_gn * D.trace_record : nullptr;
+    io.stamps = nullptr;
+    system_solve_body<LDS_PAIRS, A_GLOBAL, false>(D, iter, (int)threadIdx.x, (int)blockDim.x, lds, io, dense_pairs, adj_off, adj, solve_tab);
+}
+
+
+// ---- the chained launch: ALL Gauss-Newton iterations of a batch in ONE launch --------------------------------------------------------------
+// The plain schedule is 2 launches per iteration: the fused sweeps (every compute unit busy, then 12-15 % of the launch draining at falling
+// occupancy), then k_system_solve (one workgroup per instance: 32 of 256 compute units for ~18 us, VALU busy 0.04) -- seven times per solve, the
+// reference's serial tail (PCGInit / PCGStep*, SolverBundling.cu:575-818, 931-1003) in miniature.  Instances are independent, so nothing
+// forces instance b's iteration i + 1 to wait for instance c's iteration i.  k_chain puts the work items of all iterations into one grid:
+//
+//   per XCD x (blocks g = 8 s + x, s = position in the XCD's sequence; the dispatcher places block g on XCD g % 8 and starts an XCD's blocks
+//   in order -- observed, used for speed and for forward progress, never for the values computed) and per iteration, for each instance the XCD
+//   owns:  [its dense items, heaviest pairs first] [its sparse items] [ONE solve item]
+//
+//   sweep item (iteration i, instance b): waits until flags[b] >= i (iterate i of b is published: one relaxed agent-scope load per wave, long
+//       true in the steady state), does exactly what its k_fused_sweeps workgroup does -- same partial record, bit for bit -- stores the record
+//       write-through, drains its stores and adds 1 to arrivals[i][b].
+//   solve item (i, b): waits until arrivals[i][b] counts all of b's sweep items, takes an agent-scope acquire, runs system_solve_body<CHAIN>
+//       (k_system_solve's sums in k_system_solve's order on 256 threads) from ring slot i into ring slot i + 1, releases at agent scope and
+//       sets flags[b] = i + 1.
+//
+// While instance b is being solved, the compute unit's other five workgroup slots -- and the rest of the chip -- run the sweep items of the
+// XCD's other instances; b's next items come up in the sequence (inst_per_xcd - 1) instances later.  No launch boundary, no drain, no idle
+// 224 compute units, except once at the very end.
+// Forward progress: an item only ever waits for items EARLIER in its own XCD's sequence (all items of an instance sit on one XCD), which are
+// resident or finished when it starts; every wait is bounded by a watchdog that raises *error and lets the launch run out (the host then
+// reports the solve as failed) -- a misbehaving dispatcher costs a wrong answer that is flagged, never a hung GPU.
+// Visibility (MI355X_MICROARCH.md, "inter-workgroup visibility"): every hand-off goes to a region of its own -- ring slot / iteration /
+// instance, padded to whole 128-byte lines -- that no workgroup touches before its producer has published it, so no cache can hold an older
+// copy of it; producers write through (sweep records: sc1 stores + vmcnt drain) or release at agent scope (solve items) before the relaxed
+// agent-scope counter / flag update; the solve item acquires at agent scope; sweep items read the poses through the scalar cache, which they
+// invalidate after the wait, and through addresses the compiler cannot move above the wait.
+constexpr int kChainMaxParts = 2;     // chunks / tiles per pair the chained solve item reduces (system_solve_body<CHAIN>)
+constexpr size_t kChainLdsBytes = 26560;   // dynamic LDS of a k_chain workgroup: with the 736 static bytes a sixth of the compute unit's 160 KB -- six workgroups per CU, as k_fused_sweeps
+// floats of region R a chained solve needs behind its tables and vectors (system_solve_body<CHAIN>): the reduced sparse pair sums, then the packed matrix
+constexpr int kChainMaxFrames = 21;       // (128 lane pairs own the rows of the matrix: 6 N - 6 <= 128; the LDS budget stops at 15 frames before that)
+__host__ __device__ inline size_t chain_region_floats(int n_frames) { const size_t P = (size_t)n_frames * (n_frames - 1) / 2, na = 6 * (size_t)n_frames - 6; return P * kSparseVals > na * (na + 1) / 2 ? P * kSparseVals : na * (na + 1) / 2; }
+struct ChainDims {
+    int n_iter;                 // Gauss-Newton iterations in this launch
+    int n_inst;                 // B
+    unsigned inst_per_xcd;      // ceil(B / 8): instance b lives on XCD b / inst_per_xcd
+    unsigned items_d, items_s;  // sweep items per (instance, iteration): dense_tiles * Pd, sparse_chunks * P
+    unsigned sparse_period;     // 0: an instance's sparse items follow its dense items; R >= 2: every R-th slot of the instance is a sparse item until they are used up
+    int *flags;                 // [B] published iterate of every instance (0 = the k_prepare output): what a waiting wave polls (L2, never a cache above it)
+    const int *published;       // [n_iter + 1][B][16]: word 0 of line (e, b) becomes 1 when iterate e of instance b is published -- one 64-byte line per word,
+                                // read through the scalar cache: a line that says 1 was fetched after the publication, a line that says 0 may be stale (-> poll flags[b])
+    int *arrivals;              // [n_iter][B]
+    int *error;                 // != 0: a wait ran into the watchdog (host-visible memory)
+    long long timeout_ticks;    // 100 MHz ticks (wall_clock64)
+    size_t pose_ring, x_ring;   // floats between two ring slots of T / T^-1, of x
+    size_t sp_ring, dp_ring;    // floats between two iterations' sweep partials
+    size_t ps_size, A_size;     // floats per (iteration, instance) of the reduced-pair-sum scratch and of the matrix scratch
+    unsigned long long *trace;  // developer: per block (start, end of wait, end, kind | it << 8 | b << 16 | hardware id << 32) in 100 MHz ticks, or nullptr
+    unsigned long long *stamps; // developer: [n_iter][B][8] phase stamps of the solve items (behind the block records), or nullptr
+    int solve_prio;             // s_setprio of a solve item's waves (0 = the default priority of every wave)
+    int last_solve_external;    // 1: the solve items of the LAST iteration do nothing -- the host launches k_system_solve for it (16 waves per instance on an
+                                // idle chip: ~18 us, against the ~90 us a 4-wave solve item on a busy compute unit would leave exposed at the end of the launch)
+    int debug_skip;             // developer TIMING experiments (wrong results by construction): 1 sweep items do not wait, 2 sweep items do not arrive, 4 solve items do not wait, 8 solve items do nothing, 64 solve items do not publish (tests/test_gpu_chain.py: the watchdog)
+};
+
+// one wave waits until *word >= want: lane 0 polls with relaxed agent-scope loads (served by L2, never by this CU's L1), sleeping in between
+__device__ __forceinline__ void chain_wait_ge(const int *word, int want, const ChainDims &Cn)
+{
+    const bool lane0 = (item_tid() & 63u) == 0u;
+    auto poll = [&]() {
+        int v = 0;
+        if (lane0) v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    if (poll() >= want) return;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(16);
+        if (poll() >= want) return;
+        if (wall_clock64() - t0 > Cn.timeout_ticks) {
+            if (lane0) __hip_atomic_store(Cn.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+    }
+}
+
+template <int LAYOUT>   // 1: pinhole compact cache, 8 x 8 block walk or strips; 3: the same walking the frames' valid-pixel lists
+__global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_chain(SolveDims D, ChainDims Cn, const float4 *__restrict__ zn,
+                                                    float *T, float *Tinv, float *x, float *dense_partials,
+                                                    const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets, float *sparse_partials,
+                                                    const uint32_t *__restrict__ valid_lists, const int *__restrict__ valid_counts,
+                                                    const int2 *__restrict__ dense_pairs, const int *__restrict__ adj_off, const int *__restrict__ adj,
+                                                    const int *__restrict__ solve_tab, float *pairsum_global, float *A_scratch, float *poses_out)
+{
+    __shared__ float red[kRedFloats];
+    extern __shared__ __attribute__((aligned(16))) float dyn_lds[];       // a sweep item's look-up tables, or a solve item's vectors and tables
+    const unsigned g = blockIdx.x, xcd = g & 7u, sg = g >> 3;
+    const unsigned n_sweep = Cn.items_d + Cn.items_s, slots_per_inst = n_sweep + 1u, per_iter = Cn.inst_per_xcd * slots_per_inst;
+    const unsigned it = sg / per_iter, s = sg - it * per_iter;
+    const unsigned k = s / slots_per_inst, r = s - k * slots_per_inst;
+    const int b = (int)(xcd * Cn.inst_per_xcd + k);
+    if (b >= Cn.n_inst) return;
+    const unsigned tid = item_tid();
+    const unsigned long long t_start = Cn.trace ? (unsigned long long)wall_clock64() : 0ull;
+    unsigned long long t_wait = t_start;
+    int kind;
+    if (r < n_sweep) {
+        // ---- sweep item
+        bool is_sparse;
+        unsigned idx;                                           // index among the instance's sparse / dense items
+        if (Cn.sparse_period >= 2u) {
+            const unsigned q = r / Cn.sparse_period, m = r - q * Cn.sparse_period;
+            is_sparse = (m == Cn.sparse_period - 1u) && (q < Cn.items_s);
+            idx = is_sparse ? q : r - min(q, Cn.items_s);
+        } else {
+            is_sparse = r >= Cn.items_d;
+            idx = is_sparse ? r - Cn.items_d : r;
+        }
+        const float *T_it = T + (size_t)it * Cn.pose_ring, *Tinv_it = Tinv + (size_t)it * Cn.pose_ring;
+        if (it > 0u) {
+            // Is iterate `it` of instance b published?  Fast path: its `published` line through the scalar cache (a hit costs ~100 cycles; in the
+            // steady state the solve item finished tens of microseconds ago).  The line is this (iterate, instance)'s alone and is only ever
+            // fetched by this instance's items of this iteration, so a cached 1 cannot be older than the publication; a 0 may be, and is not
+            // trusted: the wave then polls flags[b] in L2.  The poses are read through the scalar cache as well, each 64-byte matrix a line
+            // that nobody fetches before this point -- nothing to invalidate -- and through addresses the compiler sees only AFTER the wait, so
+            // that no load of a pose can be issued before the publication has been seen (constant-address-space loads may otherwise be hoisted).
+            const int seen = (Cn.debug_skip & 1) ? 1 : *as_const(Cn.published + ((size_t)it * Cn.n_inst + b) * 16);
+            if (seen == 0) chain_wait_ge(Cn.flags + b, (int)it, Cn);
+        }
+        asm volatile("" : "+s"(T_it), "+s"(Tinv_it) :: "memory");
+        if (Cn.trace) t_wait = (unsigned long long)wall_clock64();
+        kind = is_sparse ? 1 : 0;
+        if (is_sparse) {
+            const int chunk = (int)(idx % (unsigned)D.sparse_chunks), p = (int)(idx / (unsigned)D.sparse_chunks);
+            sparse_block(D, corr, pair_offsets, T_it, sparse_partials + (size_t)it * Cn.sp_ring, chunk, p, b, red);
+        } else {
+            const int tile = D.tile_major ? (int)(idx / (unsigned)D.n_dense_pairs) : (int)(idx % (unsigned)D.dense_tiles);
+            const int p = D.tile_major ? (int)(idx % (unsigned)D.n_dense_pairs) : (int)(idx / (unsigned)D.dense_tiles);      // a WORK POSITION (dense_work_item)
+            float *dp_it = dense_partials + (size_t)it * Cn.dp_ring;
+            if (LAYOUT == 1 && D.walk_blocks) dense_block_pinhole<2>(D, zn, p, T_it, Tinv_it, dp_it, tile, b, red, valid_lists, valid_counts, dyn_lds);
+            else if (LAYOUT == 1) dense_block_pinhole<0>(D, zn, p, T_it, Tinv_it, dp_it, tile, b, red, valid_lists, valid_counts, dyn_lds);
+            else dense_block_pinhole<1>(D, zn, p, T_it, Tinv_it, dp_it, tile, b, red, valid_lists, valid_counts, dyn_lds);
+        }
+        // the record was stored write-through by lanes of wave 0: once those stores have been acknowledged, count this item in
+        if (tid < 64u && !(Cn.debug_skip & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0u) __hip_atomic_fetch_add(Cn.arrivals + (size_t)it * Cn.n_inst + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        // ---- solve item: iterate `it` -> iterate `it + 1` of instance b
+        kind = 2;
+        if ((Cn.debug_skip & 8) || (Cn.last_solve_external && (int)it == Cn.n_iter - 1)) return;
+        if (tid < 64u && !(Cn.debug_skip & 4)) {
+            chain_wait_ge(Cn.arrivals + (size_t)it * Cn.n_inst + b, (int)n_sweep, Cn);
+            if (tid == 0u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (Cn.trace) t_wait = (unsigned long long)wall_clock64();
+        const int N = D.n_frames;
+        const size_t ib = (size_t)it * Cn.n_inst + b;
+        SolveIO io;
+        io.sparse_partials = sparse_partials + (size_t)it * Cn.sp_ring + (size_t)b * D.sp_stride;
+        io.dense_partials = dense_partials + (size_t)it * Cn.dp_ring + (size_t)b * D.dp_stride;
+        io.x_in = x + (size_t)it * Cn.x_ring + (size_t)b * D.x_stride; io.x_out = x + (size_t)(it + 1u) * Cn.x_ring + (size_t)b * D.x_stride;
+        io.T_in = T + (size_t)it * Cn.pose_ring + (size_t)b * D.pose_stride;
+        io.T_out = T + (size_t)(it + 1u) * Cn.pose_ring + (size_t)b * D.pose_stride;
+        io.Tinv_out = Tinv + (size_t)(it + 1u) * Cn.pose_ring + (size_t)b * D.pose_stride;
+        io.poses_out = ((int)it == Cn.n_iter - 1) ? poses_out + 16 * (size_t)b * N : nullptr;
+        io.pairsum_global = pairsum_global + ib * Cn.ps_size;
+        io.A_scratch = A_scratch + ib * Cn.A_size;
+        io.trace = nullptr;
+        io.stamps = Cn.stamps ? Cn.stamps + 8 * ib : nullptr;
+        // a solve item is a chain of short dependent phases on ONE workgroup that shares its compute unit with five sweep workgroups: every
+        // instruction of it otherwise queues behind theirs; its instances' next items wait for it, theirs for nothing
+        if (Cn.solve_prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (Cn.solve_prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (Cn.solve_prio == 3) __builtin_amdgcn_s_setprio(3);
+        system_solve_body<false, false, true>(D, (int)it, (int)tid, kBlock, dyn_lds, io, dense_pairs, adj_off, adj, solve_tab);
+        __syncthreads();
+        if (tid == 0u && !(Cn.debug_skip & 64)) {           // (64: the watchdog's test -- an iterate that is never published)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the compiler may drop the wait behind the write-back: MI355X_MICROARCH.md, compiler hazard)
+            __hip_atomic_store(Cn.flags + b, (int)it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(const_cast<int *>(Cn.published) + ((size_t)(it + 1u) * Cn.n_inst + b) * 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (Cn.trace && tid == 0u) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n s_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        unsigned long long *q = Cn.trace + 4 * (size_t)g;
+        q[0] = t_start; q[1] = t_wait; q[2] = (unsigned long long)wall_clock64();
+        q[3] = (unsigned long long)kind | ((unsigned long long)it << 8) | ((unsigned long long)b << 16) | ((unsigned long long)(hw & 0xFFFFu) << 32) | ((unsigned long long)(xcc & 0xFu) << 48);
+    }
+}
+
+// Log / Exp / inverse of the incoming matrices into ring slot 0 of the chained launch (k_prepare with padded instance strides)
+__global__ void __launch_bounds__(64) k_prepare_strided(int total, int n_frames, int pose_stride, int x_stride, const float *__restrict__ poses,
+                                                        float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int b = idx / n_frames, f = idx - b * n_frames;
+    const Mat4 M = load_mat4(poses + 16 * (size_t)idx);
+    float rot[3], trans[3];
+    matrix_to_pose(M, rot, trans);
+    float *o = x + (size_t)b * x_stride + 6 * f;
+    o[0] = rot[0]; o[1] = rot[1]; o[2] = rot[2]; o[3] = trans[0]; o[4] = trans[1]; o[5] = trans[2];
+    const Mat4 E = pose_to_matrix(rot, trans);
+    store_mat4(T + (size_t)b * pose_stride + 16 * f, E);
+    store_mat4(Tinv + (size_t)b * pose_stride + 16 * f, mat_inverse(E));
 }
 
 }  // namespace btba

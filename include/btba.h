@@ -22,7 +22,9 @@
 extern "C" {
 #endif
 
-#define BTBA_VERSION 103     /* 103: btba_params.reduction_mode, BTBA_FLAG_KEYED_CORR = 4096, btba_workspace_set_option, btba_zn_aux.corr24 + btba_pack_correspondences24 */
+#define BTBA_VERSION 104     /* 104: chained launch (BTBA_OPT_CHAIN*, BTBA_ESCHED, btba_stats.chain_iterations); 103: btba_params.reduction_mode, BTBA_FLAG_KEYED_CORR = 4096,
+                                btba_workspace_set_option, btba_zn_aux.corr24 + btba_pack_correspondences24.  A caller built against another version's structs must not
+                                call in: check btba_version() == BTBA_VERSION once after loading the library (the Python and C++ host layers do). */
 
 #if defined(__GNUC__)
 #define BTBA_API __attribute__((visibility("default")))
@@ -36,7 +38,10 @@ enum {
     BTBA_EINVAL   = 1,   /* bad argument (n_frames < 2, null pointer, unsorted batch correspondences, ...) */
     BTBA_EHIP     = 2,   /* a HIP runtime call failed; btba_last_hip_error() has the hipError_t */
     BTBA_ENUMERIC = 3,   /* a non-finite value reached the output poses */
-    BTBA_ENOMEM   = 4
+    BTBA_ENOMEM   = 4,
+    BTBA_ESCHED   = 5    /* a wait inside the chained launch ran into its watchdog (the device did not start the launch's workgroups in grid
+                            order): the poses of that solve are invalid.  Reported by the next call that synchronises with the host
+                            (btba_workspace_sync, btba_collect_stats); the workspace solves with the plain schedule from then on. */
 };
 
 /* ---- wire formats ---------------------------------------------------------------------- */
@@ -144,6 +149,8 @@ typedef struct btba_stats {
     int32_t fused_sweeps;         /* 1: sparse + dense sweeps ran as ONE launch (timed as ms_dense_sweep) */
     int32_t cache_frames_built;   /* optimize_frames: frames cached in this call (n_frames unless keyed and already cached) */
     int32_t corr_pairs_uploaded;  /* optimize_frames: frame-pair segments that crossed PCIe in this call (all P unless BTBA_FLAG_KEYED_CORR) */
+    int32_t chain_iterations;     /* > 0: the solve ran as ONE chained launch carrying this many Gauss-Newton iterations (sweeps AND system solves);
+                                     it is timed as ms_dense_sweep / n_dense_launches, ms_system_solve stays 0 */
 } btba_stats;
 
 /* Per-instance, per-GN-iteration trace record (floats), written when BTBA_FLAG_TRACE is set.
@@ -195,7 +202,14 @@ enum {
     BTBA_OPT_OVERLAP_GROUPS       = 6,  /* instance groups of BTBA_FLAG_OVERLAP, 1 .. 8 (default 2).                            env BTBA_GROUPS         */
     BTBA_OPT_OVERLAP_EQUAL_PRIO   = 7,  /* 1: the groups' streams get equal priority (default 0: lowest for groups >= 1).        env BTBA_GROUP_PRIO=e   */
     BTBA_OPT_SPARSE_TAIL          = 9,  /* 0 .. 256: share (x / 256) of the sparse items that close the fused sweep instead of being interleaved (fills the launch's drain); -1 (default): 256 on full frames, 0 on object-masked ones. env BTBA_SPARSE_TAIL */
-    BTBA_OPT_KEYED_CORR_MIN_BYTES = 8   /* BTBA_FLAG_KEYED_CORR is ignored below this many bytes of correspondences (default 1 MiB). env of the same name */
+    BTBA_OPT_KEYED_CORR_MIN_BYTES = 8,  /* BTBA_FLAG_KEYED_CORR is ignored below this many bytes of correspondences (default 1 MiB). env of the same name */
+    BTBA_OPT_CHAIN                = 10, /* the chained launch: ALL Gauss-Newton iterations of a batch in one launch, every instance's system solve handed
+                                           over inside the launch while the other instances' sweeps run (btba_kernels.hpp: k_chain).  -1 (default): batches
+                                           of >= 16 instances; 0: never; 1: every batch the launch supports (pinhole compact cache, sparse + dense terms,
+                                           <= 23 frames, no trace, deterministic sums).  Same bits as the plain schedule.                  env BTBA_CHAIN */
+    BTBA_OPT_CHAIN_SPARSE_PERIOD  = 11, /* chained launch: 0 (default) an instance's sparse items follow its dense items; R >= 2: every R-th item of an
+                                           instance is a sparse one.                                                               env BTBA_CHAIN_PERIOD */
+    BTBA_OPT_CHAIN_TIMEOUT_MS     = 12  /* watchdog of the waits inside the chained launch (default 500 ms): see BTBA_ESCHED.        env BTBA_CHAIN_TIMEOUT_MS */
 };
 BTBA_API int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value);
 /* Stream ordering without a host wait, for callers whose producers / consumers run on another HIP stream (PyTorch's

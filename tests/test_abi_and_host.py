@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.btba_version() == 103
+    assert L.btba_version() == 104
 
 
 def test_struct_sizes_match_header():
@@ -150,7 +150,7 @@ def test_python_constants_match_the_header():
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "btba.h")).read()
     enums = {k: int(v) for k, v in re.findall(r"\b(BTBA_[A-Z0-9_]+)\s*=\s*(\d+)", hdr)}
     defines = {k: int(v) for k, v in re.findall(r"#define\s+(BTBA_[A-Z0-9_]+)\s+(\d+)\b", hdr)}
-    for name in ("BTBA_OK", "BTBA_EINVAL", "BTBA_EHIP", "BTBA_ENUMERIC", "BTBA_ENOMEM"):
+    for name in ("BTBA_OK", "BTBA_EINVAL", "BTBA_EHIP", "BTBA_ENUMERIC", "BTBA_ENOMEM", "BTBA_ESCHED"):
         assert enums[name] == getattr(_lib, name), name
     for name in ("TARGET_LOWER", "TARGET_MORE_VALID", "EXPLICIT"):
         assert enums["BTBA_PAIRS_" + name] == getattr(_lib, "PAIRS_" + name), name
@@ -160,10 +160,10 @@ def test_python_constants_match_the_header():
         assert getattr(_lib, "FLAG_" + name) == v, name
     assert defines["BTBA_MAX_FRAMES"] == 85 and defines["BTBA_MAX_FRAMES_LDS"] == 31     # the reference's MAX_NUM_IMAGES; the LDS-resident limit
     opts = {k[len("BTBA_OPT_"):]: v for k, v in enums.items() if k.startswith("BTBA_OPT_")}
-    assert len(opts) == 9 and all(getattr(_lib, "OPT_" + name) == v for name, v in opts.items())
+    assert len(opts) == 12 and all(getattr(_lib, "OPT_" + name) == v for name, v in opts.items())
     assert enums["BTBA_REDUCE_DETERMINISTIC"] == _lib.REDUCE_DETERMINISTIC and enums["BTBA_REDUCE_ATOMIC"] == _lib.REDUCE_ATOMIC
     assert 128 not in flags.values()                    # the bit that was BTBA_FLAG_FUSE stays without a meaning
-    assert C.sizeof(_lib.Stats) == 104
+    assert C.sizeof(_lib.Stats) == 104      # (chain_iterations took the struct's tail padding)
 
 
 def test_counter_file_matches_the_committed_pmc_summaries():
