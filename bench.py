@@ -53,25 +53,35 @@ def generate_instances(cfg, ids, masked=False):
     nproc = min(len(jobs), 8, max(1, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     nproc = int(os.environ.get("BTBA_BENCH_NPROC", nproc))      # 1 under rocprofv3 --pmc (no child processes)
     cache = os.environ.get("BTBA_BENCH_CACHE")                  # profiling passes of one workload: generate once, reuse (scripts/profile_bench.sh)
-    if cache:
-        import pickle
-        key = (cfg["K"], cfg["m"], tuple(ids), bool(masked))
+    if cache:                                                   # an .npz of plain arrays (never a pickle: np.load(allow_pickle=False))
+        key = json.dumps([cfg["K"], cfg["m"], list(ids), bool(masked)])
         if os.path.exists(cache):
-            k2, data = pickle.load(open(cache, "rb"))
-            if k2 == key:
-                return data
+            with np.load(cache, allow_pickle=False) as z:
+                if str(z["key"]) == key:
+                    fields = [f for f in ("campos", "normals", "intr", "corr", "poses", "zn", "K") if f"{f}0" in z]
+                    return [dict({f: (z[f"{f}{i}"].view(_lib_entryj()) if f == "corr" else z[f"{f}{i}"]) for f in fields}, H=int(z["H"]), W=int(z["W"])) for i in range(len(ids))]
         data = [_gen(j) for j in jobs] if nproc <= 1 else None
         if data is None:
             import multiprocessing as mp
             with mp.get_context("spawn").Pool(nproc) as pool:
                 data = pool.map(_gen, jobs)
-        pickle.dump((key, data), open(cache, "wb"))
+        arrs = {"key": np.array(key), "H": np.int32(data[0]["H"]), "W": np.int32(data[0]["W"])}
+        for i, q in enumerate(data):
+            for f in ("campos", "normals", "intr", "poses", "zn", "K"):
+                arrs[f"{f}{i}"] = np.asarray(q[f])
+            arrs[f"corr{i}"] = np.ascontiguousarray(q["corr"]).view(np.uint8)
+        np.savez(cache, **arrs)
         return data
     if nproc > 1:
         import multiprocessing as mp
         with mp.get_context("spawn").Pool(nproc) as pool:
             return pool.map(_gen, jobs)
     return [_gen(j) for j in jobs]
+
+
+def _lib_entryj():
+    from bundletrack_amd import _lib
+    return _lib.ENTRYJ_DTYPE
 
 
 def kernel_source_hash():
@@ -191,6 +201,27 @@ def cpu_baseline(cfg, insts, budget_s=24.0):
             "host_cpus": ncpu, "host_cpu_model": _cpu_model()}
 
 
+def oracle_parity(cfg, insts, picks, gpu_poses, bar=1e-4):
+    """The timed run's OUTPUT against the CPU oracle (oracle/btba_oracle.c, pinned against the reference's own solveBundlingStub: DESIGN.md
+    section 3) on a few of the instances the GPU has just solved: what was measured is also what is right.  picks: instance indices."""
+    from bundletrack_amd import synthetic as S
+    from oracle import oracle as O
+    try:
+        nt = min(len(os.sched_getaffinity(0)), 16)
+    except AttributeError:
+        nt = 1
+    prm = O.default_params(weight_dense_depth=cfg["w_dense"], n_threads=nt)
+    worst_r = worst_t = 0.0
+    for b in picks:
+        q = insts[b]
+        ref = O.solve(q["campos"], q["normals"], q["intr"], q["corr"], q["poses"], params=prm, want_trace=False)
+        for k in range(cfg["K"]):
+            r, t = S.pose_error(gpu_poses[b, k], ref.poses[k])
+            worst_r, worst_t = max(worst_r, r), max(worst_t, t)
+    return {"instances": len(picks), "which": list(picks), "worst_rot": float(f"{worst_r:.3e}"), "worst_trans": float(f"{worst_t:.3e}"), "bar": bar,
+            "ok": bool(worst_r < bar and worst_t < bar), "against": "CPU oracle (oracle/btba_oracle.c) on the same inputs, final poses after 7 GN x 5 PCG"}
+
+
 def measured_copy_bandwidth(torch, dev, nbytes=1 << 30, reps=10):
     """Device-to-device copy bandwidth of this box (read + write bytes / time), SURVEY.md 8(d): fractions are quoted
     against the nominal 8 TB/s AND against what the part actually streams."""
@@ -250,6 +281,7 @@ def main():
     ap.add_argument("--same-instances", action="store_true", help="every rank solves the SAME instances (global ids 0 ..): the per-rank pose checksums must then agree -- a consistency check of the sharded run, not a benchmark")
     ap.add_argument("--entryj", action="store_true", help="keep the device-resident correspondences as 32-byte EntryJ instead of packing them to 24-byte records before the timed region")
     ap.add_argument("--corr24", action="store_true", help="24-byte records also with --masked (default there: EntryJ, which measured 4 %% faster on the masked launch: profiles/r03)")
+    ap.add_argument("--baseline-n1", type=float, default=None, help="the N = 1 value of the same command: rank 0 then also reports efficiency = value / (N x this)")
     args = ap.parse_args()
 
     # --gpus N without a launcher: become the launcher (one rank per GPU under torch.distributed.run, RCCL via backend nccl)
@@ -267,6 +299,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     local_dev = local % torch.cuda.device_count()        # == local on a real node; lets a functional test run 2 ranks on 1 GPU
     torch.cuda.set_device(local_dev)
+    cpu_binding = sharding.bind_rank_to_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), local_dev) if world > 1 else {"bound": False, "why": "single rank"}
     dev = torch.device(f"cuda:{local_dev}")
     cfg = CONFIGS[args.config]
     B, K = args.instances, cfg["K"]
@@ -339,12 +372,45 @@ def main():
     st = ws.collect_stats()
     out_poses = poses_d.cpu().numpy()
     assert np.isfinite(out_poses).all(), "non-finite poses"
+    # What a tracker pays: its correspondences are NEW on every call, so the 24-byte re-layout is part of every solve.  Same steps again with
+    # the pack (btba_pack_correspondences24 on the EntryJ array already in HBM) inside the timed region.
+    seconds_incl_pack = None
+    if use_c24:
+        def step_incl_pack():                               # (same flags as the first region: its hipEvent brackets are part of both)
+            bs.pack_correspondences24(corr_d, offs_d, mx, K, out=aux_d["corr24"])
+            step()
+        for _ in range(2):
+            step_incl_pack()
+        torch.cuda.synchronize()
+        sharding.barrier(dev)
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            step_incl_pack()
+        torch.cuda.synchronize()
+        sharding.barrier(dev)
+        seconds_incl_pack = time.perf_counter() - ta
+        if not args.no_kernel_timing:
+            ws.collect_stats()                              # (the kernel times reported below are the first region's: `st`)
+        note(f"pack-inclusive region done: {seconds_incl_pack:.3f} s")
+    # work the dense sweep actually executes: 8 x 8 blocks walked (the hull test removes the provably dead ones), one counted solve
+    live_blocks_per_solve = None
+    if not args.float4_cache and not args.masked and cfg["w_dense"] > 0:
+        ws.set_option(_lib.OPT_COUNT_LIVE, 1)
+        step()
+        live_blocks_per_solve = ws.live_blocks()
+        ws.set_option(_lib.OPT_COUNT_LIVE, 0)
+        ws.collect_stats()
 
     gn_iters = float(B * bs.params.n_gn_iters * args.steps)
     backend = sharding.backend_name()                   # None: single process without a process group
     gather_dev = dev if backend == "nccl" else "cpu"
     per_rank = sharding.gather_throughput(seconds, gn_iters, device=gather_dev, checksum=float(np.abs(out_poses.astype(np.float64)).sum()))
     value, slowest = sharding.aggregate(per_rank)
+    checksums = list(sharding.gather_throughput.checksums)
+    value_incl_pack = None
+    if seconds_incl_pack is not None:
+        pr2 = sharding.gather_throughput(seconds_incl_pack, gn_iters, device=gather_dev)
+        value_incl_pack, _ = sharding.aggregate(pr2)
 
     if rank == 0:
         npix = int(cam_d.shape[2] * cam_d.shape[3])
@@ -358,11 +424,19 @@ def main():
                        "keyframes": K, "corr_per_pair": cfg["m"], "instances_per_gpu": B, "distinct_instances_per_gpu": n_distinct,
                        "gn_iters": int(bs.params.n_gn_iters), "pcg_iters": int(bs.params.n_pcg_iters),
                        "dense_tiles": st["dense_tiles"], "sparse_chunks": st["sparse_chunks"], "frame_cache": "float4 camPos + float4 normal (32 B/px)" if args.float4_cache else "compact z + normal (16 B/px)",
-                       "correspondences": "24-byte records (pos_i, pos_j), packed once from EntryJ before the timed region" if use_c24 else "EntryJ (32 B)", "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
-            "per_rank": [{"seconds": round(s, 6), "gn_iters": g, "pose_checksum": round(c, 6)} for (s, g), c in zip(per_rank, sharding.gather_throughput.checksums)],
+                       "correspondences": ("`value`: 24-byte records (pos_i, pos_j) resident in HBM, packed from EntryJ BEFORE the timed region; `value_incl_pack`: the same steps with the "
+                                           "pack (btba_pack_correspondences24) inside the timed region -- what a tracker with fresh matches on every call pays") if use_c24 else "EntryJ (32 B)",
+                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+            "value_incl_pack": round(value_incl_pack, 1) if value_incl_pack else None,
+            "ms_per_step_incl_pack": round(1e3 * seconds_incl_pack / args.steps, 4) if seconds_incl_pack else None,
+            "per_rank": [{"seconds": round(s, 6), "gn_iters": g, "ms_per_step": round(1e3 * s / args.steps, 4), "pose_checksum": round(c, 6)} for (s, g), c in zip(per_rank, checksums)],
+            "rank_spread": {"ms_per_step_min": round(1e3 * min(s for s, _ in per_rank) / args.steps, 4), "ms_per_step_max": round(1e3 * max(s for s, _ in per_rank) / args.steps, 4)},
             "collective": {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
                            "what": "one all-gather of {seconds, GN iterations, pose checksum} per rank after the timed region; no data-path collective"},
+            "cpu_binding_rank0": cpu_binding,
         }
+        if args.baseline_n1:
+            res["efficiency_vs_n1"] = {"value": round(value / (world * args.baseline_n1), 4), "formula": "value / (n_gpus x the N = 1 value passed with --baseline-n1)", "n1_value": args.baseline_n1}
         if not args.no_kernel_timing and st["n_dense_launches"] > 0:
             # Dominant kernel = the Jacobian sweep (fused: dense + sparse workgroups in one launch).  It is bound by VALU issue, not by
             # HBM (PMC: the vector pipe is ~87 % busy, HBM at ~0.2 of peak), so the roofline is the fp32 vector peak -- 157.3 TFLOP/s on
@@ -375,6 +449,7 @@ def main():
             # but the last): per launch it does `chained` times the algorithmic work of a fused sweep launch
             chained = int(st.get("chain_iterations", 0))
             sweeps_per_launch = chained if chained else 1
+            n_it_count = int(bs.params.n_gn_iters)
             depth = np.stack([p["zn"][..., 0] for p in pick]) if not args.float4_cache else np.stack([p["campos"][..., 2] for p in pick])
             nvalid = (depth >= 0.1).reshape(B, K, -1).sum(-1)                        # valid source pixels per frame
             pair_pixels = int((nvalid * np.arange(K)[None, :]).sum())                # frame j is the source of its j pairs (i < j)
@@ -389,14 +464,17 @@ def main():
                 # the pixels -- it is bound by that stream, not by the vector pipe.  Algorithmic bytes (SURVEY.md 8(d)'s 32 B per
                 # correspondence; every valid cached pixel once, 16 B) over the launch time against the HBM peak; the 24-byte device
                 # records do the same algorithmic work on 3/4 of the correspondence bytes, `layout_bytes_per_launch` is what they move.
-                alg = 32 * n_corr + 16 * int(nvalid.sum())
-                gbs = alg / (avg_ms * 1e-3) / 1e9
+                alg = sweeps_per_launch * (32 * n_corr + 16 * int(nvalid.sum()))
+                lay = sweeps_per_launch * (corr_bytes * n_corr + 16 * int(nvalid.sum()))      # what the device layout moves: `achieved` / `frac` never exceed the bandwidth actually sustained
+                gbs = lay / (avg_ms * 1e-3) / 1e9
                 res["roofline"] = {"bound": "hbm", "kernel": "k_fused_sweeps (dense + sparse workgroups)" if fused else "k_dense_sweep",
                                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                                   "algorithmic_bytes_per_launch": alg, "layout_bytes_per_launch": corr_bytes * n_corr + 16 * int(nvalid.sum()),
+                                   "layout_bytes_per_launch": lay, "algorithmic_bytes_per_launch": alg,
+                                   "algorithmic_32B_GBps": round(alg / (avg_ms * 1e-3) / 1e9, 1),
                                    "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_dense_launches"],
                                    "valu_context": {"achieved_TFLOPs": round(tflops, 2), "frac_of_vector_peak": round(tflops / VALU_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": flops_alg},
-                                   "note": "HBM roofline: (32 B x correspondences + 16 B x valid cached pixels) / launch time against 8 TB/s; durations from hipEvents on the workspace stream inside the timed region"}
+                                   "note": "HBM roofline: (bytes per correspondence of the device layout x correspondences + 16 B x valid cached pixels) / launch time against 8 TB/s; "
+                                           "algorithmic_32B_GBps is the same with SURVEY.md 8(d)'s 32 B per correspondence; durations from hipEvents on the workspace stream inside the timed region"}
             else:
                 res["roofline"] = {"bound": "valu", "kernel": (f"k_chain (ONE launch per solve: the dense + sparse sweep items of all {chained} Gauss-Newton iterations and {chained - 1} in-launch system solves)" if chained
                                                               else "k_fused_sweeps (dense + sparse workgroups)" if fused else "k_dense_sweep"),
@@ -405,6 +483,15 @@ def main():
                                    "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_dense_launches"],
                                    "note": "fp32 vector (VALU) roofline: algorithmic flops / launch time against 157.3 TFLOP/s (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz = the "
                                            "dense f32 MFMA peak); durations from hipEvents on the workspace stream inside the timed region"}
+            if not args.masked and live_blocks_per_solve:
+                # the contract number above charges 200 flop to every (frame pair, valid source pixel) of SURVEY.md 8(d); the kernel proves about
+                # half of the 8 x 8 blocks dead before it walks them (hull test, exact: tests/test_gpu_fullsize.py::test_dead_block_skip_is_exact)
+                # and never evaluates their pixels.  On the work it EXECUTES: walked blocks x 64 pixels x 200 + correspondences x 120.
+                live_px = 64.0 * live_blocks_per_solve / n_it_count * sweeps_per_launch
+                flops_exec = 200.0 * live_px + sweeps_per_launch * (120.0 * n_corr if fused else 0.0)
+                res["roofline"]["executed"] = {"frac": round(flops_exec / (avg_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4), "achieved": round(flops_exec / (avg_ms * 1e-3) / 1e12, 2),
+                                               "walked_pair_pixels_per_launch": int(live_px), "share_of_pair_pixels_walked": round(live_px / (sweeps_per_launch * pair_pixels), 4),
+                                               "what": "flops of the blocks the dense sweep walks (counted by the kernel: BTBA_OPT_COUNT_LIVE, one solve) + the sparse items', over the same launch time and peak"}
             if pc and pc.get("valu_busy_frac") is not None:
                 res["roofline"]["valu_issue"] = {"busy_frac": pc["valu_busy_frac"], "cycles_per_instruction": pc.get("valu_cycles_per_inst"),
                                                  "dual_issued_frac": pc.get("valu_dual_issued_frac"), "waves_per_simd": pc.get("waves_per_simd"),
@@ -438,10 +525,11 @@ def main():
                 "sparse_alg_GBps": (round(32 * n_corr / max(st["ms_sparse_sweep"] / max(st["n_sparse_launches"], 1), 1e-9) / 1e6, 1) if st["n_sparse_launches"] else None)}
         elif cfg["w_dense"] == 0.0 and not args.no_kernel_timing and st["n_sparse_launches"] > 0:
             avg_ms = st["ms_sparse_sweep"] / st["n_sparse_launches"]
-            achieved = 32 * n_corr / (avg_ms * 1e-3) / 1e9       # 32 B per correspondence (the 24-byte device records move 3/4 of that)
+            achieved = (24 if use_c24 else 32) * n_corr / (avg_ms * 1e-3) / 1e9       # the bytes the device layout moves (SURVEY.md 8(d)'s 32 B per correspondence: algorithmic_32B_GBps)
             pc = profiled_counters(args.config, B, args.masked, args.float4_cache, False, n_distinct, not use_c24)
             res["roofline"] = {"bound": "hbm", "kernel": "k_sparse_sweep", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pc.get("hbm_bytes_per_launch") if pc else None, "algorithmic_bytes_per_launch": 32 * n_corr,
+                               "algorithmic_32B_GBps": round(32 * n_corr / (avg_ms * 1e-3) / 1e9, 1),
                                "layout_bytes_per_launch": (24 if use_c24 else 32) * n_corr,
                                "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_sparse_launches"]}
         if args.latency:
@@ -473,7 +561,19 @@ def main():
             note("CPU baseline (oracle on the host cores)")
             res["cpu_baseline"] = cpu_baseline(cfg, inst)
             note("CPU baseline done")
+        parity_ok = True
+        if not args.no_cpu_baseline:
+            picks = sorted({0, n_distinct // 3, (2 * n_distinct) // 3, n_distinct - 1})       # instance b of the batch is inst[b % n_distinct]
+            res["parity"] = oracle_parity(cfg, inst, picks, out_poses.reshape(B, K, 4, 4))
+            parity_ok = res["parity"]["ok"]
+            note(f"parity of the timed output against the oracle: {res['parity']['worst_rot']:.2e} rad / {res['parity']['worst_trans']:.2e} m on instances {picks}")
         print(json.dumps(res), flush=True)
+        if not parity_ok:
+            print("bench.py: the timed run's poses differ from the oracle's by more than the bar", file=sys.stderr)
+            if backend is not None:
+                import torch.distributed as dist
+                dist.destroy_process_group()
+            raise SystemExit(3)
     if backend is not None:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -25,7 +25,7 @@ RANSAC_DRAW_HASH = 0x100      # ORed into `hypothesis`: counter-hash sample trip
 FLAG_TRACE, FLAG_TIME_KERNELS = 1, 2
 FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_KEYED_CORR, FLAG_FLOAT4_CACHE, FLAG_NO_COMPACTION, FLAG_COMPACTION, FLAG_TIME_SAMPLED = 32, 64, 4096, 256, 512, 1024, 2048
 OPT_DENSE_ORDER, OPT_TILE_MAJOR, OPT_BLOCK_WALK, OPT_BLOCK_SKIP, OPT_BIG_ASSEMBLY, OPT_OVERLAP_GROUPS, OPT_OVERLAP_EQUAL_PRIO, OPT_KEYED_CORR_MIN_BYTES, OPT_SPARSE_TAIL = 1, 2, 3, 4, 5, 6, 7, 8, 9
-OPT_CHAIN, OPT_CHAIN_SPARSE_PERIOD, OPT_CHAIN_TIMEOUT_MS = 10, 11, 12
+OPT_CHAIN, OPT_CHAIN_SPARSE_PERIOD, OPT_CHAIN_TIMEOUT_MS, OPT_COUNT_LIVE = 10, 11, 12, 13
 
 ENTRYJ_DTYPE = np.dtype(
     [("imgIdx_i", "<u4"), ("imgIdx_j", "<u4"), ("pos_i", "<f4", (3,)), ("pos_j", "<f4", (3,))]
@@ -34,7 +34,7 @@ ENTRYJ_DTYPE = np.dtype(
 EXPORTED_SYMBOLS = [
     "btba_params_default", "btba_strerror", "btba_last_hip_error", "btba_version",
     "btba_workspace_create", "btba_workspace_create_on_stream", "btba_workspace_destroy", "btba_workspace_sync",
-    "btba_workspace_wait_stream", "btba_workspace_signal_stream", "btba_workspace_set_option",
+    "btba_workspace_wait_stream", "btba_workspace_signal_stream", "btba_workspace_set_option", "btba_workspace_live_blocks",
     "btba_optimize_frames", "btba_optimize_frames_keyed", "btba_frame_cache_clear", "btba_frame_cache_evict", "btba_ransac_pairs", "btba_ransac_pairs_ex", "btba_ransac_reference_uniforms", "btba_build_cache", "btba_solve_batch", "btba_solve_cached", "btba_collect_stats",
     "btba_trace_layout_get", "btba_bucket_correspondences",
     "btba_matrices_to_poses", "btba_poses_to_matrices",
@@ -50,6 +50,7 @@ class Params(C.Structure):
         ("depth_min", C.c_float), ("depth_max", C.c_float),
         ("weight_sparse", C.c_float), ("weight_dense_depth", C.c_float), ("image_downscale", C.c_float),
         ("pair_policy", C.c_int32), ("dense_tiles", C.c_int32), ("sparse_chunks", C.c_int32), ("flags", C.c_int32), ("reduction_mode", C.c_int32),
+        ("weights_sparse_per_iter", C.c_void_p), ("weights_dense_per_iter", C.c_void_p),      # host float[n_gn_iters] or NULL (the scalars)
     ]
 
 
@@ -153,7 +154,7 @@ def lib() -> C.CDLL:
         L.btba_strerror.restype = C.c_char_p
         L.btba_strerror.argtypes = [C.c_int]
         for name in EXPORTED_SYMBOLS:
-            if "BTBA_LIB_PATH" in os.environ and name in ("btba_workspace_set_option", "btba_pack_correspondences24") and not hasattr(L, name):
+            if "BTBA_LIB_PATH" in os.environ and name in ("btba_workspace_set_option", "btba_pack_correspondences24", "btba_workspace_live_blocks") and not hasattr(L, name):
                 continue               # developer A/B against a build from before version 103
             getattr(L, name)           # AttributeError if the ABI and the header drift apart
         L.btba_workspace_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p]
@@ -163,6 +164,8 @@ def lib() -> C.CDLL:
         L.btba_workspace_sync.argtypes = [C.c_void_p]
         if hasattr(L, "btba_workspace_set_option"):
             L.btba_workspace_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+        if hasattr(L, "btba_workspace_live_blocks"):
+            L.btba_workspace_live_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.btba_workspace_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.btba_workspace_signal_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.btba_collect_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]

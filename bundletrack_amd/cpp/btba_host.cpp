@@ -13,6 +13,9 @@ namespace btba {
 OptimizerGpu::OptimizerGpu(std::shared_ptr<Config> yml1, void *hip_stream) : yml(std::move(yml1))
 {
     if (!yml) yml = std::make_shared<Config>();
+    // the structs of include/btba.h (btba_params, btba_stats, btba_zn_aux) carry no size field: a library built from another header version must
+    // not be called with them
+    if (btba_version() != BTBA_VERSION) throw Error(BTBA_EINVAL, "libbtba.so was built from another include/btba.h (btba_version() != BTBA_VERSION)");
     const int rc = btba_workspace_create_on_stream(&ws_, hip_stream);       // nullptr = the legacy NULL stream, as the reference
     if (rc != BTBA_OK) throw Error(rc, "btba_workspace_create_on_stream");
 }

@@ -69,6 +69,8 @@ struct btba_workspace {
     DevBuf block_ranges;                                    // per (frame, 8 x 8 block) usable depth range: dead-block test of the dense sweep
     DevBuf chain_sync;                                      // chained launch: flags[B] + arrivals[n_gn][B] (zeroed before every launch), optional timeline
     DevBuf chain_trace;
+    DevBuf live_blocks;                                     // BTBA_OPT_COUNT_LIVE: one uint64 the block-walk workgroups add their walked blocks to
+    bool count_live = false;
     int *chain_error = nullptr;                             // pinned host word the chained launch's watchdog raises (checked at every host synchronisation)
     bool chain_failed = false;                              // a watchdog fired on this workspace: chaining stays off from then on
     uint64_t chain_launches = 0;
@@ -172,6 +174,8 @@ void btba_params_default(btba_params *p)
     p->sparse_chunks = 0;
     p->flags = 0;
     p->reduction_mode = BTBA_REDUCE_DETERMINISTIC;
+    p->weights_sparse_per_iter = nullptr;
+    p->weights_dense_per_iter = nullptr;
 }
 
 const char *btba_strerror(int status)
@@ -245,7 +249,7 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A, &ws->solve_tab,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts, &ws->block_ranges,
-                       &ws->chain_sync, &ws->chain_trace, &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc, &ws->corr_stage_dev, &ws->corr_lens };
+                       &ws->chain_sync, &ws->chain_trace, &ws->live_blocks, &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc, &ws->corr_stage_dev, &ws->corr_lens };
     for (auto b : bufs) b->release();
     if (ws->corr_stage) (void)hipHostFree(ws->corr_stage);
     if (ws->chain_error) (void)hipHostFree(ws->chain_error);
@@ -269,11 +273,24 @@ int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
     case BTBA_OPT_BIG_ASSEMBLY: t.big_assembly = value != 0; break;
     case BTBA_OPT_SPARSE_TAIL: if (value < -1 || value > 256) return BTBA_EINVAL; t.sparse_tail_256 = (int)value; break;
     case BTBA_OPT_OVERLAP_GROUPS: if (value < 1 || value > btba_workspace::kMaxGroups) return BTBA_EINVAL; t.overlap_groups = (int)value; break;
-    case BTBA_OPT_OVERLAP_EQUAL_PRIO: t.overlap_equal_prio = value != 0; break;
+    case BTBA_OPT_OVERLAP_EQUAL_PRIO:
+        if (t.overlap_equal_prio != (value != 0)) {        // the groups' streams carry their priority from creation: drop them, the next BTBA_FLAG_OVERLAP solve makes new ones
+            for (auto &st : ws->aux_streams) if (st) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipStreamDestroy(st)); st = nullptr; }
+        }
+        t.overlap_equal_prio = value != 0;
+        break;
     case BTBA_OPT_KEYED_CORR_MIN_BYTES: if (value < 0) return BTBA_EINVAL; t.keyed_corr_min_bytes = (size_t)value; break;
     case BTBA_OPT_CHAIN: if (value < -1 || value > 1) return BTBA_EINVAL; t.chain = (int)value; break;
     case BTBA_OPT_CHAIN_SPARSE_PERIOD: if (value < 0 || value == 1 || value > 64) return BTBA_EINVAL; t.chain_sparse_period = (int)value; break;
     case BTBA_OPT_CHAIN_TIMEOUT_MS: if (value < 1 || value > 60000) return BTBA_EINVAL; t.chain_timeout_ms = (int)value; break;
+    case BTBA_OPT_COUNT_LIVE:
+        ws->count_live = value != 0;
+        if (ws->count_live) {
+            int rc = ws->live_blocks.ensure(sizeof(unsigned long long));
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(ws->live_blocks.p, 0, sizeof(unsigned long long), ws->stream));
+        }
+        break;
     case 1000: t.chain_debug_skip = (int)value; break;      // developer timing experiments (ChainDims::debug_skip): not part of the ABI
     default: return BTBA_EINVAL;
     }
@@ -288,6 +305,19 @@ static int chain_check(btba_workspace *ws)
     *ws->chain_error = 0;
     ws->chain_failed = true;
     return BTBA_ESCHED;
+}
+
+int btba_workspace_live_blocks(btba_workspace *ws, uint64_t *blocks)
+{
+    DeviceGuard device_guard(ws);
+    if (!ws || !blocks) return BTBA_EINVAL;
+    *blocks = 0;
+    if (!ws->live_blocks.p) return BTBA_OK;
+    HIP_TRY(hipStreamSynchronize(ws->stream));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, ws->live_blocks.p, sizeof v, hipMemcpyDeviceToHost));
+    *blocks = v;
+    return BTBA_OK;
 }
 
 int btba_workspace_sync(btba_workspace *ws)
@@ -470,10 +500,23 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     if (atomic_sums && trace) return BTBA_EINVAL;                            // the decision traces are defined on the reproducible sums
     if (N > BTBA_MAX_FRAMES) return BTBA_EINVAL;                            // MAX_NUM_IMAGES of the reference (GlobalDefines.h:8) is 85 as well
     const int P = N * (N - 1) / 2;
-    const bool use_sparse = prm->weight_sparse > 0.0f && corr && pair_offsets && max_corr_per_pair > 0;
+    // Weights of the two terms per Gauss-Newton iteration: the solveBundlingStub seam takes one array per term (input.weightsSparse[nIter],
+    // weightsDenseDepth[nIter], SolverBundling.cu:948-951; SBA.cpp:27-32 fills them with 1 / 1), and so do the optional arrays of btba_params.
+    const float *wsi = prm->weights_sparse_per_iter, *wdi = prm->weights_dense_per_iter;
+    auto ws_at = [&](int it) { return wsi ? wsi[it] : prm->weight_sparse; };
+    auto wd_at = [&](int it) { return wdi ? wdi[it] : prm->weight_dense_depth; };
+    bool any_dense_weight = false, any_sparse_weight = false;
+    for (int it = 0; it < prm->n_gn_iters; it++) {
+        if (!(ws_at(it) >= 0.0f) || !(wd_at(it) >= 0.0f)) return BTBA_EINVAL;
+        any_dense_weight |= wd_at(it) > 0.0f; any_sparse_weight |= ws_at(it) > 0.0f;
+    }
+    // The sparse sweep runs whenever a sparse weight is positive in SOME iteration; in an iteration whose weight is 0 it still runs, as in the
+    // reference: evalMinusJTFDevice walks the correspondences for the Jacobi preconditioner whatever weightSparse is (SolverBundlingEquationsLie.h:
+    // 60-137 -- the diagonal carries no weight factor), while right-hand side and operator take the factor 0.
+    const bool use_sparse = any_sparse_weight && corr && pair_offsets && max_corr_per_pair > 0;
     // dense pair list
     std::vector<int32_t> pairs;
-    if (prm->weight_dense_depth > 0.0f) {
+    if (any_dense_weight) {
         if (dense_pairs && Pd_in >= 0) pairs.assign(dense_pairs, dense_pairs + 2 * (size_t)Pd_in);
         else for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) { pairs.push_back(i); pairs.push_back(j); }
         for (size_t k = 0; k < pairs.size(); k += 2)
@@ -579,6 +622,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;
     D.order_flag = order_flag;
+    D.live_blocks = (ws->count_live && ws->live_blocks.p) ? ws->live_blocks.as<unsigned long long>() : nullptr;
     D.pose_stride = 16 * N; D.x_stride = 6 * N;                      // instances back to back (the chained launch pads them, below)
     D.sp_stride = (int64_t)P * (atomic_sums ? 1 : chunks) * kSparseVals;
     D.dp_stride = (int64_t)(Pd > 0 ? Pd : 1) * (atomic_sums ? 1 : tiles) * kDenseVals;
@@ -661,7 +705,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // (the library's own choice, chain = -1: batches of full frames from 16 instances on.  Object-masked frames walked through their valid-pixel lists
     // have sweeps so short -- 53 us per iteration at c3 x 32 -- that an instance's next items come up before its 60 us in-launch solve is done:
     // measured 0.74 against 0.52 ms per step, profiles/r04/chain_experiments.json; they keep the plain schedule unless chain = 1 asks)
-    const bool chain = chain_lay != 0 && !ws->chain_failed && ws->tune.chain != 0 && (ws->tune.chain > 0 || (B >= 16 && !compaction)) && use_sparse && use_dense
+    const bool chain = chain_lay != 0 && !ws->chain_failed && ws->tune.chain != 0 && (ws->tune.chain > 0 || (B >= 16 && !compaction)) && use_sparse && use_dense && !wsi && !wdi
                        && !trace && !atomic_sums && !a_global && !D.pre_assembled && N <= kChainMaxFrames && chunks <= kChainMaxParts && tiles <= kChainMaxParts
                        && !(prm->flags & (BTBA_FLAG_NO_FUSE | BTBA_FLAG_OVERLAP)) && !Z.frame_slot
                        && lds_rest + 16 + sizeof(float) * chain_region_floats(N) <= kChainLdsBytes;      // (c3's 15 frames are the largest window whose solve fits a sweep workgroup's LDS share)
@@ -849,6 +893,11 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     } else
     for (int it = 0; it < prm->n_gn_iters; it++) {
         const bool timing_it = timing && (timed_iteration < 0 || timed_iteration == it);
+        // this iteration's weights (parameters.weightSparse / weightDenseDepth / useDense of SolverBundling.cu:948-953)
+        SolveDims Di = D;
+        Di.w_sparse = ws_at(it); Di.w_dense = wd_at(it);
+        const bool use_dense_it = use_dense && Di.w_dense > 0.0f;
+        Di.use_dense = use_dense_it ? 1 : 0;
         for (int h = 0; h < n_halves; h++) {
             const Half &H = halves[h];
             const size_t b0 = (size_t)H.b0;
@@ -865,7 +914,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             float *ps_h = ws->pairsum.p ? ws->pairsum.as<float>() + b0 * pairsum_floats : nullptr;
             float *tr_h = trace ? trace + b0 * (size_t)D.n_gn * D.trace_record : nullptr;
             size_t slot;
-            SolveDims Dh = D;                                   // the sweeps' view of this half
+            SolveDims Dh = Di;                                  // the sweeps' view of this half
             if (Dh.pair_lens) Dh.pair_lens += b0 * P;
             Dh.corr_entry0 = corr24 ? (int64_t)b0 * corr_stride : 0;
             if (Dh.block_ranges) Dh.block_ranges += b0 * N * (size_t)((Wd / 8) * (Hd / 8));
@@ -883,7 +932,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             // one interleaved launch of both sweeps: the dense workgroups are VALU-bound, the sparse ones stream HBM, and the
             // two fill each other's idle pipes -- measured at c3 (scripts/ab_dense.py, fused vs separate step time):
             // B=1 0.486 / 0.554 ms, B=8 0.871 / 0.950 ms, B=32 2.271 / 2.380 ms
-            const bool fuse = use_sparse && use_dense && n_s >= 64 && n_d >= 64 && !(prm->flags & BTBA_FLAG_NO_FUSE);
+            const bool fuse = use_sparse && use_dense_it && n_s >= 64 && n_d >= 64 && !(prm->flags & BTBA_FLAG_NO_FUSE);
             if (fuse) {
                 // one launch: HBM-streaming sparse workgroups interleaved with the VALU-bound dense ones
                 if ((rc = time_begin(ws, timing_it, 0, &slot, H.st))) return rc;
@@ -902,10 +951,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                     k_sparse_sweep<<<dim3(chunks, P, H.nb), kBlock, 0, H.st>>>(Dh, corr_h, off_h, T_h, sp_h);
                     if ((rc = time_end(ws, slot, H.st))) return rc;
                 }
-                if (use_dense) {
+                if (use_dense_it) {
                     if ((rc = time_begin(ws, timing_it, 0, &slot, H.st))) return rc;
                     const dim3 dgrid(n_d);
-#define BTBA_DENSE_ARGS D, reinterpret_cast<const float4 *>(campos_h), reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h
+#define BTBA_DENSE_ARGS Di, reinterpret_cast<const float4 *>(campos_h), reinterpret_cast<const float4 *>(normals_h), ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h
                     if (zn_layout == 1 && !compaction) k_dense_sweep_zn<true, false><<<dgrid, kBlock, lut_bytes, H.st>>>(Dh, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
                     else if (zn_layout == 2 && !compaction) k_dense_sweep_zn<false, false><<<dgrid, kBlock, lut_bytes, H.st>>>(Dh, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
                     else if (zn_layout == 1) k_dense_sweep_zn<true, true><<<dgrid, kBlock, lut_bytes, H.st>>>(Dh, zn_h, ws->dense_pairs.as<int2>(), T_h, Ti_h, dp_h, vl_h, vc_h);
@@ -926,13 +975,13 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             if ((rc = time_begin(ws, timing_it, 2, &slot, H.st))) return rc;
             float *A_h = (a_global || D.pre_assembled) ? ws->big_A.as<float>() + b0 * (n + 2) * ld : nullptr;
             float *out_h = (it == prm->n_gn_iters - 1) ? poses + 16 * b0 * N : nullptr;     // the last iterate's matrices go straight to the caller's buffer
-            SolveDims Ds = D;                                   // the system solve's view: in atomic mode one record per pair
+            SolveDims Ds = Di;                                  // the system solve's view: in atomic mode one record per pair
             if (atomic_sums) { Ds.sparse_chunks = 1; Ds.dense_tiles = 1; }
             if (D.pre_assembled) {
                 const size_t n_sums = (size_t)P * kSparseVals + (size_t)D.n_dense_pairs * kDenseVals;
                 k_big_reduce<<<dim3((unsigned)((n_sums + 255) / 256), (unsigned)H.nb), 256, 0, H.st>>>(Ds, sp_h, dp_h, ps_h);
                 const BigTasks bt = big_tasks(N, P, (int)ld);
-                k_big_assemble<<<dim3((bt.total + 255u) / 256u, (unsigned)H.nb), 256, 0, H.st>>>(D, ps_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, ws->solve_tab.as<int>(), A_h);
+                k_big_assemble<<<dim3((bt.total + 255u) / 256u, (unsigned)H.nb), 256, 0, H.st>>>(Di, ps_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, ws->solve_tab.as<int>(), A_h);
             }
 #define BTBA_SOLVE(LP, AG) k_system_solve<LP, AG><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(Ds, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h, A_h, out_h, ws->solve_tab.as<int>())
             if (a_global) { if (D.pairsum_in_lds) BTBA_SOLVE(true, true); else BTBA_SOLVE(false, true); }

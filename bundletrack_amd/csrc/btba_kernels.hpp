@@ -95,6 +95,7 @@ struct SolveDims {
     // shared by two regions that different workgroups publish at different times.
     int pose_stride, x_stride;
     int64_t sp_stride, dp_stride;
+    unsigned long long *live_blocks;   // non-null (BTBA_OPT_COUNT_LIVE, bench.py's roofline.executed): every block-walk workgroup adds the number of 8 x 8 blocks it walks
     int publish;         // k_chain: sweep workgroups store their partial records write-through (agent scope) -- another workgroup of the SAME launch reads them
 };
 
@@ -1153,6 +1154,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         // 31 %), and a block's taps land in a compact patch of the target.  The list holds the blocks that are not provably dead.
         const int lane = (int)tid & 63, wave = __builtin_amdgcn_readfirstlane((int)tid >> 6);
         n_live = __builtin_amdgcn_readfirstlane(n_live);
+        if (D.live_blocks && tid == 0) atomicAdd(D.live_blocks, (unsigned long long)n_live);
 #ifdef BTBA_WG_TRACE
         if (tid == 0) { wg_dbg[0] = wall_clock64(); wg_dbg[2] = (unsigned long long)n_live; }
 #endif

@@ -58,6 +58,12 @@ class Workspace:
         """`stream` waits (on the device) for what the workspace has enqueued so far: results consumed on another stream."""
         check(lib().btba_workspace_signal_stream(self._h, C.c_void_p(stream) if stream else None), "btba_workspace_signal_stream")
 
+    def live_blocks(self) -> int:
+        """8 x 8 pixel blocks walked by the dense sweeps since set_option(OPT_COUNT_LIVE, 1) (btba_workspace_live_blocks)."""
+        v = C.c_uint64(0)
+        check(lib().btba_workspace_live_blocks(self._h, C.byref(v)), "btba_workspace_live_blocks")
+        return int(v.value)
+
     def collect_stats(self) -> dict:
         s = Stats()
         check(lib().btba_collect_stats(self._h, C.byref(s)), "btba_collect_stats")
@@ -272,6 +278,21 @@ class BatchSolver:
         self.ws = workspace or Workspace()
         self.params = default_params(**param_overrides)
 
+    def set_iteration_weights(self, sparse=None, dense=None):
+        """Per-iteration weights of the two terms (btba_params.weights_*_per_iter; input.weightsSparse / weightsDenseDepth of the reference's
+        solveBundlingStub seam): sequences of n_gn_iters floats, or None for the scalar weight in every iteration."""
+        n = int(self.params.n_gn_iters)
+        self._w_it = []                                     # keeps the host arrays alive as long as the params point at them
+        for name, w in (("weights_sparse_per_iter", sparse), ("weights_dense_per_iter", dense)):
+            if w is None:
+                setattr(self.params, name, None)
+                continue
+            a = np.ascontiguousarray(w, np.float32)
+            if a.shape != (n,):
+                raise ValueError(f"{name}: expected {n} weights")
+            self._w_it.append(a)
+            setattr(self.params, name, a.ctypes.data)
+
     @staticmethod
     def pack_correspondences(corr_list, n_frames):
         """Host: bucket each instance's EntryJ pair-major; returns (corr [B, stride] ENTRYJ, offsets [B,P+1] u32, max_per_pair)."""
@@ -340,14 +361,15 @@ class BatchSolver:
                   "btba_zn_valid_lists")
         return aux
 
-    def pack_correspondences24(self, corr_dev, pair_offsets_dev, max_corr_per_pair, n_frames, check_order=False):
+    def pack_correspondences24(self, corr_dev, pair_offsets_dev, max_corr_per_pair, n_frames, check_order=False, out=None):
         """Device-resident EntryJ [B, stride, 32] (uint8 view) -> 24-byte records, float32 [groups of 64 entries, 3 planes, 64, 2]
         (btba_pack_correspondences24; entry E = b * stride + e sits in group E // 64 at column E % 64): what a
         batch that stays on the device hands to solve_zn(aux={"corr24": ...}).  check_order: also return a device int32 flag that is 1 when an
         entry does not belong to the pair of its segment."""
         torch = _torch()
         B, stride = int(corr_dev.shape[0]), int(corr_dev.shape[1])
-        out = torch.zeros((-(-(B * stride) // 64), 3, 64, 2), dtype=torch.float32, device=corr_dev.device)      # groups of 64 entries x 3 planes of float2
+        if out is None:                # (out: a tensor from an earlier call on an array of the same shape -- a caller that re-packs fresh matches every solve reuses it)
+            out = torch.zeros((-(-(B * stride) // 64), 3, 64, 2), dtype=torch.float32, device=corr_dev.device)      # groups of 64 entries x 3 planes of float2
         flag = torch.zeros((1,), dtype=torch.int32, device=corr_dev.device) if check_order else None
         check(lib().btba_pack_correspondences24(self.ws.handle, B, int(n_frames), _dev_ptr(corr_dev, "corr_dev"), stride, _dev_ptr(pair_offsets_dev, "pair_offsets_dev"),
                                                 int(max_corr_per_pair), _dev_ptr(out, "corr24"), _dev_ptr(flag, "order_flag")), "btba_pack_correspondences24")

@@ -79,3 +79,44 @@ def aggregate(per_rank):
     total = sum(g for _, g in per_rank)
     slowest = max(s for s, _ in per_rank)
     return total / slowest if slowest > 0 else float("nan"), slowest
+
+
+def bind_rank_to_cpus(local_rank: int, local_world: int, gpu_index: int | None = None):
+    """Give every rank of a node its own CPUs, preferably on the NUMA node of its GPU: each rank is one launcher thread issuing ~10 k kernel
+    launches per second, and eight of them sharing one CPU quota (or bouncing across sockets) would make the host the bottleneck of an
+    N = 8 run that has none on the device.  Best effort -- returns a description of what was done (recorded in the bench line)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return {"bound": False, "why": "no sched_getaffinity"}
+    if local_world <= 1 or len(allowed) < 2 * local_world:
+        return {"bound": False, "cpus_allowed": len(allowed), "why": "single rank or too few CPUs to split"}
+    numa_cpus = None
+    numa_node = None
+    if gpu_index is not None:
+        try:                                        # the GPU's NUMA node, where the driver exposes it
+            import glob
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/numa_node"), key=lambda p: int("".join(ch for ch in p.split("/")[4] if ch.isdigit())))
+            cards = [c for c in cards if os.path.exists(os.path.join(os.path.dirname(c), "mem_info_vram_total"))]
+            if gpu_index < len(cards):
+                numa_node = int(open(cards[gpu_index]).read().strip())
+                if numa_node >= 0:
+                    cpus = set()
+                    for part in open(f"/sys/devices/system/node/node{numa_node}/cpulist").read().strip().split(","):
+                        lo, _, hi = part.partition("-")
+                        cpus.update(range(int(lo), int(hi or lo) + 1))
+                    numa_cpus = sorted(cpus & set(allowed))
+        except Exception:
+            numa_cpus = None
+    per = len(allowed) // local_world
+    mine = allowed[local_rank * per:(local_rank + 1) * per]
+    if numa_cpus and len(numa_cpus) >= 2:
+        # ranks whose GPUs share a NUMA node split that node's CPUs among themselves by local rank
+        share = max(2, len(numa_cpus) // local_world)
+        k = (local_rank * share) % max(1, len(numa_cpus) - share + 1)
+        mine = numa_cpus[k:k + share]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError as e:
+        return {"bound": False, "why": str(e)[:80]}
+    return {"bound": True, "cpus": len(mine), "first_cpu": mine[0], "numa_node": numa_node}

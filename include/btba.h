@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BTBA_VERSION 104     /* 104: chained launch (BTBA_OPT_CHAIN*, BTBA_ESCHED, btba_stats.chain_iterations); 103: btba_params.reduction_mode, BTBA_FLAG_KEYED_CORR = 4096,
+#define BTBA_VERSION 104     /* 104: chained launch (BTBA_OPT_CHAIN*, BTBA_ESCHED, btba_stats.chain_iterations), btba_params.weights_*_per_iter, btba_workspace_live_blocks; 103: btba_params.reduction_mode, BTBA_FLAG_KEYED_CORR = 4096,
                                 btba_workspace_set_option, btba_zn_aux.corr24 + btba_pack_correspondences24.  A caller built against another version's structs must not
                                 call in: check btba_version() == BTBA_VERSION once after loading the library (the Python and C++ host layers do). */
 
@@ -94,7 +94,9 @@ enum {
                                        frame's n_frames - 1 pairs).  CONTRACT: the correspondences of a pair do not change while both
                                        frames stay cached -- the reference never recomputes a pair's matches either (findCorres returns
                                        early when _matches holds the pair, FeatureManager.cpp:176) -- and n_match_per_pair is given.  A
-                                       segment whose length changed is uploaded again; btba_frame_cache_evict / _clear drop segments */
+                                       segment whose length changed is uploaded again (its superseded copy stays in the pool until one of the
+                                       pair's frames is evicted or the cache is cleared); a cached segment is not checked for pair order
+                                       again; btba_frame_cache_evict / _clear drop segments */
     BTBA_FLAG_NO_COMPACTION = 512,  /* compact cache: always walk all Wd x Hd source pixels                        */
     BTBA_FLAG_COMPACTION    = 1024  /* compact cache: walk each source frame's ordered list of pixels that carry a depth
                                        (masked scenes).  btba_optimize_frames decides by itself from the valid-pixel counts
@@ -120,6 +122,13 @@ typedef struct btba_params {
     int32_t sparse_chunks;        /* workgroups per correspondence segment (0 = auto)                  */
     int32_t flags;                /* BTBA_FLAG_*                                                        */
     int32_t reduction_mode;       /* BTBA_REDUCE_*                                                      */
+    /* Optional per-iteration weights, the form the solveBundlingStub seam takes them in (input.weightsSparse[nIter], input.weightsDenseDepth[nIter],
+     * SolverBundling.cu:948-951; SBA.cpp:27-32 fills both with constants): HOST arrays of n_gn_iters floats >= 0, or NULL = weight_sparse /
+     * weight_dense_depth in every iteration.  As in the reference, an iteration with dense weight 0 builds no dense system (useDense = false,
+     * :951-953), and an iteration with sparse weight 0 still derives its Jacobi preconditioner from the correspondences (the preconditioner carries
+     * no weight, SolverBundlingEquationsLie.h:107-108) while right-hand side and operator take the factor 0. */
+    const float *weights_sparse_per_iter;
+    const float *weights_dense_per_iter;
 } btba_params;
 
 /* Timing / diagnostics filled by the solve entry points (all times in milliseconds, measured
@@ -209,9 +218,14 @@ enum {
                                            <= 23 frames, no trace, deterministic sums).  Same bits as the plain schedule.                  env BTBA_CHAIN */
     BTBA_OPT_CHAIN_SPARSE_PERIOD  = 11, /* chained launch: 0 (default) an instance's sparse items follow its dense items; R >= 2: every R-th item of an
                                            instance is a sparse one.                                                               env BTBA_CHAIN_PERIOD */
-    BTBA_OPT_CHAIN_TIMEOUT_MS     = 12  /* watchdog of the waits inside the chained launch (default 500 ms): see BTBA_ESCHED.        env BTBA_CHAIN_TIMEOUT_MS */
+    BTBA_OPT_CHAIN_TIMEOUT_MS     = 12, /* watchdog of the waits inside the chained launch (default 500 ms): see BTBA_ESCHED.        env BTBA_CHAIN_TIMEOUT_MS */
+    BTBA_OPT_COUNT_LIVE           = 13  /* 1: the dense sweep's block-walk workgroups add the number of 8 x 8 pixel blocks they actually walk (the blocks the hull
+                                           test could not prove dead) to a counter of the workspace -- setting the option clears it, btba_workspace_live_blocks
+                                           reads it.  Measurement aid (bench.py: roofline.executed); one atomic per workgroup while it is on. */
 };
 BTBA_API int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value);
+/* Blocks walked by the dense sweeps enqueued since BTBA_OPT_COUNT_LIVE was last set to 1 (synchronises with the workspace stream). */
+BTBA_API int btba_workspace_live_blocks(btba_workspace *ws, uint64_t *blocks);
 /* Stream ordering without a host wait, for callers whose producers / consumers run on another HIP stream (PyTorch's
  * current stream, a camera driver's copy stream): _wait_stream makes everything enqueued on the workspace stream AFTER the
  * call wait for what `stream` holds at the time of the call (inputs uploaded or rendered there); _signal_stream makes

@@ -19,10 +19,10 @@ static float4x4 rs_load4(const float *m) { float4x4 M; for (int r = 0; r < 4; r+
 // above the diagonal and erased by FlipJtJ_Kernel, :49-59 -- BTBA_PAIRS_TARGET_HIGHER); any other permutation gives the
 // corresponding explicit orientation (BTBA_PAIRS_TARGET_MORE_VALID, BTBA_PAIRS_EXPLICIT).
 extern "C" __attribute__((visibility("default")))
-int ref_solve2(int N, int Wd, int Hd, const float *intr, const float *campos, const float *normals, const float *corr_in, int C,
+int ref_solve3(int N, int Wd, int Hd, const float *intr, const float *campos, const float *normals, const float *corr_in, int C,
                float *poses_io /* [N][16] row-major, camera -> model */, int n_gn, int n_pcg, float w_sparse, float w_dense, float robust_delta,
                float dist_thresh, float normal_thresh, float depth_min, float depth_max, float *x_out /* [N][6] rot, trans; may be NULL */,
-               const int *addr_rank)
+               const int *addr_rank, const float *w_sparse_it /* [n_gn] or NULL: w_sparse in every iteration */, const float *w_dense_it /* likewise */)
 {
     const size_t npix = (size_t)Wd * Hd;
     const unsigned maxCorrPerImage = C > 0 ? (unsigned)C : 1u, maxPairs = (unsigned)(N * (N - 1) / 2 > 0 ? N * (N - 1) / 2 : 1);
@@ -60,6 +60,7 @@ int ref_solve2(int N, int Wd, int Hd, const float *intr, const float *campos, co
     st.d_xRot = xRot.data(); st.d_xTrans = xTrans.data();
 
     std::vector<float> wS(n_gn, w_sparse), wD(n_gn, w_dense), wC(n_gn, 0.0f);                              // SBA.cpp:27-32
+    for (int it = 0; it < n_gn; it++) { if (w_sparse_it) wS[it] = w_sparse_it[it]; if (w_dense_it) wD[it] = w_dense_it[it]; }      // input.weightsSparse / weightsDenseDepth, read per iteration at SolverBundling.cu:948-949
     SolverParameters prm; memset(&prm, 0, sizeof prm);
     prm.denseDistThresh = dist_thresh; prm.denseNormalThresh = normal_thresh; prm.denseColorThresh = 0.1f; prm.denseColorGradientMin = 0.005f;
     prm.denseDepthMin = depth_min; prm.denseDepthMax = depth_max; prm.denseOverlapCheckSubsampleFactor = 1;  // CUDASolverBundling.cpp:93-99
@@ -90,6 +91,15 @@ int ref_solve2(int N, int Wd, int Hd, const float *intr, const float *campos, co
                         st.d_corrCountColor, st.d_sumResidualColor };
     for (void *q : to_free) free(q);
     return 0;
+}
+
+extern "C" __attribute__((visibility("default")))
+int ref_solve2(int N, int Wd, int Hd, const float *intr, const float *campos, const float *normals, const float *corr_in, int C,
+               float *poses_io, int n_gn, int n_pcg, float w_sparse, float w_dense, float robust_delta,
+               float dist_thresh, float normal_thresh, float depth_min, float depth_max, float *x_out, const int *addr_rank)
+{
+    return ref_solve3(N, Wd, Hd, intr, campos, normals, corr_in, C, poses_io, n_gn, n_pcg, w_sparse, w_dense, robust_delta, dist_thresh, normal_thresh,
+                      depth_min, depth_max, x_out, addr_rank, nullptr, nullptr);
 }
 
 extern "C" __attribute__((visibility("default")))

@@ -191,27 +191,33 @@ def lib_solver() -> C.CDLL:
 
 
 def solve(campos, normals, intr, corr, poses, n_gn=7, n_pcg=5, weight_sparse=1.0, weight_dense=1.0, robust_delta=0.005,
-          dist_thresh=0.02, normal_thresh=float(np.cos(np.pi / 4)), depth_min=0.1, depth_max=9999.0, addr_rank=None):
+          dist_thresh=0.02, normal_thresh=float(np.cos(np.pi / 4)), depth_min=0.1, depth_max=9999.0, addr_rank=None,
+          weights_sparse=None, weights_dense=None):
     """solveBundlingStub (SolverBundling.cu:931-1003) and everything under it, run by the reference's own code.
     Returns (poses [N,4,4] after n_gn Gauss-Newton iterations, x [N,6] = (rot, trans)).
     addr_rank: permutation of 0..N-1 ordering the frames' d_num_valid_points ADDRESSES, which is what orients the dense pairs in
     the reference (FindImageImageCorr_Kernel keeps (target i, source j) iff address_i > address_j): None = descending in frame
-    order (target = lower index), np.arange(N) = ascending (target = higher index, cross blocks erased by FlipJtJ)."""
+    order (target = lower index), np.arange(N) = ascending (target = higher index, cross blocks erased by FlipJtJ).
+    weights_sparse / weights_dense: per-iteration weights [n_gn] (input.weightsSparse / weightsDenseDepth, SolverBundling.cu:948-949) or None."""
     campos, normals = _f(campos, normals)
     N, Hd, Wd = campos.shape[:3]
     (intr,) = _f(intr)
     corr = np.ascontiguousarray(corr)
     P = np.ascontiguousarray(poses, np.float32).reshape(N, 16).copy()
     x = np.zeros((N, 6), np.float32)
-    f = lib_solver().ref_solve2
-    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 7 + [C.c_void_p, C.c_void_p]
+    f = lib_solver().ref_solve3
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 7 + [C.c_void_p] * 4
+    wsi = np.ascontiguousarray(weights_sparse, np.float32) if weights_sparse is not None else None
+    wdi = np.ascontiguousarray(weights_dense, np.float32) if weights_dense is not None else None
+    assert (wsi is None or len(wsi) == n_gn) and (wdi is None or len(wdi) == n_gn)
     rank = None
     if addr_rank is not None:
         rank = np.ascontiguousarray(addr_rank, np.int32)
         if sorted(rank.tolist()) != list(range(N)):
             raise ValueError("addr_rank must be a permutation of 0..N-1")
     f(N, Wd, Hd, _p(intr), _p(campos), _p(normals), _p(corr), len(corr), _p(P), n_gn, n_pcg, weight_sparse, weight_dense, robust_delta,
-      dist_thresh, normal_thresh, depth_min, depth_max, _p(x), _p(rank) if rank is not None else None)
+      dist_thresh, normal_thresh, depth_min, depth_max, _p(x), _p(rank) if rank is not None else None,
+      _p(wsi) if wsi is not None else None, _p(wdi) if wdi is not None else None)
     return P.reshape(N, 4, 4), x
 
 

@@ -216,3 +216,36 @@ def test_random_windows_match_the_reference_solver(oracle):
           f"above 1e-4 before any differing decision, within 3x the oracle's own summation-order spread: {by_roundoff}")
     assert len(above) <= n_windows // 4                  # even in the weak class most windows agree to 1e-4
     assert n_strict >= 6
+
+
+@pytest.mark.parametrize("name,ws,wd", [
+    ("dense term switched on at the third iteration", None, [0, 0, 1, 1, 1, 1, 1]),
+    ("both terms ramped", [1, 1, 0.5, 0.5, 0.25, 0.25, 1], [0.25, 0.5, 1, 1, 2, 0, 1]),
+    ("sparse weight 0 in two iterations (preconditioner still from the correspondences)", [1, 0, 1, 0, 1, 1, 1], None),
+])
+def test_per_iteration_weights_match_the_reference_seam(name, ws, wd):
+    """solveBundlingStub reads its weights PER ITERATION (parameters.weightSparse = input.weightsSparse[nIter], weightDenseDepth likewise,
+    useDense = weightDenseDepth > 0: SolverBundling.cu:948-953; SBA.cpp:27-32 fills the arrays).  btba_params.weights_*_per_iter is that seam:
+    the reference's own solver is run with the same arrays."""
+    import torch
+    from bundletrack_amd.optimizer import BatchSolver, Workspace
+    pb = S.make_problem(6, 400, 77, background=False, full_res=False)
+    campos, normals, intr = S.analytic_cache(pb)
+    ref, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, weights_sparse=ws, weights_dense=wd)
+    const, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init)
+    dev = torch.device("cuda:0")
+    bs = BatchSolver(Workspace())
+    bs.set_iteration_weights(sparse=ws, dense=wd)
+    corr, offs, mx = bs.pack_correspondences([pb.corr], pb.n_frames)
+    zn_d = torch.from_numpy(S.compact_cache(pb)[None]).to(dev)
+    corr_d = torch.from_numpy(corr.view(np.uint8).reshape(1, -1, 32)).to(dev)
+    offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
+    poses_d = torch.from_numpy(pb.poses_init[None].copy()).to(dev)
+    bs.solve_zn(zn_d, pb.H, pb.W, pb.K, corr_d, offs_d, mx, poses_d)
+    bs.ws.sync()
+    got = poses_d.cpu().numpy()[0]
+    worst = max(max(S.pose_error(got[k], ref[k])) for k in range(pb.n_frames))
+    moved = max(max(S.pose_error(ref[k], const[k])) for k in range(pb.n_frames))
+    print(f"{name}: HIP vs the reference's solver {worst:.2e}; the schedule moves the result by {moved:.2e} against constant weights")
+    assert worst < 1e-4, worst
+    assert moved > 2e-4, "the weight schedule must matter for this to test anything"
