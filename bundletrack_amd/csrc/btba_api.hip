@@ -624,8 +624,9 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.order_flag = order_flag;
     D.live_blocks = (ws->count_live && ws->live_blocks.p) ? ws->live_blocks.as<unsigned long long>() : nullptr;
     D.pose_stride = 16 * N; D.x_stride = 6 * N;                      // instances back to back (the chained launch pads them, below)
-    D.sp_stride = (int64_t)P * (atomic_sums ? 1 : chunks) * kSparseVals;
-    D.dp_stride = (int64_t)(Pd > 0 ? Pd : 1) * (atomic_sums ? 1 : tiles) * kDenseVals;
+    D.sp_stride = (unsigned)((size_t)P * (atomic_sums ? 1 : chunks) * kSparseVals);
+    D.dp_stride = (unsigned)((size_t)(Pd > 0 ? Pd : 1) * (atomic_sums ? 1 : tiles) * kDenseVals);
+    if ((size_t)B * std::max(D.sp_stride, D.dp_stride) >= ((size_t)1 << 32) || (size_t)B * 16 * N >= ((size_t)1 << 31)) return BTBA_EINVAL;      // the sweeps address an instance's poses and partials in 32 bits
     D.atomic_sums = atomic_sums ? 1 : 0;
     D.corr24 = corr24 ? 1 : 0;
     D.pair_lens = pair_lens;
@@ -715,7 +716,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     if (chain) {
         const int n_it = prm->n_gn_iters;
         D.pose_stride = (int)pad32(16 * (size_t)N); D.x_stride = (int)pad32(6 * (size_t)N);
-        D.sp_stride = (int64_t)pad32((size_t)P * chunks * kSparseVals); D.dp_stride = (int64_t)pad32((size_t)Pd * tiles * kDenseVals);
+        D.sp_stride = (unsigned)pad32((size_t)P * chunks * kSparseVals); D.dp_stride = (unsigned)pad32((size_t)Pd * tiles * kDenseVals);
         D.publish = 1;
         plain_pairsum_in_lds = D.pairsum_in_lds;
         D.pairsum_in_lds = 0;

@@ -94,7 +94,7 @@ struct SolveDims {
     // the instances back to back; the chained launch (k_chain) pads every instance's region to whole 128-byte lines, so that no cache line is
     // shared by two regions that different workgroups publish at different times.
     int pose_stride, x_stride;
-    int64_t sp_stride, dp_stride;
+    unsigned sp_stride, dp_stride;      // (32-bit: an instance's partials are a few MB at most; 64-bit strides cost the short masked / sparse items ~100 scalar instructions)
     unsigned long long *live_blocks;   // non-null (BTBA_OPT_COUNT_LIVE, bench.py's roofline.executed): every block-walk workgroup adds the number of 8 x 8 blocks it walks
     int publish;         // k_chain: sweep workgroups store their partial records write-through (agent scope) -- another workgroup of the SAME launch reads them
 };
@@ -304,8 +304,9 @@ __device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const floa
     const uint32_t len = D.pair_lens ? as_const(D.pair_lens)[(size_t)b * D.n_pairs + p] : off[p + 1] - seg0;       // (pool segments are not back to back)
     const uint32_t per = (len + D.sparse_chunks - 1) / D.sparse_chunks;
     const uint32_t lo = seg0 + min(len, per * chunk), hi = seg0 + min(len, per * (chunk + 1));
-    const Mat4 Ti = load_mat4_uniform(T + (size_t)b * D.pose_stride + 16 * fi);
-    const Mat4 Tj = load_mat4_uniform(T + (size_t)b * D.pose_stride + 16 * fj);
+    const float *Tb = T + (unsigned)b * (unsigned)D.pose_stride;
+    const Mat4 Ti = load_mat4_uniform(Tb + 16 * fi);
+    const Mat4 Tj = load_mat4_uniform(Tb + 16 * fj);
     float acc[kSparseVals];
 #pragma unroll
     for (int k = 0; k < kSparseVals; k++) acc[k] = 0.0f;
@@ -371,7 +372,7 @@ __device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const floa
         }
         if (D.order_flag && misplaced) atomicOr(D.order_flag, 1);
     }
-    float *out = partials + (size_t)b * D.sp_stride + (D.atomic_sums ? (size_t)p : (size_t)p * D.sparse_chunks + chunk) * kSparseVals;
+    float *out = partials + ((unsigned)b * D.sp_stride + (unsigned)(D.atomic_sums ? p : p * D.sparse_chunks + chunk) * (unsigned)kSparseVals);
     block_reduce_store<kSparseVals, 4>(acc, red, out, D.atomic_sums ? 1 : D.publish ? 2 : 0);
 }
 __device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
@@ -636,7 +637,7 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
 {
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
-    const size_t pb = (size_t)b * D.pose_stride;
+    const unsigned pb = (unsigned)b * (unsigned)D.pose_stride;
     dense_stage_M(red, T + pb + 16 * fi);
     DenseCtx C;
     C.Tij = mat_mul(load_mat4(Tinv + pb + 16 * fi), load_mat4(T + pb + 16 * fj));      // source camera -> target camera
@@ -667,7 +668,7 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
             pixel_accumulate(C, g, c00, c10, c01, c11, n00, n10, n01, n11, acc);
         }
     }
-    float *out = partials + (size_t)b * D.dp_stride + (D.atomic_sums ? (size_t)p : (size_t)p * D.dense_tiles + tile) * kDenseVals;
+    float *out = partials + ((unsigned)b * D.dp_stride + (unsigned)(D.atomic_sums ? p : p * D.dense_tiles + tile) * (unsigned)kDenseVals);
     dense_epilogue(acc, red, out, D.atomic_sums ? 1 : D.publish ? 2 : 0);
 }
 
@@ -773,7 +774,7 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
     const float *lut_x = lut, *lut_y = lut + D.width;
     const int fi = ij.x, fj = ij.y;                       // fi = target, fj = source
     const size_t fb = (size_t)b * D.n_frames;
-    const size_t pb = (size_t)b * D.pose_stride;
+    const unsigned pb = (unsigned)b * (unsigned)D.pose_stride;
     dense_stage_M(red, T + pb + 16 * fi);
     DenseCtx C;
     C.Tij = mat_mul(load_mat4(Tinv + pb + 16 * fi), load_mat4(T + pb + 16 * fj));
@@ -836,7 +837,7 @@ __device__ __forceinline__ void dense_block_zn(const SolveDims &D, const float4 
         pixel_accumulate(C, g, make_float4(c00.x, c00.y, c00.z, 1.f), make_float4(c10.x, c10.y, c10.z, 1.f), make_float4(c01.x, c01.y, c01.z, 1.f), make_float4(c11.x, c11.y, c11.z, 1.f),
                          make_float4(z00.y, z00.z, z00.w, 0.f), make_float4(z10.y, z10.z, z10.w, 0.f), make_float4(z01.y, z01.z, z01.w, 0.f), make_float4(z11.y, z11.z, z11.w, 0.f), acc);
     }
-    float *out = partials + (size_t)b * D.dp_stride + (D.atomic_sums ? (size_t)p : (size_t)p * D.dense_tiles + tile) * kDenseVals;
+    float *out = partials + ((unsigned)b * D.dp_stride + (unsigned)(D.atomic_sums ? p : p * D.dense_tiles + tile) * (unsigned)kDenseVals);
     dense_epilogue(acc, red, out, D.atomic_sums ? 1 : D.publish ? 2 : 0);
 }
 
@@ -936,6 +937,39 @@ __device__ __forceinline__ bool block_is_live(const SolveDims &D, const float (&
     return live;
 }
 
+// The same test from the workgroup's ROTATED-RAY tables (colA[x] = R[:, 0] lx(x), rowB[y] = R[:, 1] ly(y) + R[:, 2], filled for the pixel loop anyway) and
+// without a division.  A point q = d r + t of the block's hull, q.z > 0, projects left of the image by more than the margin m iff
+//     fx q.x / q.z + cx < -0.5 - m   <=>   fx q.x + (cx + 0.5 + m) q.z < 0   <=>   d alpha_L(r) + beta_L < 0,   alpha_L = fx r.x + c_L r.z,  beta_L = fx t.x + c_L t.z,
+// a LINEAR form in d for a fixed ray, so over the block's depth range it peaks at one of the two ends; likewise for the other three image edges.  The
+// block is outside iff one of the four forms keeps its sign over all 4 corner rays x 2 depths: per ray 3 adds, 2 + 4 multiply-adds for the alphas, 8 products
+// and 8 min / max instead of 2 x (9 multiply-adds, a reciprocal, 4 operations for (u, v) and 5 min / max) -- and no table entries recomputed per lane.
+// 220 -> ~120 instructions of a workgroup's ~400-instruction prologue.  Same margin (0.01 pixel), same verdicts up to rounding far inside it.
+__device__ __forceinline__ bool block_is_live_planes(const SolveDims &D, const float4 *colA, const float4 *rowB, const float (&t)[3], float2 zr, int bxl, int byg)
+{
+    zr.x = fmaxf(zr.x, D.depth_min); zr.y = fminf(zr.y, D.depth_max);      // usable depths: depth_min < z < depth_max
+    bool live = zr.x <= zr.y;
+    if (live) {
+        const float4 ca = colA[8 * bxl], cb = colA[8 * bxl + 7], ra = rowB[8 * byg], rb = rowB[8 * byg + 7];
+        const float m = 0.01f;
+        const float cL = D.cx + 0.5f + m, cR = D.cx - ((float)D.width - 0.5f + m), cT = D.cy + 0.5f + m, cB = D.cy - ((float)D.height - 0.5f + m);
+        float maxL = -INFINITY, minR = INFINITY, maxT = -INFINITY, minB = INFINITY, zq = INFINITY;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4 cx4 = (k & 1) ? cb : ca, ry4 = (k & 2) ? rb : ra;
+            const float rx = cx4.x + ry4.x, ry = cx4.y + ry4.y, rz = cx4.z + ry4.z;
+            const float fxrx = rx * D.fx, fyry = ry * D.fy;
+            const float aL = fxrx + cL * rz, aR = fxrx + cR * rz, aT = fyry + cT * rz, aB = fyry + cB * rz;
+            maxL = fmaxf(maxL, fmaxf(aL * zr.x, aL * zr.y)); minR = fminf(minR, fminf(aR * zr.x, aR * zr.y));
+            maxT = fmaxf(maxT, fmaxf(aT * zr.x, aT * zr.y)); minB = fminf(minB, fminf(aB * zr.x, aB * zr.y));
+            zq = fminf(zq, fminf(rz * zr.x, rz * zr.y));
+        }
+        const float bL = D.fx * t[0] + cL * t[2], bR = D.fx * t[0] + cR * t[2], bT = D.fy * t[1] + cT * t[2], bB = D.fy * t[1] + cB * t[2];
+        const bool outside = (maxL + bL < 0.0f) | (minR + bR > 0.0f) | (maxT + bT < 0.0f) | (minB + bB > 0.0f);
+        live = !((zq + t[2] > 1e-3f) && outside);         // a corner at or behind the camera plane: the block stays
+    }
+    return live;
+}
+
 // (target, source, dense pair) of work position q: computed where the work order is the closed form (the default pair policies), read from
 // the work table otherwise.  q is wave-uniform: scalar arithmetic / a scalar load.
 __device__ __forceinline__ void dense_work_item(const SolveDims &D, int q, int &fi, int &fj, int &p)
@@ -969,7 +1003,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     const size_t fb = (size_t)b * D.n_frames;
     const size_t slot_t = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fi));
     const size_t slot_s = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fj));
-    const size_t pb = (size_t)b * D.pose_stride;
+    const unsigned pb = (unsigned)b * (unsigned)D.pose_stride;
     const Mat4 Tinv_i = load_mat4_uniform(Tinv + pb + 16 * fi), T_j = load_mat4_uniform(T + pb + 16 * fj);
     float m_stage = 0.0f;                                 // M of the epilogue's congruence, from the target frame's pose (see dense_stage_M)
     if (tid >= 64 && tid < 64 + 36) {
@@ -1012,8 +1046,9 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     unsigned *blist = reinterpret_cast<unsigned *>(hdr + 8);
     int n_live = 0;
     if (WALK == 2) {
-        // Blocks that are provably dead (block_is_live: 90 % of the dead ones at c3) are removed BEFORE the walk; the live ones are compacted
+        // Blocks that are provably dead (block_is_live_planes: 90 % of the dead ones at c3) are removed BEFORE the walk; the live ones are compacted
         // into an ordered list in LDS (ballot + mbcnt, block order: deterministic) that the four waves share round-robin.
+        __syncthreads();                                      // the ray tables are read by the test
         const int lane_c = (int)tid & 63, wave_c = __builtin_amdgcn_readfirstlane((int)tid >> 6);
         for (int c0 = 0; c0 < nb; c0 += kBlock) {
             const int idx = c0 + (int)tid;
@@ -1022,7 +1057,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
             if (idx < nb) {
                 const int byl = idx / bw, bxl = idx - byl * bw, byg = r0 + byl;
                 code = ((unsigned)byg << 16) | (unsigned)bxl;
-                live = rng ? block_is_live(D, C.R, C.t, c0 ? rng[idx] : zr0, bxl, byg) : true;
+                live = rng ? block_is_live_planes(D, colA, rowB, C.t, c0 ? rng[idx] : zr0, bxl, byg) : true;
             }
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(live);
             if (lane_c == 0) hdr[wave_c] = __popcll(bal);
@@ -1230,7 +1265,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
             pixel(zs, 4u * ox, 4u * oy);                  // 4-byte table offsets -> 16-byte entries (rowB follows colA as the row table follows the column table)
         }
     }
-    float *out = partials + (size_t)b * D.dp_stride + (D.atomic_sums ? (size_t)p : (size_t)p * D.dense_tiles + tile) * kDenseVals;
+    float *out = partials + ((unsigned)b * D.dp_stride + (unsigned)(D.atomic_sums ? p : p * D.dense_tiles + tile) * (unsigned)kDenseVals);
     dense_epilogue<true>(acc, red, out, D.atomic_sums ? 1 : D.publish ? 2 : 0);
 }
 
@@ -1637,11 +1672,12 @@ struct SolveIO {
 //                  workgroups and may only use a sweep workgroup's share of the LDS: the matrix lives in an L2-resident global scratch, the
 //                  mat-vec of the PCG is spread over all four waves (two lanes per row, each the two partial sums of the one-wave version
 //                  that belong to its half of the 16-byte chunks), everything else of a PCG step is the one-wave code, bit for bit.
-template <bool LDS_PAIRS, bool A_GLOBAL, bool CHAIN>
-__device__ __forceinline__ void system_solve_body(const SolveDims &D, int iter, const int tid, const int nthr, float *lds, const SolveIO &io,
+template <bool LDS_PAIRS, bool A_GLOBAL, bool CHAIN, int NTHR>
+__device__ __forceinline__ void system_solve_body(const SolveDims &D, int iter, const int tid, float *lds, const SolveIO &io,
                                                   const int2 *__restrict__ dense_pairs, const int *__restrict__ adj_off, const int *__restrict__ adj,
                                                   const int *__restrict__ solve_tab)
 {
+    constexpr int nthr = NTHR;                           // the workgroup size, a compile-time constant: loop strides and bounds against it fold
     float *sparse_partials = io.sparse_partials, *dense_partials = io.dense_partials;
     float *A_scratch = io.A_scratch;
     const int N = D.n_frames, n = 6 * N, ld = 4 * (((n + 3) / 4) | 1);   // odd multiple of 4: 16-B rows, conflict-free ds_read_b128
@@ -2184,7 +2220,7 @@ _Pragma("unroll 4")
     BTBA_STAMP(3);
     // Phase D: x_k <- Log(Exp(delta_k) Exp(x_k)); next iterate's T, T^-1  (SolverBundling.cu:805-815, 890-897)
     for (int k = tid; k < N; k += nthr) {
-        float *xk = io.x_out + 6 * k;
+        float *xk = (CHAIN ? io.x_out : const_cast<float *>(io.x_in)) + 6 * k;       // (in place unless chained: one base pointer less to keep)
         const float *xl = x_l + 6 * k;
         float rot[3] = { xl[0], xl[1], xl[2] }, trans[3] = { xl[3], xl[4], xl[5] };
         if (k > 0) {
@@ -2195,7 +2231,7 @@ _Pragma("unroll 4")
         }
         if (k > 0 || CHAIN) { xk[0] = rot[0]; xk[1] = rot[1]; xk[2] = rot[2]; xk[3] = trans[0]; xk[4] = trans[1]; xk[5] = trans[2]; }      // (in place: frame 0 keeps its x)
         const Mat4 E = pose_to_matrix(rot, trans);
-        store_mat4(io.T_out + 16 * k, E);
+        store_mat4((CHAIN ? io.T_out : const_cast<float *>(io.T_in)) + 16 * k, E);
         if (io.poses_out) store_mat4(io.poses_out + 16 * k, E);      // last iterate: convertPosesToMatricesCU (SBA.cpp:115), no separate copy
         store_mat4(io.Tinv_out + 16 * k, mat_inverse(E));
         if (tr) {
@@ -2229,7 +2265,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_system_solve(SolveDims D, int i
     io.A_scratch = A_scratch ? A_scratch + b * (size_t)(n + 2) * ld : nullptr;
     io.trace = trace ? trace + b * (size_t)D.n_gn * D.trace_record : nullptr;
     io.stamps = nullptr;
-    system_solve_body<LDS_PAIRS, A_GLOBAL, false>(D, iter, (int)threadIdx.x, (int)blockDim.x, lds, io, dense_pairs, adj_off, adj, solve_tab);
+    system_solve_body<LDS_PAIRS, A_GLOBAL, false, kSolveBlock>(D, iter, (int)threadIdx.x, lds, io, dense_pairs, adj_off, adj, solve_tab);
 }
 
 
@@ -2401,7 +2437,7 @@ __global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_chain(SolveDims D,
         if (Cn.solve_prio == 1) __builtin_amdgcn_s_setprio(1);
         else if (Cn.solve_prio == 2) __builtin_amdgcn_s_setprio(2);
         else if (Cn.solve_prio == 3) __builtin_amdgcn_s_setprio(3);
-        system_solve_body<false, false, true>(D, (int)it, (int)tid, kBlock, dyn_lds, io, dense_pairs, adj_off, adj, solve_tab);
+        system_solve_body<false, false, true, kBlock>(D, (int)it, (int)tid, dyn_lds, io, dense_pairs, adj_off, adj, solve_tab);
         __syncthreads();
         if (tid == 0u && !(Cn.debug_skip & 64)) {           // (64: the watchdog's test -- an iterate that is never published)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
