@@ -86,7 +86,7 @@ struct btba_workspace {
         int overlap_groups = 2;        // BTBA_OPT_OVERLAP_GROUPS (env BTBA_GROUPS): instance groups of BTBA_FLAG_OVERLAP
         bool overlap_equal_prio = false;   // BTBA_OPT_OVERLAP_EQUAL_PRIO (env BTBA_GROUP_PRIO=e...)
         size_t keyed_corr_min_bytes = (size_t)1 << 20;   // BTBA_OPT_KEYED_CORR_MIN_BYTES (env of the same name): below it the keyed correspondence cache is not used
-        int chain = -1;                // BTBA_OPT_CHAIN         (env BTBA_CHAIN): all Gauss-Newton iterations of a batch in ONE launch (k_chain); -1 = from 16 instances on, 0 = never, 1 = whenever the launch supports the solve
+        int chain = 0;                 // BTBA_OPT_CHAIN         (env BTBA_CHAIN): 1 = all Gauss-Newton iterations of a batch in ONE launch (k_chain) whenever the launch supports the solve; 0 (default) / -1 = the plain schedule
         int chain_sparse_period = 0;   // BTBA_OPT_CHAIN_SPARSE_PERIOD (env BTBA_CHAIN_PERIOD): 0 = an instance's sparse items follow its dense items, R >= 2 = every R-th item is a sparse one
         int chain_timeout_ms = 500;    // BTBA_OPT_CHAIN_TIMEOUT_MS (env BTBA_CHAIN_TIMEOUT_MS): watchdog of the waits inside the chained launch
         int chain_solve_prio = 0;      // env BTBA_CHAIN_SOLVE_PRIO (developer A/B): s_setprio of the solve items' waves
@@ -453,25 +453,27 @@ static int pick_tiles(const btba_params *prm, int B, int Pd, int npix, bool list
 {
     if (prm->dense_tiles > 0) return prm->dense_tiles;
     if (Pd == 0) return 1;
-    // measured with the fused sweep launch (bench.py, BTBA_BENCH_TILES; fused-sweep time per launch):
-    //   c3 x 32 (3 360 pair-instances): 437 / 279 / 320 / 287 / 304 / 325 us for 1 / 2 / 3 / 4 / 6 / 8 tiles; c4 x 32: 1.66 / 1.12 / 1.23 / 1.17 ms
-    //   for 1 / 2 / 3 / 4; c3 x 32 on masked frames 0.78 vs 0.93 ms per step for 2 vs 4 -- every workgroup pays its set-up (LUT,
-    //   relative pose, block reduction), so a big batch wants few, large tiles; B=8 0.871 / 0.886 / 0.874 / 0.900 ms per step for
-    //   4 / 5 / 6 / 8; a single instance wants 10-15 (0.486 ms) to fill the chip
+    // Workgroups per dense frame pair.  Every workgroup pays its set-up (item, poses, ray tables, hull test: ~7 of a two-tile item's 35 us at c3), so a
+    // launch wants the FEWEST tiles that still fill the chip: about one dense item per resident workgroup slot (1 536).  Measured with the fused launch
+    // of round 4 (hull-culled block walk, sparse items closing the launch), c3 (105 pairs per instance), ms per step for 1 / 2 / 3 / 4 / 5 / 8 tiles,
+    // gpurun_out/r04_17 ... r04_19 (profiles/r04/tile_sweep.json):
+    //   B = 1   0.521 / 0.317 / 0.281 / 0.267 / 0.261 / 0.250        B = 2   0.504 / 0.344 / 0.315 / 0.279 / 0.295 / 0.297
+    //   B = 4   0.528 / 0.368 / 0.375 / 0.352 / 0.391 / 0.392        B = 8   0.519 / 0.457 / 0.468 / 0.487 / 0.512 / 0.571
+    //   B = 16  0.688 / 0.698 / -     / 0.771                        B = 32  1.247 / 1.306        B = 64  2.351 / 2.428
+    // (round 2's table, taken before the dead blocks were culled and the sparse items moved to the end of the launch, had 2 tiles from 2 048
+    // pair-instances on and 4 from 512: "one tile per pair 2.07 against 1.52 ms, the drain dominates" no longer holds -- the short sparse items
+    // fill the drain of the long dense ones.)
     const long blocks = (long)B * Pd;
-    // masked frames walked through their valid-pixel lists (~5 % of the image): one workgroup per pair is enough work per set-up
-    // once the batch fills the chip (c3 x 32 masked, fused sweep per launch: 56.6 / 66.0 / 97.5 / 87.5 us for 1 / 2 / 3 / 4 tiles)
-    if (lists && blocks >= 2048) return 1;
-    int want = blocks >= 2048 ? 2 : blocks >= 512 ? 4 : (int)((2048 + blocks - 1) / blocks);
+    // object-masked frames walked through their valid-pixel lists (~5 % of the image): 1 / 2 / 3 / 5 tiles  B = 1: 0.219 / 0.216 / 0.215 / 0.221,
+    // B = 8: 0.274 / 0.288 / 0.306 / 0.348,  B = 32: 0.494 / 0.554 / 0.624 / 0.785
+    if (lists) return blocks >= 384 ? 1 : 3;
+    int want = blocks >= 1536 ? 1 : blocks >= 768 ? 2 : blocks >= 192 ? 4 : 8;
     const int cap = (npix + kBlock - 1) / kBlock;
     if (want > cap) want = cap;
-    if (want < 2) want = 2;
-    if (want > 10) want = 10;          // more tiles = more partials for k_system_solve to reduce (latency mode)
-    // masked frames, small batches: a single instance measured 0.218 / 0.225 / 0.235 / 0.255 ms per solve for 5 / 8 / 10 / 15 tiles
-    if (lists && want > 5) want = 5;
+    if (want < 1) want = 1;
     // the block walk splits the image by rows of 8 x 8 blocks: tiles beyond ceil(rows / rows-per-tile) would be empty workgroups and
     // empty partials (160 x 120: 15 block rows, 10 tiles -> 2 rows per tile -> 8 tiles; a single instance: 0.301 -> 0.269 ms per solve)
-    if (!lists && Wd % 8 == 0 && Hd % 8 == 0) {
+    if (Wd % 8 == 0 && Hd % 8 == 0) {
         const int bh = Hd / 8, rows_per = (bh + want - 1) / want;
         want = (bh + rows_per - 1) / rows_per;
     }
@@ -703,10 +705,11 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // The chained launch (btba_kernels.hpp: k_chain): all Gauss-Newton iterations in ONE launch, the system solves handed over inside it.
     // Same sums in the same order as the plain schedule; taken for the batches it pays for and the configurations it is written for.
     const int chain_lay = zn_layout == 1 ? (compaction ? 3 : 1) : 0;
-    // (the library's own choice, chain = -1: batches of full frames from 16 instances on.  Object-masked frames walked through their valid-pixel lists
-    // have sweeps so short -- 53 us per iteration at c3 x 32 -- that an instance's next items come up before its 60 us in-launch solve is done:
-    // measured 0.74 against 0.52 ms per step, profiles/r04/chain_experiments.json; they keep the plain schedule unless chain = 1 asks)
-    const bool chain = chain_lay != 0 && !ws->chain_failed && ws->tune.chain != 0 && (ws->tune.chain > 0 || (B >= 16 && !compaction)) && use_sparse && use_dense && !wsi && !wdi
+    // Only on request (BTBA_OPT_CHAIN = 1).  Measured at c3 x 32 on one box (profiles/r04/chain_experiments.json): the chained launch with two tiles
+    // per pair 1.280 ms per step against 1.306 ms for the plain schedule with two tiles -- and 1.247 ms for the plain schedule with ONE tile, which the
+    // chained launch cannot use (1.314 ms: its sparse items come in bursts behind every instance's dense items instead of closing the launch).
+    // Object-masked frames: 0.74 against 0.52 ms (their sweeps are shorter than an in-launch solve).  The library's own choice is the plain schedule.
+    const bool chain = chain_lay != 0 && !ws->chain_failed && ws->tune.chain > 0 && use_sparse && use_dense && !wsi && !wdi
                        && !trace && !atomic_sums && !a_global && !D.pre_assembled && N <= kChainMaxFrames && chunks <= kChainMaxParts && tiles <= kChainMaxParts
                        && !(prm->flags & (BTBA_FLAG_NO_FUSE | BTBA_FLAG_OVERLAP)) && !Z.frame_slot
                        && lds_rest + 16 + sizeof(float) * chain_region_floats(N) <= kChainLdsBytes;      // (c3's 15 frames are the largest window whose solve fits a sweep workgroup's LDS share)

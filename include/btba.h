@@ -213,9 +213,10 @@ enum {
     BTBA_OPT_SPARSE_TAIL          = 9,  /* 0 .. 256: share (x / 256) of the sparse items that close the fused sweep instead of being interleaved (fills the launch's drain); -1 (default): 256 on full frames, 0 on object-masked ones. env BTBA_SPARSE_TAIL */
     BTBA_OPT_KEYED_CORR_MIN_BYTES = 8,  /* BTBA_FLAG_KEYED_CORR is ignored below this many bytes of correspondences (default 1 MiB). env of the same name */
     BTBA_OPT_CHAIN                = 10, /* the chained launch: ALL Gauss-Newton iterations of a batch in one launch, every instance's system solve handed
-                                           over inside the launch while the other instances' sweeps run (btba_kernels.hpp: k_chain).  -1 (default): batches
-                                           of >= 16 instances; 0: never; 1: every batch the launch supports (pinhole compact cache, sparse + dense terms,
-                                           <= 23 frames, no trace, deterministic sums).  Same bits as the plain schedule.                  env BTBA_CHAIN */
+                                           over inside the launch while the other instances' sweeps run (btba_kernels.hpp: k_chain).  0 (default) / -1: the
+                                           plain schedule (two launches per iteration) -- it measured faster once one tile per pair became the better
+                                           choice; 1: every batch the launch supports (pinhole compact cache, sparse + dense terms,
+                                           <= 15 frames, no trace, deterministic sums).  Same bits as the plain schedule with the same tile count.  env BTBA_CHAIN */
     BTBA_OPT_CHAIN_SPARSE_PERIOD  = 11, /* chained launch: 0 (default) an instance's sparse items follow its dense items; R >= 2: every R-th item of an
                                            instance is a sparse one.                                                               env BTBA_CHAIN_PERIOD */
     BTBA_OPT_CHAIN_TIMEOUT_MS     = 12, /* watchdog of the waits inside the chained launch (default 500 ms): see BTBA_ESCHED.        env BTBA_CHAIN_TIMEOUT_MS */

@@ -80,15 +80,17 @@ def c3x32():
 
 def test_the_benched_path_is_pinned(c3x32):
     """What `python bench.py` times: btba_solve_batch_zn_aux with B = 32 DISTINCT c3 instances, aux.corr24 (24-byte correspondences packed
-    from EntryJ), prebuilt block ranges, the library's own schedule (chained from 16 instances on) --
+    from EntryJ), prebuilt block ranges, the library's own schedule (the fused launch with ONE tile per pair, sparse items closing it) --
       (a) bit-identical to the EntryJ / no-aux call on the plain schedule, the configuration the other parity tests reach;
       (b) instances 0, 13 and 31 against the reference's own solveBundlingStub, < 1e-4 rad / m."""
     bt = c3x32
     benched, st = bt.solve(-1, corr24=True, aux=True)
-    assert st["chain_iterations"] == 7 and st["dense_tiles"] == 2 and st["sparse_chunks"] == 1, st
+    assert st["chain_iterations"] == 0 and st["dense_tiles"] == 1 and st["sparse_chunks"] == 1 and st["fused_sweeps"] == 1, st
     plain, st0 = bt.solve(0)
     assert st0["chain_iterations"] == 0
     assert np.array_equal(benched, plain), f"worst difference {np.abs(benched - plain).max():.3e}"
+    chained, st1 = bt.solve(1, corr24=True, aux=True)            # ... and the chained launch of the same batch, same tile count
+    assert st1["chain_iterations"] == 7 and np.array_equal(benched, chained)
     from oracle import reference as R
     if not os.path.exists(R.SO_SOLVER):
         pytest.skip("oracle/_ref/libbtba_ref_solver.so not built")
