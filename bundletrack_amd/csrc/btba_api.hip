@@ -69,6 +69,7 @@ struct btba_workspace {
     DevBuf block_ranges;                                    // per (frame, 8 x 8 block) usable depth range: dead-block test of the dense sweep
     DevBuf chain_sync;                                      // chained launch: flags[B] + arrivals[n_gn][B] (zeroed before every launch), optional timeline
     DevBuf chain_trace;
+    DevBuf corr24_tmp;                                      // re-layout of a call's EntryJ array written by its first iteration's sparse sweep (BTBA_OPT_RELAYOUT)
     DevBuf live_blocks;                                     // BTBA_OPT_COUNT_LIVE: one uint64 the block-walk workgroups add their walked blocks to
     bool count_live = false;
     int *chain_error = nullptr;                             // pinned host word the chained launch's watchdog raises (checked at every host synchronisation)
@@ -87,6 +88,8 @@ struct btba_workspace {
         bool overlap_equal_prio = false;   // BTBA_OPT_OVERLAP_EQUAL_PRIO (env BTBA_GROUP_PRIO=e...)
         size_t keyed_corr_min_bytes = (size_t)1 << 20;   // BTBA_OPT_KEYED_CORR_MIN_BYTES (env of the same name): below it the keyed correspondence cache is not used
         int chain = 0;                 // BTBA_OPT_CHAIN         (env BTBA_CHAIN): 1 = all Gauss-Newton iterations of a batch in ONE launch (k_chain) whenever the launch supports the solve; 0 (default) / -1 = the plain schedule
+        bool relayout = true;          // BTBA_OPT_RELAYOUT (env BTBA_NO_RELAYOUT=1 turns it off): a batch given as EntryJ is re-laid out to 24-byte records by its first iteration's sweep
+        int chain_group = 1;           // env BTBA_CHAIN_GROUP (developer A/B): instances per group of the chained launch's sequence (ChainDims::group)
         int chain_sparse_period = 0;   // BTBA_OPT_CHAIN_SPARSE_PERIOD (env BTBA_CHAIN_PERIOD): 0 = an instance's sparse items follow its dense items, R >= 2 = every R-th item is a sparse one
         int chain_timeout_ms = 500;    // BTBA_OPT_CHAIN_TIMEOUT_MS (env BTBA_CHAIN_TIMEOUT_MS): watchdog of the waits inside the chained launch
         int chain_solve_prio = 0;      // env BTBA_CHAIN_SOLVE_PRIO (developer A/B): s_setprio of the solve items' waves
@@ -223,6 +226,8 @@ static int workspace_create(btba_workspace **out, void *stream, bool use_given)
         if (const char *e = std::getenv("BTBA_KEYED_CORR_MIN_BYTES")) t.keyed_corr_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
         if (const char *e = std::getenv("BTBA_CHAIN")) t.chain = std::max(-1, std::min(1, std::atoi(e)));
         if (const char *e = std::getenv("BTBA_CHAIN_PERIOD")) t.chain_sparse_period = std::max(0, std::atoi(e));
+        t.relayout = !on("BTBA_NO_RELAYOUT");
+        if (const char *e = std::getenv("BTBA_CHAIN_GROUP")) t.chain_group = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("BTBA_CHAIN_TIMEOUT_MS")) t.chain_timeout_ms = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("BTBA_CHAIN_TRACE_FILE")) t.chain_trace_file = e;
         if (const char *e = std::getenv("BTBA_CHAIN_SOLVE_PRIO")) t.chain_solve_prio = std::max(0, std::min(3, std::atoi(e)));
@@ -249,7 +254,7 @@ void btba_workspace_destroy(btba_workspace *ws)
     for (auto e : ws->event_pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = { &ws->x, &ws->T, &ws->Tinv, &ws->sparse_part, &ws->dense_part, &ws->pairsum, &ws->dense_pairs, &ws->ptrs, &ws->big_A, &ws->solve_tab,
                        &ws->corr, &ws->offsets, &ws->poses, &ws->campos, &ws->normals, &ws->nvalid, &ws->valid_lists, &ws->valid_counts, &ws->block_ranges,
-                       &ws->chain_sync, &ws->chain_trace, &ws->live_blocks, &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc, &ws->corr_stage_dev, &ws->corr_lens };
+                       &ws->chain_sync, &ws->chain_trace, &ws->live_blocks, &ws->corr24_tmp, &ws->pool_zn, &ws->pool_lists, &ws->pool_counts, &ws->pool_nvalid, &ws->pool_map, &ws->pool_ranges, &ws->ransac, &ws->ransac_u, &ws->corr_pool, &ws->corr_desc, &ws->corr_stage_dev, &ws->corr_lens };
     for (auto b : bufs) b->release();
     if (ws->corr_stage) (void)hipHostFree(ws->corr_stage);
     if (ws->chain_error) (void)hipHostFree(ws->chain_error);
@@ -283,6 +288,7 @@ int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
     case BTBA_OPT_CHAIN: if (value < -1 || value > 1) return BTBA_EINVAL; t.chain = (int)value; break;
     case BTBA_OPT_CHAIN_SPARSE_PERIOD: if (value < 0 || value == 1 || value > 64) return BTBA_EINVAL; t.chain_sparse_period = (int)value; break;
     case BTBA_OPT_CHAIN_TIMEOUT_MS: if (value < 1 || value > 60000) return BTBA_EINVAL; t.chain_timeout_ms = (int)value; break;
+    case BTBA_OPT_RELAYOUT: t.relayout = value != 0; break;
     case BTBA_OPT_COUNT_LIVE:
         ws->count_live = value != 0;
         if (ws->count_live) {
@@ -713,6 +719,13 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                        && !trace && !atomic_sums && !a_global && !D.pre_assembled && N <= kChainMaxFrames && chunks <= kChainMaxParts && tiles <= kChainMaxParts
                        && !(prm->flags & (BTBA_FLAG_NO_FUSE | BTBA_FLAG_OVERLAP)) && !Z.frame_slot
                        && lds_rest + 16 + sizeof(float) * chain_region_floats(N) <= kChainLdsBytes;      // (c3's 15 frames are the largest window whose solve fits a sweep workgroup's LDS share)
+    // Fresh matches arrive as EntryJ (32 B, the wire format).  A solve reads them once per Gauss-Newton iteration, so from the second
+    // iteration on it pays to stream 24-byte records (the frame indices are implied by the pair-major segment): the FIRST iteration's sparse
+    // sweep writes them as the entries pass by (SolveDims::corr24_out) -- no separate pack pass over the array (btba_pack_correspondences24:
+    // 65 us + a launch at c3 x 32, 7 % of a step; the fused re-layout costs the first launch ~15 us and saves the others ~6 us each).
+    const bool relayout = ws->tune.relayout && use_sparse && !corr24 && !pair_lens && !chain && prm->n_gn_iters >= 3 && !atomic_sums
+                          && (size_t)B * (size_t)corr_stride * sizeof(btba_entryj) >= ((size_t)4 << 20);
+    if (relayout) { if ((rc = ws->corr24_tmp.ensure(sizeof(float2) * 192 * (((size_t)B * (size_t)corr_stride + 63) / 64)))) return rc; }
     ChainDims Cn{};
     int plain_pairsum_in_lds = 0;
     auto pad32 = [](size_t floats) { return (floats + 31) & ~(size_t)31; };      // whole 128-byte lines
@@ -729,6 +742,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         Cn.sparse_period = (unsigned)ws->tune.chain_sparse_period;
         if (Cn.sparse_period >= 2u && Cn.sparse_period * Cn.items_s > Cn.items_d + Cn.items_s) Cn.sparse_period = (Cn.items_d + Cn.items_s) / Cn.items_s;      // all sparse items must find a slot
         if (Cn.sparse_period < 2u) Cn.sparse_period = 0u;
+        Cn.group = (Cn.sparse_period == 0u && ws->tune.chain_group > 1 && Cn.inst_per_xcd % (unsigned)ws->tune.chain_group == 0u && B % 8 == 0) ? (unsigned)ws->tune.chain_group : 1u;
         Cn.timeout_ticks = (long long)ws->tune.chain_timeout_ms * 100000ll;
         Cn.solve_prio = ws->tune.chain_solve_prio;
         Cn.debug_skip = ws->tune.chain_debug_skip;
@@ -910,7 +924,9 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             const uint32_t *vl_h = compaction ? lists_base + b0 * N * npix : nullptr;
             const int *vc_h = compaction ? counts_base + b0 * N : nullptr;
             // (24-byte correspondences live in 64-entry groups counted from the start of the array: the half keeps the array's base and its first instance's entry offset)
-            const float4 *corr_h = corr ? (corr24 ? reinterpret_cast<const float4 *>(corr) : reinterpret_cast<const float4 *>(corr) + 2 * b0 * (size_t)corr_stride) : nullptr;
+            const bool c24_it = corr24 || (relayout && it > 0);      // this iteration reads 24-byte records (the caller's, or the ones iteration 0 wrote)
+            const float4 *corr_h = corr ? (corr24 ? reinterpret_cast<const float4 *>(corr) : (relayout && it > 0) ? ws->corr24_tmp.as<float4>()
+                                                  : reinterpret_cast<const float4 *>(corr) + 2 * b0 * (size_t)corr_stride) : nullptr;
             const uint32_t *off_h = pair_offsets ? pair_offsets + b0 * (P + 1) : nullptr;
             float *x_h = ws->x.as<float>() + 6 * b0 * N, *T_h = ws->T.as<float>() + 16 * b0 * N, *Ti_h = ws->Tinv.as<float>() + 16 * b0 * N;
             float *sp_h = ws->sparse_part.as<float>() + b0 * P * (atomic_sums ? 1 : chunks) * kSparseVals;
@@ -920,7 +936,9 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             size_t slot;
             SolveDims Dh = Di;                                  // the sweeps' view of this half
             if (Dh.pair_lens) Dh.pair_lens += b0 * P;
-            Dh.corr_entry0 = corr24 ? (int64_t)b0 * corr_stride : 0;
+            Dh.corr24 = c24_it ? 1 : 0;
+            Dh.corr_entry0 = (c24_it || relayout) ? (int64_t)b0 * corr_stride : 0;
+            Dh.corr24_out = (relayout && it == 0) ? ws->corr24_tmp.as<float2>() : nullptr;
             if (Dh.block_ranges) Dh.block_ranges += b0 * N * (size_t)((Wd / 8) * (Hd / 8));
 #ifdef BTBA_WG_TRACE
             static DevBuf wg_trace_buf;

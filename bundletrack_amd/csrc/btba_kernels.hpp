@@ -95,6 +95,8 @@ struct SolveDims {
     // shared by two regions that different workgroups publish at different times.
     int pose_stride, x_stride;
     unsigned sp_stride, dp_stride;      // (32-bit: an instance's partials are a few MB at most; 64-bit strides cost the short masked / sparse items ~100 scalar instructions)
+    float2 *corr24_out;  // non-null (EntryJ sweeps only): the sweep also WRITES every entry it reads as a 24-byte record (corr24_index layout, entry index counted from
+                         // corr_entry0 + b * corr_stride): the first iteration of a solve re-lays the caller's fresh EntryJ array out for the iterations that follow
     unsigned long long *live_blocks;   // non-null (BTBA_OPT_COUNT_LIVE, bench.py's roofline.executed): every block-walk workgroup adds the number of 8 x 8 blocks it walks
     int publish;         // k_chain: sweep workgroups store their partial records write-through (agent scope) -- another workgroup of the SAME launch reads them
 };
@@ -356,10 +358,18 @@ __device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const floa
     } else {
         const float4 *cb = corr + 2 * (size_t)b * D.corr_stride;
         bool misplaced = false;                       // an entry whose (imgIdx_i, imgIdx_j) is not this segment's pair
-        auto entry = [&](const float4 &q0, const float4 &q1, bool live) {
+        float2 *const c24 = D.corr24_out;             // (wave-uniform) the re-layout of the first iteration: k_pack_corr24_batch's records, written as the entries pass by
+        const size_t e_out = (size_t)D.corr_entry0 + (size_t)b * (size_t)D.corr_stride;
+        auto entry = [&](const float4 &q0, const float4 &q1, bool live, uint32_t e) {
             // q0 = (imgIdx_i, imgIdx_j, pos_i.x, pos_i.y)  q1 = (pos_i.z, pos_j.x, pos_j.y, pos_j.z)
             const bool valid = live && __float_as_uint(q0.x) != 0xFFFFFFFFu;      // EntryJ::isValid
             misplaced |= valid & ((__float_as_uint(q0.x) != (uint32_t)fi) | (__float_as_uint(q0.y) != (uint32_t)fj));
+            if (c24 && live) {
+                float2 *o = c24 + corr24_index(e_out + e);
+                o[0] = make_float2(valid ? q0.z : __uint_as_float(0xFFFFFFFFu), q0.w);
+                o[64] = make_float2(q1.x, q1.y);
+                o[128] = make_float2(q1.z, q1.w);
+            }
             accumulate(valid, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w);
         };
         for (uint32_t e = lo + tid; e < hi; e += 2 * kBlock) {
@@ -367,8 +377,8 @@ __device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const floa
             const bool live2 = e2 < hi;
             const uint32_t e2c = live2 ? e2 : e;
             const float4 a0 = cb[2 * (size_t)e], a1 = cb[2 * (size_t)e + 1], b0 = cb[2 * (size_t)e2c], b1 = cb[2 * (size_t)e2c + 1];
-            entry(a0, a1, true);
-            entry(b0, b1, live2);
+            entry(a0, a1, true, e);
+            entry(b0, b1, live2, e2c);
         }
         if (D.order_flag && misplaced) atomicOr(D.order_flag, 1);
     }
@@ -2308,6 +2318,8 @@ struct ChainDims {
     unsigned inst_per_xcd;      // ceil(B / 8): instance b lives on XCD b / inst_per_xcd
     unsigned items_d, items_s;  // sweep items per (instance, iteration): dense_tiles * Pd, sparse_chunks * P
     unsigned sparse_period;     // 0: an instance's sparse items follow its dense items; R >= 2: every R-th slot of the instance is a sparse item until they are used up
+    unsigned group;             // instances per GROUP of an XCD's sequence (sparse_period = 0): [dense items of the group's instances][their sparse items][their solve
+                                // items] -- the short sparse items then come in fewer, longer runs (1: after every instance; inst_per_xcd: once per iteration)
     int *flags;                 // [B] published iterate of every instance (0 = the k_prepare output): what a waiting wave polls (L2, never a cache above it)
     const int *published;       // [n_iter + 1][B][16]: word 0 of line (e, b) becomes 1 when iterate e of instance b is published -- one 64-byte line per word,
                                 // read through the scalar cache: a line that says 1 was fetched after the publication, a line that says 0 may be stale (-> poll flags[b])
@@ -2359,7 +2371,16 @@ __global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_chain(SolveDims D,
     const unsigned g = blockIdx.x, xcd = g & 7u, sg = g >> 3;
     const unsigned n_sweep = Cn.items_d + Cn.items_s, slots_per_inst = n_sweep + 1u, per_iter = Cn.inst_per_xcd * slots_per_inst;
     const unsigned it = sg / per_iter, s = sg - it * per_iter;
-    const unsigned k = s / slots_per_inst, r = s - k * slots_per_inst;
+    unsigned k = s / slots_per_inst, r = s - k * slots_per_inst;
+    if (Cn.group > 1u) {
+        // groups of `group` instances (the host makes inst_per_xcd a multiple of it): position inside the group -> (instance, kind, index)
+        const unsigned per_group = Cn.group * slots_per_inst, gi = s / per_group, rg = s - gi * per_group;
+        unsigned kg, rr;
+        if (rg < Cn.group * Cn.items_d) { kg = rg / Cn.items_d; rr = rg - kg * Cn.items_d; }
+        else if (rg < Cn.group * n_sweep) { const unsigned q = rg - Cn.group * Cn.items_d; kg = q / Cn.items_s; rr = Cn.items_d + (q - kg * Cn.items_s); }
+        else { kg = rg - Cn.group * n_sweep; rr = n_sweep; }
+        k = gi * Cn.group + kg; r = rr;
+    }
     const int b = (int)(xcd * Cn.inst_per_xcd + k);
     if (b >= Cn.n_inst) return;
     const unsigned tid = item_tid();

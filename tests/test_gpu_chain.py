@@ -27,12 +27,13 @@ class Batch:
         self.poses0 = torch.from_numpy(np.stack([pb.poses_init for pb in pbs])).to(self.dev)
         self.masked = masked
 
-    def solve(self, chain, corr24=False, aux=False, tiles=0, period=0, timeout_ms=None):
+    def solve(self, chain, corr24=False, aux=False, tiles=0, period=0, timeout_ms=None, relayout=True):
         """-> (poses [B, N, 4, 4], stats).  chain: BTBA_OPT_CHAIN (-1 library's choice, 0 plain schedule, 1 chained wherever supported)."""
         from bundletrack_amd.optimizer import BatchSolver, Workspace
         ws = Workspace()
         ws.set_option(_lib.OPT_CHAIN, chain)
         ws.set_option(_lib.OPT_CHAIN_SPARSE_PERIOD, period)
+        ws.set_option(_lib.OPT_RELAYOUT, 1 if relayout else 0)
         if timeout_ms is not None:
             ws.set_option(_lib.OPT_CHAIN_TIMEOUT_MS, timeout_ms)
         bs = BatchSolver(ws)
@@ -86,9 +87,11 @@ def test_the_benched_path_is_pinned(c3x32):
     bt = c3x32
     benched, st = bt.solve(-1, corr24=True, aux=True)
     assert st["chain_iterations"] == 0 and st["dense_tiles"] == 1 and st["sparse_chunks"] == 1 and st["fused_sweeps"] == 1, st
-    plain, st0 = bt.solve(0)
+    plain, st0 = bt.solve(0)                                     # EntryJ in: re-laid out by the first iteration's sweep (BTBA_OPT_RELAYOUT), what bench.py's value_incl_pack times
     assert st0["chain_iterations"] == 0
     assert np.array_equal(benched, plain), f"worst difference {np.abs(benched - plain).max():.3e}"
+    wire, _ = bt.solve(0, relayout=False)                        # ... and with every iteration reading the 32-byte wire format
+    assert np.array_equal(benched, wire)
     chained, st1 = bt.solve(1, corr24=True, aux=True)            # ... and the chained launch of the same batch, same tile count
     assert st1["chain_iterations"] == 7 and np.array_equal(benched, chained)
     from oracle import reference as R
