@@ -84,12 +84,16 @@ def _lib_entryj():
     return _lib.ENTRYJ_DTYPE
 
 
+SOLVER_SOURCES = ("btba_kernels.hpp", "btba_device.hpp", "btba_api.hip")      # what the sweep / solve kernels are built from
+
+
 def kernel_source_hash():
-    """sha256 over the sources libbtba.so is built from: counter summaries under profiles/ are only quoted for the kernels they were taken on."""
+    """sha256 over the SOLVER's sources (the sweep and solve kernels and the code that launches them): counter summaries under profiles/ are only
+    quoted for the kernels they were taken on -- an edit of the image or RANSAC kernels does not invalidate them."""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, "bundletrack_amd", "csrc")
-    for f in sorted(os.listdir(src)) + ["../../include/btba.h"]:
+    for f in SOLVER_SOURCES:
         h.update(open(os.path.join(src, f), "rb").read())
     return h.hexdigest()[:16]
 

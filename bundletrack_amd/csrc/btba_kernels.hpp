@@ -324,7 +324,11 @@ __device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const floa
         wjx = m != 0.0f ? wjx : 0.0f; wjy = m != 0.0f ? wjy : 0.0f; wjz = m != 0.0f ? wjz : 0.0f;
         const float rx = wix - wjx, ry = wiy - wjy, rz = wiz - wjz;
         const float e2 = rx * rx + ry * ry + rz * rz;
+#ifdef BTBA_EXACT_DIV
+        const float rho = m * ((e2 <= delta2) ? 1.0f : D.robust_delta / sqrtf(e2));
+#else
         const float rho = m * ((e2 <= delta2) ? 1.0f : D.robust_delta * __builtin_amdgcn_rsqf(e2));
+#endif
         acc[0] += m;
         acc[1] += wix; acc[2] += wiy; acc[3] += wiz;
         acc[4] += wjx; acc[5] += wjy; acc[6] += wjz;
@@ -440,8 +444,15 @@ __global__ void __launch_bounds__(kBlock) k_sparse_sweep(SolveDims D, const floa
 // The reference is built with nvcc -use_fast_math (CMakeLists.txt:7): its divisions, sqrt and rsqrt are the
 // approximate hardware forms.  v_rcp_f32 / v_rsq_f32 (1 ulp) are the CDNA counterparts; an IEEE division
 // costs ~10 VALU instructions and this kernel had ~25 of them per pixel.
+// -DBTBA_EXACT_DIV (an EXPERIMENT build, scripts/exact_div_experiment.py -- never the product): IEEE division and square root instead, to measure
+// how much of the difference between this path's accept decisions and the oracle's the 1-ulp forms explain (profiles/r04/exact_div_experiment.json).
+#ifdef BTBA_EXACT_DIV
+__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float fast_rsq(float x) { return 1.0f / sqrtf(x); }
+#else
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+#endif
 
 // XCD-aware remap of a 1-D grid: the dispatcher places block L on XCD L % 8 (observed, used for speed only),
 // so logical work item L' = (contiguous range per XCD) keeps one instance's frames in ONE XCD's L2 instead of

@@ -8,22 +8,22 @@
 #            (the calibrated VALU-busy measurement, profiles/r02/valu_calibration.md)
 # Usage: scripts/profile_bench.sh <tag> [bench args, e.g. --masked | --config c4]     then: python scripts/summarize_profiles.py <tag> <version> [same bench args]
 set -u
-TAG=${1:-r03}; shift || true
+TAG=${1:-r04}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-export BTBA_BENCH_CACHE=/tmp/bench_instances_$TAG.pkl      # the passes share one set of generated instances
+export BTBA_BENCH_CACHE=/tmp/bench_instances_$TAG.npz      # the passes share one set of generated instances
 echo "bench args: $*" > "$OUT/args.txt"
 # instances generated once, by a plain run (child processes allowed), before any profiler is attached
-BTBA_BENCH_NPROC=8 timeout 300 python "$REPO/bench.py" --no-cpu-baseline --steps 2 --warmup 1 $* > "$OUT/pre.log" 2>&1
+BTBA_BENCH_NPROC=8 timeout 300 python "$REPO/bench.py" --no-cpu-baseline --steps 2 --warmup 1 --settle-ms 0 $* > "$OUT/pre.log" 2>&1
 echo "pre rc=$?" >> "$OUT/pre.log"
 export BTBA_BENCH_NPROC=1
 # the stats pass runs bench.py's DEFAULT step counts, so that the kernel durations are taken at the same clocks as the bench line
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$REPO/bench.py" --no-cpu-baseline $* > "$OUT/stats.log" 2>&1
 echo "stats rc=$?" >> "$OUT/stats.log"
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing $*"
+ARGS="--steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-kernel-timing $*"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o bench -- python "$REPO/bench.py" $ARGS > "$OUT/fetch.log" 2>&1
 echo "fetch rc=$?" >> "$OUT/fetch.log"
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o bench -- python "$REPO/bench.py" $ARGS > "$OUT/write.log" 2>&1
