@@ -287,6 +287,7 @@ def main():
     ap.add_argument("--corr24", action="store_true", help="24-byte records also with --masked (default there: EntryJ, which measured 4 %% faster on the masked launch: profiles/r03)")
     ap.add_argument("--settle-ms", type=float, default=200.0, help="untimed steps run for this long BEFORE the --warmup steps: a process that has just started finds the GPU at idle clocks, and "
                                                                     "5 warm-up steps (7 ms) do not ramp them -- the same command measured 5 %% slower at --steps 20 than at --steps 250 (0 disables)")
+    ap.add_argument("--no-incl-pack", action="store_true", help="skip the second timed region (value_incl_pack): profiling passes, whose per-kernel averages must be those of the first region")
     ap.add_argument("--baseline-n1", type=float, default=None, help="the N = 1 value of the same command: rank 0 then also reports efficiency = value / (N x this)")
     args = ap.parse_args()
 
@@ -392,7 +393,7 @@ def main():
     # the solve the EntryJ array (already in HBM): the library re-lays it out inside the first iteration's sweep (BTBA_OPT_RELAYOUT) and streams the
     # 24-byte records from the second iteration on -- nothing is prepared outside the timed region.
     seconds_incl_pack = None
-    if use_c24:
+    if use_c24 and not args.no_incl_pack:
         aux_fresh = {k: v for k, v in aux_d.items() if k != "corr24"}
         def step_incl_pack():                               # (same flags as the first region: its hipEvent brackets are part of both)
             poses_d.copy_(poses0)
