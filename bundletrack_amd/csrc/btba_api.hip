@@ -723,7 +723,9 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // iteration on it pays to stream 24-byte records (the frame indices are implied by the pair-major segment): the FIRST iteration's sparse
     // sweep writes them as the entries pass by (SolveDims::corr24_out) -- no separate pack pass over the array (btba_pack_correspondences24:
     // 65 us + a launch at c3 x 32, 7 % of a step; the fused re-layout costs the first launch ~15 us and saves the others ~6 us each).
-    const bool relayout = ws->tune.relayout && use_sparse && !corr24 && !pair_lens && !chain && prm->n_gn_iters >= 3 && !atomic_sums
+    // (not on object-masked frames walked through valid-pixel lists: their fused launch is short and latency-bound, and it measured FASTER on the
+    // 32-byte entries -- 49.1 against 51.2 us, profiles/r03 -- before the re-layout's extra write in the first iteration: 454 k -> 402 k GN it/s with it)
+    const bool relayout = ws->tune.relayout && use_sparse && !corr24 && !pair_lens && !chain && prm->n_gn_iters >= 3 && !atomic_sums && !compaction
                           && (size_t)B * (size_t)corr_stride * sizeof(btba_entryj) >= ((size_t)4 << 20);
     if (relayout) { if ((rc = ws->corr24_tmp.ensure(sizeof(float2) * 192 * (((size_t)B * (size_t)corr_stride + 63) / 64)))) return rc; }
     ChainDims Cn{};

@@ -1822,10 +1822,11 @@ __device__ __forceinline__ void system_solve_body(const SolveDims &D, int iter, 
     // items per lane per trip: one trip covers the c3 window (105 pairs: 4 620 sparse / 2 940 dense sums over 1 024 lanes).  (Reducing both kinds at
     // the same time on disjoint groups of waves -- one round of fabric-latency loads instead of two -- measured 0.5 us SLOWER per launch, r03 call 39.)
     // (k_chain: 256 lanes under the sweep's 80-register budget and at most two partials per sum -- more items per lane, narrower rounds)
-    if (CHAIN) {
-        // 256 lanes, at most two partials per sum (kChainMaxParts): 16-byte loads, and ALL of a lane's loads -- sparse and dense records -- issued before
-        // the first add: one round of fabric latency instead of the four of the scalar scheme above (6.4 -> ~2.5 us).  The same sums: 0 + first (+ second).
-        constexpr int kS4 = kSparseVals / 4, kD4 = kDenseVals / 4, kRounds = 6;          // a lane holds up to 6 sums of four: covers 15 frames (1 155 + 735 sums of four over 256 lanes = 7.4 -> two passes)
+    // Batches big enough to fill the chip run with one or two partials per sum (pick_chunks, pick_tiles): 16-byte loads then, and ALL of a lane's loads --
+    // sparse and dense records -- issued before the first add: ONE round of fabric latency instead of the two (plain kernel: sparse, then dense) or four
+    // (256-lane chained solve) of the scalar scheme below.  The same sums: 0 + first (+ second).  Chained solve 6.4 -> 4.5 us; plain kernel: see DESIGN.md 4.3.
+    if (CHAIN || (D.sparse_chunks <= 2 && D.dense_tiles <= 2 && !D.atomic_sums)) {
+        constexpr int kS4 = kSparseVals / 4, kD4 = kDenseVals / 4, kRounds = CHAIN ? 6 : 2;          // sums of four a lane holds per pass: 15 frames = 1 155 + 735 of them, 7.4 per lane of 256, 1.85 per lane of 1 024
         const int ns4 = D.use_sparse ? D.n_pairs * kS4 : 0, nd4 = D.use_dense ? D.n_dense_pairs * kD4 : 0;
         if (!D.use_sparse) for (int e = tid; e < D.n_pairs * kSparseVals; e += nthr) ps[e] = 0.0f;
         for (int e0 = tid; e0 < ns4 + nd4; e0 += kRounds * nthr) {
@@ -1848,8 +1849,10 @@ __device__ __forceinline__ void system_solve_body(const SolveDims &D, int iter, 
                 if (e >= ns4 + nd4) continue;
                 float4 sum = make_float4(0.0f + v0[u].x, 0.0f + v0[u].y, 0.0f + v0[u].z, 0.0f + v0[u].w);
                 if (two[u]) { sum.x += v1[u].x; sum.y += v1[u].y; sum.z += v1[u].z; sum.w += v1[u].w; }
-                float4 *dst = e < ns4 ? reinterpret_cast<float4 *>(ps) + e : reinterpret_cast<float4 *>(pd) + (e - ns4);
-                *dst = sum;
+                // (four scalar stores: the plain kernel's LDS copy of the pair sums is not 16-byte aligned; two branches, not a selected pointer: ps and pd
+                // may live in different address spaces, and a select between them sends this compiler's backend into an illegal instruction)
+                if (e < ns4) { float *dst = ps + 4 * (size_t)e; dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z; dst[3] = sum.w; }
+                else { float *dst = pd + 4 * (size_t)(e - ns4); dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z; dst[3] = sum.w; }
             }
         }
     } else {
