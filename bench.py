@@ -319,8 +319,6 @@ def main():
     note("instances ready; uploading")
     pick = [inst[b % n_distinct] for b in range(B)]
     ws = Workspace()
-    if args.entryj:
-        ws.set_option(_lib.OPT_RELAYOUT, 0)                 # --entryj: every iteration reads the 32-byte wire format
     bs = BatchSolver(ws, weight_dense_depth=cfg["w_dense"])
     if not args.no_kernel_timing:
         bs.params.flags |= _lib.FLAG_TIME_KERNELS | _lib.FLAG_TIME_SAMPLED      # one Gauss-Newton iteration of every solve is bracketed with hipEvents (rotating): every launch costs ~4 %
@@ -389,9 +387,9 @@ def main():
     st = ws.collect_stats()
     out_poses = poses_d.cpu().numpy()
     assert np.isfinite(out_poses).all(), "non-finite poses"
-    # What a tracker pays: its correspondences are NEW on every call, so the 24-byte re-layout is part of every solve.  Same steps again, handing
-    # the solve the EntryJ array (already in HBM): the library re-lays it out inside the first iteration's sweep (BTBA_OPT_RELAYOUT) and streams the
-    # 24-byte records from the second iteration on -- nothing is prepared outside the timed region.
+    # What a tracker pays: its correspondences are NEW on every call, so nothing about them can be prepared outside the call.  Same steps again,
+    # handing the solve the EntryJ array (already in HBM) as it is -- the library's default for fresh matches reads the 32-byte wire format in
+    # every iteration (an in-sweep re-layout, BTBA_OPT_RELAYOUT, and a separate pack pass both measured no better: profiles/r04/relayout.json).
     seconds_incl_pack = None
     if use_c24 and not args.no_incl_pack:
         aux_fresh = {k: v for k, v in aux_d.items() if k != "corr24"}
@@ -445,7 +443,7 @@ def main():
                        "gn_iters": int(bs.params.n_gn_iters), "pcg_iters": int(bs.params.n_pcg_iters),
                        "dense_tiles": st["dense_tiles"], "sparse_chunks": st["sparse_chunks"], "frame_cache": "float4 camPos + float4 normal (32 B/px)" if args.float4_cache else "compact z + normal (16 B/px)",
                        "correspondences": ("`value`: 24-byte records (pos_i, pos_j) resident in HBM, packed from EntryJ BEFORE the timed region; `value_incl_pack`: the same steps with the "
-                                           "EntryJ array handed to every solve, re-laid out by the first iteration's sweep inside the timed region (BTBA_OPT_RELAYOUT) -- what a tracker "
+                                           "EntryJ array (32-byte wire format) handed to every solve as it is, nothing prepared outside the timed region -- what a tracker "
                                            "with fresh matches on every call pays") if use_c24 else "EntryJ (32 B), every iteration",
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "value_incl_pack": round(value_incl_pack, 1) if value_incl_pack else None,

@@ -88,7 +88,7 @@ struct btba_workspace {
         bool overlap_equal_prio = false;   // BTBA_OPT_OVERLAP_EQUAL_PRIO (env BTBA_GROUP_PRIO=e...)
         size_t keyed_corr_min_bytes = (size_t)1 << 20;   // BTBA_OPT_KEYED_CORR_MIN_BYTES (env of the same name): below it the keyed correspondence cache is not used
         int chain = 0;                 // BTBA_OPT_CHAIN         (env BTBA_CHAIN): 1 = all Gauss-Newton iterations of a batch in ONE launch (k_chain) whenever the launch supports the solve; 0 (default) / -1 = the plain schedule
-        bool relayout = true;          // BTBA_OPT_RELAYOUT (env BTBA_NO_RELAYOUT=1 turns it off): a batch given as EntryJ is re-laid out to 24-byte records by its first iteration's sweep
+        bool relayout = false;         // BTBA_OPT_RELAYOUT (env BTBA_RELAYOUT=1 turns it on): a batch given as EntryJ is re-laid out to 24-byte records by its first iteration's sweep
         int chain_group = 1;           // env BTBA_CHAIN_GROUP (developer A/B): instances per group of the chained launch's sequence (ChainDims::group)
         int chain_sparse_period = 0;   // BTBA_OPT_CHAIN_SPARSE_PERIOD (env BTBA_CHAIN_PERIOD): 0 = an instance's sparse items follow its dense items, R >= 2 = every R-th item is a sparse one
         int chain_timeout_ms = 500;    // BTBA_OPT_CHAIN_TIMEOUT_MS (env BTBA_CHAIN_TIMEOUT_MS): watchdog of the waits inside the chained launch
@@ -226,7 +226,7 @@ static int workspace_create(btba_workspace **out, void *stream, bool use_given)
         if (const char *e = std::getenv("BTBA_KEYED_CORR_MIN_BYTES")) t.keyed_corr_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
         if (const char *e = std::getenv("BTBA_CHAIN")) t.chain = std::max(-1, std::min(1, std::atoi(e)));
         if (const char *e = std::getenv("BTBA_CHAIN_PERIOD")) t.chain_sparse_period = std::max(0, std::atoi(e));
-        t.relayout = !on("BTBA_NO_RELAYOUT");
+        t.relayout = on("BTBA_RELAYOUT");
         if (const char *e = std::getenv("BTBA_CHAIN_GROUP")) t.chain_group = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("BTBA_CHAIN_TIMEOUT_MS")) t.chain_timeout_ms = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("BTBA_CHAIN_TRACE_FILE")) t.chain_trace_file = e;
@@ -719,10 +719,11 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                        && !trace && !atomic_sums && !a_global && !D.pre_assembled && N <= kChainMaxFrames && chunks <= kChainMaxParts && tiles <= kChainMaxParts
                        && !(prm->flags & (BTBA_FLAG_NO_FUSE | BTBA_FLAG_OVERLAP)) && !Z.frame_slot
                        && lds_rest + 16 + sizeof(float) * chain_region_floats(N) <= kChainLdsBytes;      // (c3's 15 frames are the largest window whose solve fits a sweep workgroup's LDS share)
-    // Fresh matches arrive as EntryJ (32 B, the wire format).  A solve reads them once per Gauss-Newton iteration, so from the second
-    // iteration on it pays to stream 24-byte records (the frame indices are implied by the pair-major segment): the FIRST iteration's sparse
-    // sweep writes them as the entries pass by (SolveDims::corr24_out) -- no separate pack pass over the array (btba_pack_correspondences24:
-    // 65 us + a launch at c3 x 32, 7 % of a step; the fused re-layout costs the first launch ~15 us and saves the others ~6 us each).
+    // Fresh matches arrive as EntryJ (32 B, the wire format).  A solve reads them once per Gauss-Newton iteration; with BTBA_OPT_RELAYOUT the FIRST
+    // iteration's sparse sweep writes 24-byte records as the entries pass by (SolveDims::corr24_out) and the other iterations stream those -- no separate
+    // pack pass (btba_pack_correspondences24: 65 us + a launch at c3 x 32, 7 % of a step).  Measured (profiles/r04/relayout.json): the first launch's
+    // extra 161 MB of writes (+55 us, the launch's sparse tail is HBM-bound) cost what six launches save by reading 24 instead of 32 bytes:
+    // 1.286 / 1.300 ms per step against 1.297 / 1.287 ms with EntryJ in every iteration on two boxes -- a wash, so it is OFF by default.
     // (not on object-masked frames walked through valid-pixel lists: their fused launch is short and latency-bound, and it measured FASTER on the
     // 32-byte entries -- 49.1 against 51.2 us, profiles/r03 -- before the re-layout's extra write in the first iteration: 454 k -> 402 k GN it/s with it)
     const bool relayout = ws->tune.relayout && use_sparse && !corr24 && !pair_lens && !chain && prm->n_gn_iters >= 3 && !atomic_sums && !compaction

@@ -220,9 +220,9 @@ enum {
     BTBA_OPT_CHAIN_SPARSE_PERIOD  = 11, /* chained launch: 0 (default) an instance's sparse items follow its dense items; R >= 2: every R-th item of an
                                            instance is a sparse one.                                                               env BTBA_CHAIN_PERIOD */
     BTBA_OPT_CHAIN_TIMEOUT_MS     = 12, /* watchdog of the waits inside the chained launch (default 500 ms): see BTBA_ESCHED.        env BTBA_CHAIN_TIMEOUT_MS */
-    BTBA_OPT_RELAYOUT             = 14, /* 1 (default): a batch whose correspondences arrive as EntryJ (4 MiB or more, three iterations or more) is re-laid out to
-                                           24-byte records BY ITS FIRST ITERATION'S SWEEP, and the other iterations stream those -- what a tracker with fresh matches on
-                                           every call pays instead of a separate btba_pack_correspondences24 pass; 0: every iteration reads EntryJ.  Same bits.  env BTBA_NO_RELAYOUT */
+    BTBA_OPT_RELAYOUT             = 14, /* 1: a batch whose correspondences arrive as EntryJ (4 MiB or more, three iterations or more, full frames) is re-laid out to
+                                           24-byte records BY ITS FIRST ITERATION'S SWEEP, and the other iterations stream those; 0 (default): every iteration reads
+                                           EntryJ.  Same bits; measured a wash at c3 x 32 (the first launch's extra writes cost what the others save).  env BTBA_RELAYOUT */
     BTBA_OPT_COUNT_LIVE           = 13  /* 1: the dense sweep's block-walk workgroups add the number of 8 x 8 pixel blocks they actually walk (the blocks the hull
                                            test could not prove dead) to a counter of the workspace -- setting the option clears it, btba_workspace_live_blocks
                                            reads it.  Measurement aid (bench.py: roofline.executed); one atomic per workgroup while it is on. */

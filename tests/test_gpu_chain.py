@@ -87,10 +87,10 @@ def test_the_benched_path_is_pinned(c3x32):
     bt = c3x32
     benched, st = bt.solve(-1, corr24=True, aux=True)
     assert st["chain_iterations"] == 0 and st["dense_tiles"] == 1 and st["sparse_chunks"] == 1 and st["fused_sweeps"] == 1, st
-    plain, st0 = bt.solve(0)                                     # EntryJ in: re-laid out by the first iteration's sweep (BTBA_OPT_RELAYOUT), what bench.py's value_incl_pack times
+    plain, st0 = bt.solve(0)                                     # EntryJ in, re-laid out to 24-byte records by the first iteration's sweep (BTBA_OPT_RELAYOUT = 1)
     assert st0["chain_iterations"] == 0
     assert np.array_equal(benched, plain), f"worst difference {np.abs(benched - plain).max():.3e}"
-    wire, _ = bt.solve(0, relayout=False)                        # ... and with every iteration reading the 32-byte wire format
+    wire, _ = bt.solve(0, relayout=False)                        # ... and with every iteration reading the 32-byte wire format (the default; what bench.py's value_incl_pack times)
     assert np.array_equal(benched, wire)
     chained, st1 = bt.solve(1, corr24=True, aux=True)            # ... and the chained launch of the same batch, same tile count
     assert st1["chain_iterations"] == 7 and np.array_equal(benched, chained)

@@ -63,3 +63,28 @@ def test_two_rank_gloo_gather():
 def test_single_process_needs_no_group():
     assert sharding.gather_throughput(2.0, 14.0) == [(2.0, 14.0)]
     assert sharding.aggregate([(2.0, 14.0)]) == (7.0, 2.0)
+
+
+def test_rank_cpu_binding_is_disjoint_and_reversible():
+    """bench.py binds every rank of a node to its own CPUs (eight launcher threads must not share one quota).  The binding of two local ranks is
+    disjoint, never leaves the set the process was allowed, reports what it did, and a single rank is left alone."""
+    import os
+    from bundletrack_amd import sharding
+    if not hasattr(os, "sched_getaffinity"):
+        return
+    allowed = set(os.sched_getaffinity(0))
+    try:
+        assert sharding.bind_rank_to_cpus(0, 1)["bound"] is False
+        got = []
+        for r in range(2):
+            os.sched_setaffinity(0, allowed)
+            info = sharding.bind_rank_to_cpus(r, 2, gpu_index=None)
+            if len(allowed) < 4:
+                assert info["bound"] is False
+                return
+            assert info["bound"] is True and info["cpus"] >= 1
+            got.append(set(os.sched_getaffinity(0)))
+            assert got[-1] <= allowed
+        assert not (got[0] & got[1])
+    finally:
+        os.sched_setaffinity(0, allowed)
