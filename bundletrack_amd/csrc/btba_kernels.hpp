@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(kBlock) k_sparse_sweep(SolveDims D, const floa
 // The reference is built with nvcc -use_fast_math (CMakeLists.txt:7): its divisions, sqrt and rsqrt are the
 // approximate hardware forms.  v_rcp_f32 / v_rsq_f32 (1 ulp) are the CDNA counterparts; an IEEE division
 // costs ~10 VALU instructions and this kernel had ~25 of them per pixel.
-// -DBTBA_EXACT_DIV (an EXPERIMENT build, scripts/exact_div_experiment.py -- never the product): IEEE division and square root instead, to measure
+// -DBTBA_EXACT_DIV (an EXPERIMENT build, tests/tools/exact_div_experiment.py -- never the product): IEEE division and square root instead, to measure
 // how much of the difference between this path's accept decisions and the oracle's the 1-ulp forms explain (profiles/r04/exact_div_experiment.json).
 #ifdef BTBA_EXACT_DIV
 __device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }

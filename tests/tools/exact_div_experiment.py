@@ -2,8 +2,8 @@
 """How much of the HIP path's disagreement with the oracle's DECISIONS is due to its 1-ulp reciprocal / reciprocal square root (v_rcp_f32, v_rsq_f32:
 the counterpart of the reference's own -use_fast_math, CMakeLists.txt:7) and how much to its re-ordered arithmetic?  GPU box, one library per process:
 
-    BTBA_LIB_PATH=build/ab/exactdiv.so python scripts/exact_div_experiment.py 120 > gpurun_out/exact_div_exact.jsonl
-                                       python scripts/exact_div_experiment.py 120 > gpurun_out/exact_div_product.jsonl
+    BTBA_LIB_PATH=build/ab/exactdiv.so python tests/tools/exact_div_experiment.py 120 > gpurun_out/exact_div_exact.jsonl
+                                       python tests/tools/exact_div_experiment.py 120 > gpurun_out/exact_div_product.jsonl
 
 Runs the 120 windows of tests/tools/fuzz_parity.py with both traces for EVERY case and prints per case: the final pose difference, the first
 decision the two sides take differently (tests/helpers.py: an accepted-pixel count of a dense pair, or a PCG epsilon guard), the number of
@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
