@@ -22,6 +22,7 @@ def main():
     dev = torch.device("cuda:0")
     ws = Workspace()
     bs = BatchSolver(ws)
+    bs.params.dense_tiles = int(os.environ.get("BTBA_BENCH_TILES", "0"))          # 0 = the library's choice
     corr, offs, mx = bs.pack_correspondences([p["corr"] for p in pick], 15)
     zn_d = torch.from_numpy(np.stack([p["zn"] for p in pick])).to(dev)
     corr_d = torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(dev); offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)

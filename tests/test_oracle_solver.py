@@ -173,3 +173,26 @@ def test_golden_regression(oracle, path):
     assert np.array_equal(tr.dense_count, g["dense_count"])
     assert np.allclose(tr.T_after, g["T_after"], atol=1e-6)
     assert np.allclose(tr.poses, g["poses_out"], atol=1e-6)
+
+
+def test_bench_parity_leg_accepts_the_oracle_and_rejects_a_moved_pose():
+    """bench.py's `parity` field: the timed run's output poses of a few instances against the oracle.  Fed the oracle's own result it reports ~0 and ok;
+    with one frame rotated by 1e-3 rad it must report that and fail the bar (bench.py then exits non-zero)."""
+    import bench
+    from bundletrack_amd import synthetic as S
+    cfg = dict(K=3, m=40, w_dense=1.0)
+    insts = []
+    for seed in (3, 4):
+        pb = S.make_problem(cfg["K"], cfg["m"], seed, background=False, full_res=False)
+        campos, normals, intr = S.analytic_cache(pb)
+        insts.append(dict(campos=campos, normals=normals, intr=intr, corr=pb.corr, poses=pb.poses_init))
+    from oracle import oracle as O
+    ref = [O.solve(q["campos"], q["normals"], q["intr"], q["corr"], q["poses"], params=O.default_params(weight_dense_depth=1.0), want_trace=False).poses for q in insts]
+    out = np.stack([np.asarray(r, np.float32).reshape(cfg["K"], 4, 4) for r in ref])
+    good = bench.oracle_parity(cfg, insts, [0, 1], out)
+    assert good["ok"] and good["worst_rot"] < 1e-6 and good["instances"] == 2
+    moved = out.copy()
+    c, s = np.cos(1e-3), np.sin(1e-3)
+    moved[1, 2, :3, :3] = moved[1, 2, :3, :3] @ np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], np.float32)
+    bad = bench.oracle_parity(cfg, insts, [0, 1], moved)
+    assert not bad["ok"] and 5e-4 < bad["worst_rot"] < 2e-3
