@@ -88,6 +88,9 @@ struct btba_workspace {
         bool overlap_equal_prio = false;   // BTBA_OPT_OVERLAP_EQUAL_PRIO (env BTBA_GROUP_PRIO=e...)
         size_t keyed_corr_min_bytes = (size_t)1 << 20;   // BTBA_OPT_KEYED_CORR_MIN_BYTES (env of the same name): below it the keyed correspondence cache is not used
         int chain = 0;                 // BTBA_OPT_CHAIN         (env BTBA_CHAIN): 1 = all Gauss-Newton iterations of a batch in ONE launch (k_chain) whenever the launch supports the solve; 0 (default) / -1 = the plain schedule
+        int corr_nt = -1;              // env BTBA_CORR_NT (developer; option 1003): non-temporal correspondence loads  1 always, 0 never, -1 (default) the library's choice (corr_nt_auto)
+        int corr_nt_partial = 1;       // env BTBA_CORR_NT_PARTIAL=0 (developer): all instances stream non-temporally once the batch exceeds the cache, not only those that do not fit
+        long long last_level_cache = 224ll << 20;   // env BTBA_LLC_MB: what of the 256 MB memory-side cache a batch's frames + correspondences may fill before the stream is read non-temporally
         bool relayout = false;         // BTBA_OPT_RELAYOUT (env BTBA_RELAYOUT=1 turns it on): a batch given as EntryJ is re-laid out to 24-byte records by its first iteration's sweep
         int chain_group = 1;           // env BTBA_CHAIN_GROUP (developer A/B): instances per group of the chained launch's sequence (ChainDims::group)
         int chain_sparse_period = 0;   // BTBA_OPT_CHAIN_SPARSE_PERIOD (env BTBA_CHAIN_PERIOD): 0 = an instance's sparse items follow its dense items, R >= 2 = every R-th item is a sparse one
@@ -227,6 +230,9 @@ static int workspace_create(btba_workspace **out, void *stream, bool use_given)
         if (const char *e = std::getenv("BTBA_CHAIN")) t.chain = std::max(-1, std::min(1, std::atoi(e)));
         if (const char *e = std::getenv("BTBA_CHAIN_PERIOD")) t.chain_sparse_period = std::max(0, std::atoi(e));
         t.relayout = on("BTBA_RELAYOUT");
+        if (const char *e = std::getenv("BTBA_CORR_NT")) t.corr_nt = std::atoi(e);
+        if (const char *e = std::getenv("BTBA_LLC_MB")) t.last_level_cache = (long long)std::atoll(e) << 20;
+        if (const char *e = std::getenv("BTBA_CORR_NT_PARTIAL")) t.corr_nt_partial = std::atoi(e);
         if (const char *e = std::getenv("BTBA_CHAIN_GROUP")) t.chain_group = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("BTBA_CHAIN_TIMEOUT_MS")) t.chain_timeout_ms = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("BTBA_CHAIN_TRACE_FILE")) t.chain_trace_file = e;
@@ -297,6 +303,7 @@ int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
             HIP_TRY(hipMemsetAsync(ws->live_blocks.p, 0, sizeof(unsigned long long), ws->stream));
         }
         break;
+    case 1003: t.corr_nt = (int)value; break;               // developer A/B: non-temporal correspondence loads  1 all, 0 none, -1 the library's choice (same bits either way)
     case 1000: t.chain_debug_skip = (int)value; break;      // developer timing experiments (ChainDims::debug_skip): not part of the ABI
     default: return BTBA_EINVAL;
     }
@@ -629,6 +636,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     D.depth_min = prm->depth_min; D.depth_max = prm->depth_max;
     D.w_sparse = prm->weight_sparse; D.w_dense = prm->weight_dense_depth;
     D.corr_stride = corr_stride;
+    D.corr_nt_from = B;                // plain loads unless decided otherwise below
     D.order_flag = order_flag;
     D.live_blocks = (ws->count_live && ws->live_blocks.p) ? ws->live_blocks.as<unsigned long long>() : nullptr;
     D.pose_stride = 16 * N; D.x_stride = 6 * N;                      // instances back to back (the chained launch pads them, below)
@@ -729,6 +737,20 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     const bool relayout = ws->tune.relayout && use_sparse && !corr24 && !pair_lens && !chain && prm->n_gn_iters >= 3 && !atomic_sums && !compaction
                           && (size_t)B * (size_t)corr_stride * sizeof(btba_entryj) >= ((size_t)4 << 20);
     if (relayout) { if ((rc = ws->corr24_tmp.ensure(sizeof(float2) * 192 * (((size_t)B * (size_t)corr_stride + 63) / 64)))) return rc; }
+    // Non-temporal correspondence loads (SolveDims::corr_nt).  Every iteration re-reads the batch's frames (dense items, through L2) and streams its
+    // correspondences once.  While both fit the memory-side cache (256 MB) the next iteration finds them there and plain loads are fastest (c3 x 8,
+    // c2 x 32, object-masked frames, which touch a few per cent of their pixels: non-temporal loads measured -2 ... -17 %); beyond it the cyclic stream
+    // evicts the frames, and reading it non-temporally keeps them resident: c3 x 32 (147 + 161 MB) 185.2 -> 195.2 k GN it/s, c4 x 32 +3.7 %
+    // (profiles/r04/nontemporal_stream.json).  Same bits.
+    const long long frames_bytes = use_dense ? (long long)B * N * npix * (use_zn ? 16 : 32) / (compaction ? 8 : 1) : 0;
+    const long long corr_bytes = use_sparse ? (long long)B * (long long)corr_stride * (corr24 ? 24 : 32) : 0;
+    const long long corr_per_instance = corr_bytes / B;
+    // instances from this index on stream non-temporally: all that does not fit beside the frames (everything when the frames alone exceed the cache)
+    int corr_nt_auto = B;
+    if (use_dense && use_sparse && frames_bytes + corr_bytes > ws->tune.last_level_cache)
+        corr_nt_auto = (frames_bytes >= ws->tune.last_level_cache || corr_per_instance <= 0) ? 0 : (int)std::min<long long>(B, (ws->tune.last_level_cache - frames_bytes) / corr_per_instance);
+    if (ws->tune.corr_nt_partial == 0 && corr_nt_auto < B) corr_nt_auto = 0;
+    const int corr_nt_from = ws->tune.corr_nt >= 0 ? (ws->tune.corr_nt ? 0 : B) : corr_nt_auto;
     ChainDims Cn{};
     int plain_pairsum_in_lds = 0;
     auto pad32 = [](size_t floats) { return (floats + 31) & ~(size_t)31; };      // whole 128-byte lines
@@ -737,6 +759,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         D.pose_stride = (int)pad32(16 * (size_t)N); D.x_stride = (int)pad32(6 * (size_t)N);
         D.sp_stride = (unsigned)pad32((size_t)P * chunks * kSparseVals); D.dp_stride = (unsigned)pad32((size_t)Pd * tiles * kDenseVals);
         D.publish = 1;
+        D.corr_nt_from = corr_nt_from;
         plain_pairsum_in_lds = D.pairsum_in_lds;
         D.pairsum_in_lds = 0;
         Cn.last_solve_external = 1;
@@ -958,6 +981,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
             // two fill each other's idle pipes -- measured at c3 (scripts/ab_dense.py, fused vs separate step time):
             // B=1 0.486 / 0.554 ms, B=8 0.871 / 0.950 ms, B=32 2.271 / 2.380 ms
             const bool fuse = use_sparse && use_dense_it && n_s >= 64 && n_d >= 64 && !(prm->flags & BTBA_FLAG_NO_FUSE);
+            Dh.corr_nt_from = ((fuse && use_dense_it) || ws->tune.corr_nt >= 0) ? corr_nt_from - (int)b0 : B;      // (b counts from the group's first instance)
             if (fuse) {
                 // one launch: HBM-streaming sparse workgroups interleaved with the VALU-bound dense ones
                 if ((rc = time_begin(ws, timing_it, 0, &slot, H.st))) return rc;

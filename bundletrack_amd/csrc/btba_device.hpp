@@ -217,6 +217,20 @@ typedef float btba_f4v __attribute__((ext_vector_type(4)));
 typedef int btba_i4v __attribute__((ext_vector_type(4)));
 // 16 aligned bytes through a constant-address-space pointer (the HIP vector classes cannot be copied out of another address space)
 __device__ __forceinline__ float4 ld_const_f4(const void *p) { const btba_f4v v = *as_const(reinterpret_cast<const btba_f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+// read-once streams (a sweep's correspondences): optionally non-temporal loads, so that they do not evict the frames the dense taps keep hitting in L2
+typedef float btba_f2v __attribute__((ext_vector_type(2)));
+template <bool NT> __device__ __forceinline__ float2 ld_stream_f2(const float2 *p)
+{
+    if (!NT) return *p;
+    const btba_f2v v = __builtin_nontemporal_load(reinterpret_cast<const btba_f2v *>(p));
+    return make_float2(v.x, v.y);
+}
+template <bool NT> __device__ __forceinline__ float4 ld_stream_f4(const float4 *p)
+{
+    if (!NT) return *p;
+    const btba_f4v v = __builtin_nontemporal_load(reinterpret_cast<const btba_f4v *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ int4 ld_const_i4(const void *p) { const btba_i4v v = *as_const(reinterpret_cast<const btba_i4v *>(p)); return make_int4(v.x, v.y, v.z, v.w); }
 
 // threadIdx.x through an opaque copy.  Inside the item loop of the persistent sweep (k_fused_sweeps) everything derived from the thread

@@ -99,6 +99,9 @@ struct SolveDims {
                          // corr_entry0 + b * corr_stride): the first iteration of a solve re-lays the caller's fresh EntryJ array out for the iterations that follow
     unsigned long long *live_blocks;   // non-null (BTBA_OPT_COUNT_LIVE, bench.py's roofline.executed): every block-walk workgroup adds the number of 8 x 8 blocks it walks
     int publish;         // k_chain: sweep workgroups store their partial records write-through (agent scope) -- another workgroup of the SAME launch reads them
+    int corr_nt_from;    // instances b >= corr_nt_from read their correspondences with NON-TEMPORAL loads: once a batch's frames + correspondences exceed the memory-side
+                         // cache, the read-once stream otherwise evicts the frames the dense items re-read every iteration (btba_api.hip: corr_nt_auto); what still fits
+                         // beside the frames -- the first instances' correspondences -- stays cached, and below the limit plain loads are faster for everything
 };
 
 __device__ __forceinline__ size_t frame_slot_of(const SolveDims &D, size_t f) { return D.frame_slot ? (size_t)D.frame_slot[f] : f; }
@@ -294,7 +297,7 @@ __global__ void __launch_bounds__(kBlock) k_pack_zn(size_t total, const float4 *
 //            EntryJ on the masked launch although they move a quarter less (52.0 vs 49.9 us, gpurun_out/r03_13).
 // float2 index of entry E's first plane (the other two follow at + 64 and + 128); E counts entries from the start of the array
 __device__ __forceinline__ size_t corr24_index(size_t E) { return (E >> 6) * 192 + (E & 63); }
-template <bool C24>
+template <bool C24, bool NT>
 __device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
                                                   const float *__restrict__ T, float *__restrict__ partials, int chunk, int p, int b, float *red)
 {
@@ -355,7 +358,7 @@ __device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const floa
             const uint32_t e2 = e + kBlock;
             const bool live2 = e2 < hi;
             const float2 *qa = cb + corr24_index(e_base + e), *qb = cb + corr24_index(e_base + (live2 ? e2 : e));
-            const float2 a0 = qa[0], a1 = qa[64], a2 = qa[128], b0 = qb[0], b1 = qb[64], b2 = qb[128];
+            const float2 a0 = ld_stream_f2<NT>(qa), a1 = ld_stream_f2<NT>(qa + 64), a2 = ld_stream_f2<NT>(qa + 128), b0 = ld_stream_f2<NT>(qb), b1 = ld_stream_f2<NT>(qb + 64), b2 = ld_stream_f2<NT>(qb + 128);
             accumulate(__float_as_uint(a0.x) != 0xFFFFFFFFu, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
             accumulate(live2 && __float_as_uint(b0.x) != 0xFFFFFFFFu, b0.x, b0.y, b1.x, b1.y, b2.x, b2.y);
         }
@@ -380,7 +383,7 @@ __device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const floa
             const uint32_t e2 = e + kBlock;
             const bool live2 = e2 < hi;
             const uint32_t e2c = live2 ? e2 : e;
-            const float4 a0 = cb[2 * (size_t)e], a1 = cb[2 * (size_t)e + 1], b0 = cb[2 * (size_t)e2c], b1 = cb[2 * (size_t)e2c + 1];
+            const float4 a0 = ld_stream_f4<NT>(cb + 2 * (size_t)e), a1 = ld_stream_f4<NT>(cb + 2 * (size_t)e + 1), b0 = ld_stream_f4<NT>(cb + 2 * (size_t)e2c), b1 = ld_stream_f4<NT>(cb + 2 * (size_t)e2c + 1);
             entry(a0, a1, true, e);
             entry(b0, b1, live2, e2c);
         }
@@ -392,8 +395,9 @@ __device__ __forceinline__ void sparse_block_impl(const SolveDims &D, const floa
 __device__ __forceinline__ void sparse_block(const SolveDims &D, const float4 *__restrict__ corr, const uint32_t *__restrict__ pair_offsets,
                                              const float *__restrict__ T, float *__restrict__ partials, int chunk, int p, int b, float *red)
 {
-    if (D.corr24) sparse_block_impl<true>(D, corr, pair_offsets, T, partials, chunk, p, b, red);
-    else sparse_block_impl<false>(D, corr, pair_offsets, T, partials, chunk, p, b, red);
+    // (four instances of one loop; the choice is uniform over the workgroup)
+    if (D.corr24) { if (b >= D.corr_nt_from) sparse_block_impl<true, true>(D, corr, pair_offsets, T, partials, chunk, p, b, red); else sparse_block_impl<true, false>(D, corr, pair_offsets, T, partials, chunk, p, b, red); }
+    else { if (b >= D.corr_nt_from) sparse_block_impl<false, true>(D, corr, pair_offsets, T, partials, chunk, p, b, red); else sparse_block_impl<false, false>(D, corr, pair_offsets, T, partials, chunk, p, b, red); }
 }
 
 // EntryJ segments -> 24-byte correspondences, in place in the entry index space (entry e of the input is entry e of the output).

@@ -27,7 +27,7 @@ class Batch:
         self.poses0 = torch.from_numpy(np.stack([pb.poses_init for pb in pbs])).to(self.dev)
         self.masked = masked
 
-    def solve(self, chain, corr24=False, aux=False, tiles=0, period=0, timeout_ms=None, relayout=True):
+    def solve(self, chain, corr24=False, aux=False, tiles=0, period=0, timeout_ms=None, relayout=True, corr_nt=None):
         """-> (poses [B, N, 4, 4], stats).  chain: BTBA_OPT_CHAIN (-1 library's choice, 0 plain schedule, 1 chained wherever supported)."""
         from bundletrack_amd.optimizer import BatchSolver, Workspace
         ws = Workspace()
@@ -36,6 +36,8 @@ class Batch:
         ws.set_option(_lib.OPT_RELAYOUT, 1 if relayout else 0)
         if timeout_ms is not None:
             ws.set_option(_lib.OPT_CHAIN_TIMEOUT_MS, timeout_ms)
+        if corr_nt is not None:
+            ws.set_option(1003, corr_nt)                 # developer switch (not part of the ABI): non-temporal correspondence loads  1 all instances, 0 none, -1 the library's choice
         bs = BatchSolver(ws)
         bs.params.dense_tiles = tiles
         if self.masked:
@@ -104,6 +106,20 @@ def test_the_benched_path_is_pinned(c3x32):
         worst = max(max(S.pose_error(benched[b, k], ref[k])) for k in range(15))
         print(f"benched path, instance {b}: worst pose difference against the reference's solver {worst:.2e}")
         assert worst < 1e-4, (b, worst)
+
+
+def test_nontemporal_correspondence_stream_has_the_same_bits(c3x32):
+    """Once a batch's frames + correspondences exceed the memory-side cache (c3 x 32: 147 + 161 MB against 256 MB) the sparse items read the
+    correspondences of the instances that no longer fit with non-temporal loads (btba_api.hip: corr_nt_auto) -- a cache policy, not arithmetic:
+    all / none / the library's choice give the same poses, with 24-byte records and with EntryJ."""
+    bt = c3x32
+    auto, _ = bt.solve(-1, corr24=True, aux=True)
+    for nt in (0, 1):
+        out, _ = bt.solve(-1, corr24=True, aux=True, corr_nt=nt)
+        assert np.array_equal(auto, out), (nt, np.abs(auto - out).max())
+    wire_nt, _ = bt.solve(0, relayout=False, corr_nt=1)
+    wire, _ = bt.solve(0, relayout=False, corr_nt=0)
+    assert np.array_equal(wire_nt, wire) and np.array_equal(wire, auto)
 
 
 def test_chained_launch_is_reproducible_under_load(c3x32):
