@@ -88,7 +88,7 @@ struct btba_workspace {
         bool overlap_equal_prio = false;   // BTBA_OPT_OVERLAP_EQUAL_PRIO (env BTBA_GROUP_PRIO=e...)
         size_t keyed_corr_min_bytes = (size_t)1 << 20;   // BTBA_OPT_KEYED_CORR_MIN_BYTES (env of the same name): below it the keyed correspondence cache is not used
         int chain = 0;                 // BTBA_OPT_CHAIN         (env BTBA_CHAIN): 1 = all Gauss-Newton iterations of a batch in ONE launch (k_chain) whenever the launch supports the solve; 0 (default) / -1 = the plain schedule
-        int corr_nt = -1;              // env BTBA_CORR_NT (developer; option 1003): non-temporal correspondence loads  1 always, 0 never, -1 (default) the library's choice (corr_nt_auto)
+        int corr_nt = -1;              // BTBA_OPT_CORR_NONTEMPORAL (env BTBA_CORR_NT): non-temporal correspondence loads  1 always, 0 never, -1 (default) the library's choice (corr_nt_auto)
         int corr_nt_partial = 1;       // env BTBA_CORR_NT_PARTIAL=0 (developer): all instances stream non-temporally once the batch exceeds the cache, not only those that do not fit
         long long last_level_cache = 224ll << 20;   // env BTBA_LLC_MB: what of the 256 MB memory-side cache a batch's frames + correspondences may fill before the stream is read non-temporally
         bool relayout = false;         // BTBA_OPT_RELAYOUT (env BTBA_RELAYOUT=1 turns it on): a batch given as EntryJ is re-laid out to 24-byte records by its first iteration's sweep
@@ -295,6 +295,7 @@ int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
     case BTBA_OPT_CHAIN_SPARSE_PERIOD: if (value < 0 || value == 1 || value > 64) return BTBA_EINVAL; t.chain_sparse_period = (int)value; break;
     case BTBA_OPT_CHAIN_TIMEOUT_MS: if (value < 1 || value > 60000) return BTBA_EINVAL; t.chain_timeout_ms = (int)value; break;
     case BTBA_OPT_RELAYOUT: t.relayout = value != 0; break;
+    case BTBA_OPT_CORR_NONTEMPORAL: if (value < -1 || value > 1) return BTBA_EINVAL; t.corr_nt = (int)value; break;
     case BTBA_OPT_COUNT_LIVE:
         ws->count_live = value != 0;
         if (ws->count_live) {
@@ -303,7 +304,6 @@ int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
             HIP_TRY(hipMemsetAsync(ws->live_blocks.p, 0, sizeof(unsigned long long), ws->stream));
         }
         break;
-    case 1003: t.corr_nt = (int)value; break;               // developer A/B: non-temporal correspondence loads  1 all, 0 none, -1 the library's choice (same bits either way)
     case 1000: t.chain_debug_skip = (int)value; break;      // developer timing experiments (ChainDims::debug_skip): not part of the ABI
     default: return BTBA_EINVAL;
     }
@@ -742,12 +742,12 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // c2 x 32, object-masked frames, which touch a few per cent of their pixels: non-temporal loads measured -2 ... -17 %); beyond it the cyclic stream
     // evicts the frames, and reading it non-temporally keeps them resident: c3 x 32 (147 + 161 MB) 185.2 -> 195.2 k GN it/s, c4 x 32 +3.7 %
     // (profiles/r04/nontemporal_stream.json).  Same bits.
-    const long long frames_bytes = use_dense ? (long long)B * N * npix * (use_zn ? 16 : 32) / (compaction ? 8 : 1) : 0;
+    const long long frames_bytes = use_dense ? (long long)B * N * npix * (use_zn ? 16 : 32) : 0;
     const long long corr_bytes = use_sparse ? (long long)B * (long long)corr_stride * (corr24 ? 24 : 32) : 0;
     const long long corr_per_instance = corr_bytes / B;
     // instances from this index on stream non-temporally: all that does not fit beside the frames (everything when the frames alone exceed the cache)
     int corr_nt_auto = B;
-    if (use_dense && use_sparse && frames_bytes + corr_bytes > ws->tune.last_level_cache)
+    if (use_dense && use_sparse && !compaction && frames_bytes + corr_bytes > ws->tune.last_level_cache)        // (object-masked frames: measured slower at c3 x 32 whatever the layout)
         corr_nt_auto = (frames_bytes >= ws->tune.last_level_cache || corr_per_instance <= 0) ? 0 : (int)std::min<long long>(B, (ws->tune.last_level_cache - frames_bytes) / corr_per_instance);
     if (ws->tune.corr_nt_partial == 0 && corr_nt_auto < B) corr_nt_auto = 0;
     const int corr_nt_from = ws->tune.corr_nt >= 0 ? (ws->tune.corr_nt ? 0 : B) : corr_nt_auto;

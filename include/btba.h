@@ -223,6 +223,11 @@ enum {
     BTBA_OPT_RELAYOUT             = 14, /* 1: a batch whose correspondences arrive as EntryJ (4 MiB or more, three iterations or more, full frames) is re-laid out to
                                            24-byte records BY ITS FIRST ITERATION'S SWEEP, and the other iterations stream those; 0 (default): every iteration reads
                                            EntryJ.  Same bits; measured a wash at c3 x 32 (the first launch's extra writes cost what the others save).  env BTBA_RELAYOUT */
+    BTBA_OPT_CORR_NONTEMPORAL     = 15, /* how the sparse items read the correspondences: -1 (default) with plain loads while the batch's frames + correspondences fit the
+                                           memory-side cache (224 MiB of MI355X's 256 MB; env BTBA_LLC_MB), beyond that the instances whose correspondences no longer
+                                           fit beside the frames are read with NON-TEMPORAL loads, so that the read-once stream does not evict the frames the dense items
+                                           re-read every iteration (c3 x 32: 185 -> 198 k GN it/s; never on object-masked frames); 0: plain loads always; 1: non-temporal
+                                           always.  A cache policy: same bits.                                                    env BTBA_CORR_NT */
     BTBA_OPT_COUNT_LIVE           = 13  /* 1: the dense sweep's block-walk workgroups add the number of 8 x 8 pixel blocks they actually walk (the blocks the hull
                                            test could not prove dead) to a counter of the workspace -- setting the option clears it, btba_workspace_live_blocks
                                            reads it.  Measurement aid (bench.py: roofline.executed); one atomic per workgroup while it is on. */

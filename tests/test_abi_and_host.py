@@ -160,7 +160,7 @@ def test_python_constants_match_the_header():
         assert getattr(_lib, "FLAG_" + name) == v, name
     assert defines["BTBA_MAX_FRAMES"] == 85 and defines["BTBA_MAX_FRAMES_LDS"] == 31     # the reference's MAX_NUM_IMAGES; the LDS-resident limit
     opts = {k[len("BTBA_OPT_"):]: v for k, v in enums.items() if k.startswith("BTBA_OPT_")}
-    assert len(opts) == 14 and all(getattr(_lib, "OPT_" + name) == v for name, v in opts.items())
+    assert len(opts) == 15 and all(getattr(_lib, "OPT_" + name) == v for name, v in opts.items())
     assert enums["BTBA_REDUCE_DETERMINISTIC"] == _lib.REDUCE_DETERMINISTIC and enums["BTBA_REDUCE_ATOMIC"] == _lib.REDUCE_ATOMIC
     assert 128 not in flags.values()                    # the bit that was BTBA_FLAG_FUSE stays without a meaning
     assert C.sizeof(_lib.Stats) == 104      # (chain_iterations took the struct's tail padding)

@@ -37,7 +37,7 @@ class Batch:
         if timeout_ms is not None:
             ws.set_option(_lib.OPT_CHAIN_TIMEOUT_MS, timeout_ms)
         if corr_nt is not None:
-            ws.set_option(1003, corr_nt)                 # developer switch (not part of the ABI): non-temporal correspondence loads  1 all instances, 0 none, -1 the library's choice
+            ws.set_option(_lib.OPT_CORR_NONTEMPORAL, corr_nt)      # 1 all instances, 0 none, -1 the library's choice
         bs = BatchSolver(ws)
         bs.params.dense_tiles = tiles
         if self.masked:
