@@ -84,7 +84,7 @@ def _lib_entryj():
     return _lib.ENTRYJ_DTYPE
 
 
-SOLVER_SOURCES = ("btba_kernels.hpp", "btba_device.hpp", "btba_api.hip")      # what the sweep / solve kernels are built from
+SOLVER_SOURCES = ("btba_kernels.hpp", "btba_solve_small.hpp", "btba_device.hpp", "btba_api.hip")      # what the sweep / solve kernels are built from
 
 
 def kernel_source_hash():
@@ -370,8 +370,6 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if os.environ.get("BTBA_BENCH_SKIP_AFTER_WARMUP"):      # developer timing experiment (wrong results by construction): ChainDims::debug_skip from here on
-        ws.set_option(1000, int(os.environ["BTBA_BENCH_SKIP_AFTER_WARMUP"]))
     if not args.no_kernel_timing:
         ws.collect_stats()                                  # drop warm-up events
     sharding.barrier(dev)

@@ -25,7 +25,7 @@ RANSAC_DRAW_HASH = 0x100      # ORed into `hypothesis`: counter-hash sample trip
 FLAG_TRACE, FLAG_TIME_KERNELS = 1, 2
 FLAG_OVERLAP, FLAG_NO_FUSE, FLAG_KEYED_CORR, FLAG_FLOAT4_CACHE, FLAG_NO_COMPACTION, FLAG_COMPACTION, FLAG_TIME_SAMPLED = 32, 64, 4096, 256, 512, 1024, 2048
 OPT_DENSE_ORDER, OPT_TILE_MAJOR, OPT_BLOCK_WALK, OPT_BLOCK_SKIP, OPT_BIG_ASSEMBLY, OPT_OVERLAP_GROUPS, OPT_OVERLAP_EQUAL_PRIO, OPT_KEYED_CORR_MIN_BYTES, OPT_SPARSE_TAIL = 1, 2, 3, 4, 5, 6, 7, 8, 9
-OPT_CHAIN, OPT_CHAIN_SPARSE_PERIOD, OPT_CHAIN_TIMEOUT_MS, OPT_COUNT_LIVE, OPT_RELAYOUT, OPT_CORR_NONTEMPORAL = 10, 11, 12, 13, 14, 15
+OPT_CHAIN, OPT_CHAIN_SPARSE_PERIOD, OPT_CHAIN_TIMEOUT_MS, OPT_COUNT_LIVE, OPT_RELAYOUT, OPT_CORR_NONTEMPORAL, OPT_SOLVE_SMALL = 10, 11, 12, 13, 14, 15, 16
 
 ENTRYJ_DTYPE = np.dtype(
     [("imgIdx_i", "<u4"), ("imgIdx_j", "<u4"), ("pos_i", "<f4", (3,)), ("pos_j", "<f4", (3,))]
@@ -51,6 +51,7 @@ class Params(C.Structure):
         ("weight_sparse", C.c_float), ("weight_dense_depth", C.c_float), ("image_downscale", C.c_float),
         ("pair_policy", C.c_int32), ("dense_tiles", C.c_int32), ("sparse_chunks", C.c_int32), ("flags", C.c_int32), ("reduction_mode", C.c_int32),
         ("weights_sparse_per_iter", C.c_void_p), ("weights_dense_per_iter", C.c_void_p),      # host float[n_gn_iters] or NULL (the scalars)
+        ("n_weights_per_iter", C.c_int32),                                                     # their length (must equal n_gn_iters when either is set)
     ]
 
 

@@ -19,6 +19,7 @@
 
 #include "../../include/btba.h"
 #include "btba_kernels.hpp"
+#include "btba_solve_small.hpp"
 #include "btba_image.hpp"
 #include "btba_ransac.hpp"
 #include "btba_xorwow.hpp"
@@ -97,6 +98,7 @@ struct btba_workspace {
         int chain_timeout_ms = 500;    // BTBA_OPT_CHAIN_TIMEOUT_MS (env BTBA_CHAIN_TIMEOUT_MS): watchdog of the waits inside the chained launch
         int chain_solve_prio = 0;      // env BTBA_CHAIN_SOLVE_PRIO (developer A/B): s_setprio of the solve items' waves
         int chain_debug_skip = 0;      // env BTBA_CHAIN_DEBUG_SKIP (developer TIMING experiments, wrong results): ChainDims::debug_skip
+        bool solve_small = true;       // BTBA_OPT_SOLVE_SMALL (env BTBA_SOLVE_LEGACY=1 turns it off): k_solve_small for windows of <= 21 frames
         int debug_lds_pad = 0;         // env BTBA_DEBUG_LDS_PAD (developer): extra dynamic LDS bytes per sweep workgroup -- what a larger LDS footprint costs the fused sweep
         std::string chain_trace_file;  // env BTBA_CHAIN_TRACE_FILE (developer, scripts/chain_trace.py): every chained solve synchronises and dumps its workgroup timeline there
     } tune;
@@ -108,7 +110,8 @@ struct btba_workspace {
     std::vector<EventPair> events;                          // pending timed regions
     std::vector<hipEvent_t> event_pool;
     btba_stats stats{};
-    bool lds_attr_set = false;
+    bool lds_attr_set = false, small_attr_set = false;
+    int n_cus = 0;                     // compute units of the workspace's device (256 = all eight XCDs of an MI355X in SPX mode: what k_chain's item -> XCD mapping assumes)
     bool always_time_region = false;   // optimize_frames: ms_solve is part of its stats contract
     static constexpr int kMaxGroups = 8;
     uint64_t solves_enqueued = 0;      // rotates the sampled iteration of BTBA_FLAG_TIME_SAMPLED
@@ -182,6 +185,7 @@ void btba_params_default(btba_params *p)
     p->reduction_mode = BTBA_REDUCE_DETERMINISTIC;
     p->weights_sparse_per_iter = nullptr;
     p->weights_dense_per_iter = nullptr;
+    p->n_weights_per_iter = 0;
 }
 
 const char *btba_strerror(int status)
@@ -215,6 +219,7 @@ static int workspace_create(btba_workspace **out, void *stream, bool use_given)
     btba_workspace *ws = new (std::nothrow) btba_workspace();
     if (!ws) return BTBA_ENOMEM;
     if (hipGetDevice(&ws->device) != hipSuccess) { delete ws; return BTBA_EHIP; }
+    if (hipDeviceGetAttribute(&ws->n_cus, hipDeviceAttributeMultiprocessorCount, ws->device) != hipSuccess) ws->n_cus = 0;
     {   // developer switches from the environment: here and nowhere else
         auto on = [](const char *name) { const char *e = std::getenv(name); return e && e[0] && e[0] != '0'; };
         btba_workspace::Tuning &t = ws->tune;
@@ -230,15 +235,18 @@ static int workspace_create(btba_workspace **out, void *stream, bool use_given)
         if (const char *e = std::getenv("BTBA_CHAIN")) t.chain = std::max(-1, std::min(1, std::atoi(e)));
         if (const char *e = std::getenv("BTBA_CHAIN_PERIOD")) t.chain_sparse_period = std::max(0, std::atoi(e));
         t.relayout = on("BTBA_RELAYOUT");
+        t.solve_small = !on("BTBA_SOLVE_LEGACY");
         if (const char *e = std::getenv("BTBA_CORR_NT")) t.corr_nt = std::atoi(e);
         if (const char *e = std::getenv("BTBA_LLC_MB")) t.last_level_cache = (long long)std::atoll(e) << 20;
         if (const char *e = std::getenv("BTBA_CORR_NT_PARTIAL")) t.corr_nt_partial = std::atoi(e);
-        if (const char *e = std::getenv("BTBA_CHAIN_GROUP")) t.chain_group = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("BTBA_CHAIN_TIMEOUT_MS")) t.chain_timeout_ms = std::max(1, std::atoi(e));
+#ifdef BTBA_DEV_EXPERIMENTS      // developer builds only (scripts/chain_trace.py and the timing experiments of profiles/r04): these change schedules in ways a product build never does
+        if (const char *e = std::getenv("BTBA_CHAIN_GROUP")) t.chain_group = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("BTBA_CHAIN_TRACE_FILE")) t.chain_trace_file = e;
         if (const char *e = std::getenv("BTBA_CHAIN_SOLVE_PRIO")) t.chain_solve_prio = std::max(0, std::min(3, std::atoi(e)));
         if (const char *e = std::getenv("BTBA_CHAIN_DEBUG_SKIP")) t.chain_debug_skip = std::atoi(e);
         if (const char *e = std::getenv("BTBA_DEBUG_LDS_PAD")) t.debug_lds_pad = std::max(0, std::min(60000, std::atoi(e)));
+#endif
     }
     if (use_given) {
         ws->stream = reinterpret_cast<hipStream_t>(stream);       // may be the NULL stream
@@ -274,6 +282,7 @@ void btba_workspace_destroy(btba_workspace *ws)
 
 int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
 {
+    DeviceGuard device_guard(ws);      // (BTBA_OPT_COUNT_LIVE allocates, BTBA_OPT_OVERLAP_EQUAL_PRIO destroys streams: on the workspace's device, whatever is current)
     if (!ws) return BTBA_EINVAL;
     btba_workspace::Tuning &t = ws->tune;
     switch (option) {
@@ -295,6 +304,7 @@ int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
     case BTBA_OPT_CHAIN_SPARSE_PERIOD: if (value < 0 || value == 1 || value > 64) return BTBA_EINVAL; t.chain_sparse_period = (int)value; break;
     case BTBA_OPT_CHAIN_TIMEOUT_MS: if (value < 1 || value > 60000) return BTBA_EINVAL; t.chain_timeout_ms = (int)value; break;
     case BTBA_OPT_RELAYOUT: t.relayout = value != 0; break;
+    case BTBA_OPT_SOLVE_SMALL: t.solve_small = value != 0; break;
     case BTBA_OPT_CORR_NONTEMPORAL: if (value < -1 || value > 1) return BTBA_EINVAL; t.corr_nt = (int)value; break;
     case BTBA_OPT_COUNT_LIVE:
         ws->count_live = value != 0;
@@ -304,7 +314,15 @@ int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
             HIP_TRY(hipMemsetAsync(ws->live_blocks.p, 0, sizeof(unsigned long long), ws->stream));
         }
         break;
-    case 1000: t.chain_debug_skip = (int)value; break;      // developer timing experiments (ChainDims::debug_skip): not part of the ABI
+    case 1000:      // not part of the ABI.  64 = the watchdog's self-test (solve items never publish: the launch runs into the watchdog, the solve is REPORTED failed,
+                    // tests/test_gpu_chain.py); the timing experiments (other bits: sweep items that skip their waits, solve items that do nothing -- wrong poses
+                    // behind BTBA_OK) exist in developer builds only
+#ifdef BTBA_DEV_EXPERIMENTS
+        t.chain_debug_skip = (int)value; break;
+#else
+        if (value != 0 && value != 64) return BTBA_EINVAL;
+        t.chain_debug_skip = (int)value; break;
+#endif
     default: return BTBA_EINVAL;
     }
     return BTBA_OK;
@@ -487,8 +505,15 @@ static int pick_tiles(const btba_params *prm, int B, int Pd, int npix, bool list
     // the block walk splits the image by rows of 8 x 8 blocks: tiles beyond ceil(rows / rows-per-tile) would be empty workgroups and
     // empty partials (160 x 120: 15 block rows, 10 tiles -> 2 rows per tile -> 8 tiles; a single instance: 0.301 -> 0.269 ms per solve)
     if (Wd % 8 == 0 && Hd % 8 == 0) {
-        const int bh = Hd / 8, rows_per = (bh + want - 1) / want;
+        // ... and a band must not hold more than 1 024 blocks (4 x 256 lanes test a band's blocks: solve_enqueue drops the hull-culled walk for row strips
+        // beyond that).  The one-tile policy above was measured on 160 x 120 caches (300 blocks); a 320 x 240 cache (image_downscale 2: 1 200 blocks)
+        // in a chip-filling batch gets the two tiles that keep the walk
+        const int bw = Wd / 8, bh = Hd / 8;
+        const int min_tiles = (bw * bh + 1023) / 1024;
+        if (want < min_tiles && bw <= 1024) want = std::min(min_tiles, bh);
+        const int rows_per = (bh + want - 1) / want;
         want = (bh + rows_per - 1) / rows_per;
+        while (want < bh && (long)((bh + want - 1) / want) * bw > 1024 && bw <= 1024) want++;      // (rows per tile round up)
     }
     return want;
 }
@@ -510,6 +535,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
 {
     if (!ws || !prm || B < 1 || N < 2 || Hd < 2 || Wd < 2 || !intr || !poses) return BTBA_EINVAL;
     if (prm->n_gn_iters < 1 || prm->n_pcg_iters < 0) return BTBA_EINVAL;   // MLIB_ASSERT, CUDASolverBundling.cpp:194
+    // A watchdog of an EARLIER chained launch fired and nobody has synchronised through the library since (a caller that orders its own stream with
+    // btba_workspace_signal_stream never passes btba_workspace_sync): report it now -- that solve's poses were poisoned with NaN by the kernel (k_chain),
+    // this and every later solve of the workspace runs unchained.
+    if (ws->chain_error && *ws->chain_error) { *ws->chain_error = 0; ws->chain_failed = true; return BTBA_ESCHED; }
     if (prm->reduction_mode != BTBA_REDUCE_DETERMINISTIC && prm->reduction_mode != BTBA_REDUCE_ATOMIC) return BTBA_EINVAL;
     const bool atomic_sums = prm->reduction_mode == BTBA_REDUCE_ATOMIC;      // the reference's way of summing (float atomics, order not fixed)
     if (atomic_sums && trace) return BTBA_EINVAL;                            // the decision traces are defined on the reproducible sums
@@ -518,6 +547,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // Weights of the two terms per Gauss-Newton iteration: the solveBundlingStub seam takes one array per term (input.weightsSparse[nIter],
     // weightsDenseDepth[nIter], SolverBundling.cu:948-951; SBA.cpp:27-32 fills them with 1 / 1), and so do the optional arrays of btba_params.
     const float *wsi = prm->weights_sparse_per_iter, *wdi = prm->weights_dense_per_iter;
+    if ((wsi || wdi) && prm->n_weights_per_iter != prm->n_gn_iters) return BTBA_EINVAL;      // the arrays' stated length: never read past it
     auto ws_at = [&](int it) { return wsi ? wsi[it] : prm->weight_sparse; };
     auto wd_at = [&](int it) { return wdi ? wdi[it] : prm->weight_dense_depth; };
     bool any_dense_weight = false, any_sparse_weight = false;
@@ -612,10 +642,11 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // tables of k_system_solve that depend on the window size only: canonical pair p -> (i << 8 | j), then the 72
     // descriptors of the sparse 6x6 block entries (btba_kernels.hpp: sparse_entry_descriptor)
     if (ws->solve_tab_frames != N) {
-        std::vector<int32_t> tab((size_t)P + 288);
+        const size_t lut16 = ((size_t)P + 288 + 3) & ~(size_t)3;           // a second, 16-byte aligned copy of the descriptors (k_solve_small loads them as int4)
+        std::vector<int32_t> tab(lut16 + 288);
         int q = 0;
         for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) tab[q++] = (i << 8) | j;
-        for (int t = 0; t < 72; t++) sparse_entry_descriptor(t >= 36, (t % 36) / 6, t % 6, &tab[(size_t)P + 4 * t]);
+        for (int t = 0; t < 72; t++) { sparse_entry_descriptor(t >= 36, (t % 36) / 6, t % 6, &tab[(size_t)P + 4 * t]); sparse_entry_descriptor(t >= 36, (t % 36) / 6, t % 6, &tab[lut16 + 4 * t]); }
         if ((rc = ws->solve_tab.ensure(sizeof(int32_t) * tab.size()))) return rc;
         HIP_TRY(hipMemcpyAsync(ws->solve_tab.p, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice, ws->stream));
         HIP_TRY(hipStreamSynchronize(ws->stream));         // `tab` is a local
@@ -697,6 +728,19 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         ws->lds_attr_set = true;
     }
 
+    // tracker-sized windows run k_solve_small (btba_solve_small.hpp) instead of k_system_solve: not in atomic mode (its records are accumulators
+    // the solve has to clear), not for the chained launch's last solve, and only while everything fits the CU's LDS
+    const int small_cpl_v = small_cpl(N);
+    const size_t small_lds = sizeof(float) * small_solve_lds_floats(N, D.n_dense_pairs, small_cpl_v);
+    const bool small_solve = ws->tune.solve_small && N <= kSmallMaxFrames && !atomic_sums && !a_global && !D.pre_assembled && small_lds <= lds_limit;
+    if (small_solve && !ws->small_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        ws->small_attr_set = true;
+    }
+
     // stats bookkeeping (collected after sync)
     btba_stats &S = ws->stats;
     if (ws->events.empty() || !timing) std::memset(&S, 0, sizeof S);     // new accumulation window
@@ -723,7 +767,9 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // per pair 1.280 ms per step against 1.306 ms for the plain schedule with two tiles -- and 1.247 ms for the plain schedule with ONE tile, which the
     // chained launch cannot use (1.314 ms: its sparse items come in bursts behind every instance's dense items instead of closing the launch).
     // Object-masked frames: 0.74 against 0.52 ms (their sweeps are shorter than an in-launch solve).  The library's own choice is the plain schedule.
-    const bool chain = chain_lay != 0 && !ws->chain_failed && ws->tune.chain > 0 && use_sparse && use_dense && !wsi && !wdi
+    // (only on a device that shows all 8 XCDs x 32 compute units -- the launch's forward progress rests on workgroup g running on XCD g % 8 in grid order;
+    // a partitioned device runs the plain schedule)
+    const bool chain = chain_lay != 0 && !ws->chain_failed && ws->n_cus == 256 && ws->tune.chain > 0 && use_sparse && use_dense && !wsi && !wdi
                        && !trace && !atomic_sums && !a_global && !D.pre_assembled && N <= kChainMaxFrames && chunks <= kChainMaxParts && tiles <= kChainMaxParts
                        && !(prm->flags & (BTBA_FLAG_NO_FUSE | BTBA_FLAG_OVERLAP)) && !Z.frame_slot
                        && lds_rest + 16 + sizeof(float) * chain_region_floats(N) <= kChainLdsBytes;      // (c3's 15 frames are the largest window whose solve fits a sweep workgroup's LDS share)
@@ -921,6 +967,9 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
 #undef BTBA_LAST_SOLVE
             if ((rc = time_end(ws, slot))) return rc;
         }
+        // a watchdog that fired inside the launch leaves poses nobody may use: NaN them on the device, so that a caller who never synchronises through
+        // the library (and so never sees BTBA_ESCHED from btba_workspace_sync) runs into its own finiteness checks / BTBA_ENUMERIC
+        k_chain_poison<<<(16 * B * N + 255) / 256, 256, 0, ws->stream>>>(Cn.error, poses, 16 * B * N);
         S.chain_iterations = prm->n_gn_iters;
         S.fused_sweeps = 1;
         ws->chain_launches++;
@@ -1033,6 +1082,24 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                 k_big_assemble<<<dim3((bt.total + 255u) / 256u, (unsigned)H.nb), 256, 0, H.st>>>(Di, ps_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, ws->solve_tab.as<int>(), A_h);
             }
 #define BTBA_SOLVE(LP, AG) k_system_solve<LP, AG><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(Ds, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h, A_h, out_h, ws->solve_tab.as<int>())
+            if (small_solve) {
+                // tracker-sized windows: k_solve_small (btba_solve_small.hpp)
+                SmallSolveArgs Sa{};
+                Sa.n_frames = N; Sa.n_pairs = P; Sa.n_dense_pairs = use_dense_it ? D.n_dense_pairs : 0;
+                Sa.sparse_chunks = Ds.sparse_chunks; Sa.dense_tiles = Ds.dense_tiles; Sa.n_pcg = D.n_pcg; Sa.use_sparse = use_sparse ? 1 : 0;
+                Sa.w_sparse = Di.w_sparse;
+                Sa.sp_stride = D.sp_stride; Sa.dp_stride = D.dp_stride; Sa.pose_stride = D.pose_stride; Sa.x_stride = D.x_stride;
+                Sa.iter = it;
+                Sa.trace_record = D.trace_record; Sa.tr_x = D.tr_x; Sa.tr_T = D.tr_T; Sa.tr_rhs = D.tr_rhs; Sa.tr_prec = D.tr_prec; Sa.tr_pcg = D.tr_pcg;
+                Sa.tr_delta = D.tr_delta; Sa.tr_dpair = D.tr_dpair; Sa.tr_A = D.tr_A; Sa.tr_clk = D.tr_clk; Sa.trace_instance = (int64_t)D.n_gn * D.trace_record;
+                Sa.sparse_partials = sp_h; Sa.dense_partials = dp_h;
+                Sa.adj_off = d_adj_off; Sa.adj = d_adj; Sa.cross = d_adj + 2 * (size_t)Pd; Sa.pair_ij = ws->solve_tab.as<int>(); Sa.entry_lut = ws->solve_tab.as<int>() + (((size_t)P + 288 + 3) & ~(size_t)3);
+                Sa.x = x_h; Sa.T = T_h; Sa.Tinv = Ti_h; Sa.poses_out = out_h; Sa.trace = D.trace_on ? tr_h : nullptr;
+                if (small_cpl_v == 4) k_solve_small<4><<<H.nb, kSmallBlock, small_lds, H.st>>>(Sa);
+                else if (small_cpl_v == 8) k_solve_small<8><<<H.nb, kSmallBlock, small_lds, H.st>>>(Sa);
+                else if (small_cpl_v == 12) k_solve_small<12><<<H.nb, kSmallBlock, small_lds, H.st>>>(Sa);
+                else k_solve_small<16><<<H.nb, kSmallBlock, small_lds, H.st>>>(Sa);
+            } else
             if (a_global) { if (D.pairsum_in_lds) BTBA_SOLVE(true, true); else BTBA_SOLVE(false, true); }
             else { if (D.pairsum_in_lds) BTBA_SOLVE(true, false); else BTBA_SOLVE(false, false); }
 #undef BTBA_SOLVE

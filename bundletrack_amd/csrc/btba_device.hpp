@@ -137,17 +137,37 @@ __device__ __forceinline__ void ln_rotation(const float R[9], float out[3])
 }
 
 // SE(3) log: 4x4 -> (rot, trans)   (matrixToPose)
+// The reference evaluates sinf(theta / 2) for the translation's scale and, inside exp_rotation(-rot / 2), sinf and cosf of |rot / 2| again:
+// |-rot / 2| = sqrtf(sum (rot_i / 2)^2) = theta / 2 BIT FOR BIT (scaling by a power of two commutes with every rounding of the sum and of the
+// correctly rounded square root), so one sincosf serves both -- ~40 instructions off k_solve_small's one-lane update chain, same bits
+// (tests/test_gpu_parity.py::test_se3_helpers_bit_exact against the reference's own LieDerivUtil.h).
 __device__ __forceinline__ void matrix_to_pose(const Mat4 &M, float rot[3], float trans[3])
 {
     const float R[9] = { M.m[0], M.m[1], M.m[2], M.m[4], M.m[5], M.m[6], M.m[8], M.m[9], M.m[10] };
     const float t[3] = { M.m[3], M.m[7], M.m[11] };
     ln_rotation(R, rot);
     const float theta = sqrtf(rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
-    float shtot = 0.5f;
-    if (theta > 0.00001f) shtot = sinf(theta * 0.5f) / theta;
+    float shtot = 0.5f, sn = 0.0f, cs = 1.0f;
+    if (theta > 0.00001f) { sincosf(theta * 0.5f, &sn, &cs); shtot = sn / theta; }
     const float rh[3] = { rot[0] * -0.5f, rot[1] * -0.5f, rot[2] * -0.5f };
     float Hh[9];
-    exp_rotation(rh, Hh);
+    {   // exp_rotation(rh, Hh) with the sine and cosine of |rh| = theta / 2 from above
+        const float theta_sq = rh[0] * rh[0] + rh[1] * rh[1] + rh[2] * rh[2];
+        const float theta_h = sqrtf(theta_sq);
+        float A, B;
+        if ((double)theta_sq < 1e-8) {
+            A = 1.0f - BTBA_ONE_SIXTH * theta_sq;
+            B = 0.5f;
+        } else if ((double)theta_sq < 1e-6) {
+            B = 0.5f - 0.25f * BTBA_ONE_SIXTH * theta_sq;
+            A = 1.0f - theta_sq * BTBA_ONE_SIXTH * (1.0f - BTBA_ONE_TWENTIETH * theta_sq);
+        } else {
+            const float inv_theta = 1.0f / theta_h;
+            A = sn * inv_theta;
+            B = (1.0f - cs) * (inv_theta * inv_theta);
+        }
+        rodrigues(rh, A, B, Hh);
+    }
     float tr0 = Hh[0] * t[0] + Hh[1] * t[1] + Hh[2] * t[2];
     float tr1 = Hh[3] * t[0] + Hh[4] * t[1] + Hh[5] * t[2];
     float tr2 = Hh[6] * t[0] + Hh[7] * t[1] + Hh[8] * t[2];

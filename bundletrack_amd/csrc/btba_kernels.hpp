@@ -2494,6 +2494,13 @@ __global__ void __launch_bounds__(kBlock, BTBA_FUSED_WAVES) k_chain(SolveDims D,
     }
 }
 
+// after a chained solve: a raised watchdog word (host-visible memory) turns the solve's output poses into NaN
+__global__ void __launch_bounds__(256) k_chain_poison(const int *__restrict__ error, float *__restrict__ poses, int n)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) poses[e] = __int_as_float(0x7FC00000);
+}
+
 // Log / Exp / inverse of the incoming matrices into ring slot 0 of the chained launch (k_prepare with padded instance strides)
 __global__ void __launch_bounds__(64) k_prepare_strided(int total, int n_frames, int pose_stride, int x_stride, const float *__restrict__ poses,
                                                         float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv)

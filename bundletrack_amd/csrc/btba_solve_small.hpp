@@ -1,0 +1,456 @@
+// btba_solve_small.hpp -- k_solve_small: the per-instance system solve of tracker-sized windows (N <= 21 frames), round 5.
+//
+// Replaces k_system_solve (btba_kernels.hpp) wherever the window fits; what it computes is the same Gauss-Newton step
+//   reduce the sweep partials -> A = w_s JsT Js + JdT Jd, b -> 5 x Jacobi-PCG -> x <- Log(Exp(delta) Exp(x)), T, T^-1
+// of SolverBundling.cu:575-651 (PCGInit), :692-818 (PCGStep / epsilon guards), :805-815 + :890-897 (update, matrices) and
+// SolverBundlingDenseUtil.h:349-385 (dense blocks), with the SAME sums but NOT in k_system_solve's order: round 4's verdict asked
+// for the kernel to become shorter instead of hidden, and dropped the "same bits as round 1" rule for it (gate: the parity suite
+// and the decision traces against the oracle / the reference).
+//
+// What bounds a kernel like this (profiles/r05/solve_small.json): ONE workgroup per instance on one compute unit, a chain of short
+// dependent phases (k_system_solve: 44 k cycles = reduce 10.6 k + assemble 11.2 k + PCG 13.5 k + update 7.9 k, profiles/r03/
+// system_solve_experiments.json).  Measured while writing this kernel:
+//   * a wave ALONE on its SIMD retires one instruction per ~10-12 cycles (dependent issue + LDS round trips it cannot hide): phases
+//     with work for everybody run on all 16 waves (4 per SIMD: one instruction per 4 cycles per SIMD), whatever their set-up costs;
+//   * every vector instruction that all 16 waves execute costs 16 cycles of the compute unit: per-lane set-up and index arithmetic
+//     are what the throughput phases consist of, so they are cut to the bone (descriptors from the host's table, compile-time LDS
+//     offsets, 24-bit multiplies, no 64-bit address arithmetic, no divisions);
+//   * hipcc sinks a load into the conditional block that uses it and then waits for every load in turn (first version: eight
+//     serial fabric round trips in the reduce phase): loads and stores are UNCONDITIONAL here -- dead slots repeat the last live one;
+//   * a cold instruction cache is NOT what bounds it (the body run twice: the second pass is no faster).
+//
+//   reduce     16-byte loads -> 16-byte LDS stores; source index = destination index when there is one partial per sum (every
+//              chip-filling batch): ONE fabric round trip; up to four partials of two slots per lane in flight otherwise.
+//   assemble   a lane keeps ONE (row, column) of the 6 x 6 block pattern for its lifetime and walks pairs -- no per-entry decode
+//              (e / 36, pair_index, tri21).  Diagonal blocks: the sparse blocks are LINEAR in the pair's moment sums, so a frame's 20
+//              sparse and 27 dense sums over its pairs are formed first (47 (N - 1) lanes, loads batched) and expanded once, instead
+//              of expanding every pair's block and summing 36 entries x 14 pairs.
+//   PCG        the matrix is read from LDS ONCE into registers -- eight lanes per row, CPL columns each, 8 rows per wave -- and a
+//              step is: packed FMAs against p (broadcast reads), three DPP adds, A p through LDS, a barrier, the two dot products
+//              and vector updates on ONE wave alone on its SIMD, a barrier.  alpha and beta by v_rcp_f32 (1 ulp; the reference is
+//              built with -use_fast_math), guards as they stand.
+//   update     one lane per frame for Exp / Log; the generic cofactor inverse (float4x4::getInverse, ~300 instructions of the chain)
+//              on sixteen lanes per frame: one adjugate entry each, the same six products per entry.
+//
+// LDS-resident; frame 0 (fixed) has no rows or columns here.
+#pragma once
+#include "btba_kernels.hpp"
+
+#ifndef BTBA_SOLVE_REPEAT
+#define BTBA_SOLVE_REPEAT 1          // developer experiment (> 1: the whole body again, stamps of the last pass -- what a warm instruction cache is worth; wrong results)
+#endif
+
+namespace btba {
+
+constexpr int kSmallMaxFrames = 21;      // 6 (N - 1) <= 128 unknowns: two vector entries per lane of a PCG wave, four waves x 32 rows
+constexpr int kSmallBlock = 1024;
+constexpr int kFrameSums = 48;           // floats per frame of the frame-sum table (20 sparse + 27 dense used)
+
+struct SmallSolveArgs {
+    int n_frames, n_pairs, n_dense_pairs;        // N, P = N (N - 1) / 2, dense pairs in THIS iteration (0: dense term off)
+    int sparse_chunks, dense_tiles, n_pcg, use_sparse;
+    float w_sparse;
+    unsigned sp_stride, dp_stride;               // floats per instance in the sweep partials
+    int pose_stride, x_stride;
+    int iter;
+    const float *sparse_partials, *dense_partials;
+    const int *adj_off, *adj, *cross, *pair_ij;  // dense adjacency (frame -> (pair << 1 | is_source)), canonical pair -> dense pair carrying its cross block (-1: none), canonical pair -> (i << 8 | j)
+    const int *entry_lut;                        // 72 x 4 ints: sparse_entry_descriptor of the 36 diagonal-block and the 36 cross-block entries
+    float *x, *T, *Tinv, *poses_out, *trace;
+    int64_t trace_record, tr_x, tr_T, tr_rhs, tr_prec, tr_pcg, tr_delta, tr_dpair, tr_A, tr_clk, trace_instance;      // trace_instance: floats per instance (n_gn records)
+};
+
+__host__ __device__ constexpr int small_lda(int cpl) { return 4 * ((2 * cpl) | 1); }      // row length 8 CPL, padded to an odd multiple of 4 floats: 16-byte rows, conflict-free 16-byte reads down a column of rows
+__host__ __device__ constexpr int round4(int v) { return (v + 3) & ~3; }
+// columns per lane the PCG is compiled for (eight lanes per matrix row): the smallest instantiation with 8 CPL >= 6 (N - 1)
+__host__ inline int small_cpl(int n_frames) { const int na = 6 * (n_frames - 1); return na <= 32 ? 4 : na <= 64 ? 8 : na <= 96 ? 12 : 16; }
+
+// LDS layout of k_solve_small<CPL>, in floats: every region is sized for the LARGEST window of the instantiation, so that every address
+// in the kernel is a compile-time offset (plus an index); only the dense pair sums, at the end, have a run-time size.
+template <int CPL>
+struct SmallLayout {
+    static constexpr int NA = 8 * CPL;                                       // unknowns (rows / columns) provided for
+    static constexpr int NF = (NA / 6 + 1) < kSmallMaxFrames ? (NA / 6 + 1) : kSmallMaxFrames;      // frames
+    static constexpr int NP = NF * (NF - 1) / 2;                             // canonical pairs
+    static constexpr int lda = small_lda(CPL);
+    static constexpr int oA = 0;                                             // [NA][lda] system matrix (frame 0 has no rows / columns); columns na .. 8 CPL - 1 zero
+    static constexpr int op = oA + NA * lda;                                 // p (zero beyond na)
+    static constexpr int oAp = op + lda;                                     // A p, two buffers
+    static constexpr int ob = oAp + 2 * lda, oM = ob + lda, od = oM + lda;   // right-hand side, Jacobi preconditioner, delta
+    static constexpr int oT = od + lda;                                      // this iterate's T [N][16]
+    static constexpr int oE = oT + 16 * NF;                                  // the next iterate's T (input of the sixteen-lane inverse)
+    static constexpr int ox = oE + 16 * NF;                                  // this iterate's x
+    static constexpr int oF = ox + round4(6 * NF);                           // frame sums [(N - 1)][48]
+    static constexpr int opij = oF + (NF - 1) * kFrameSums;                  // ints: canonical pair -> (i << 8 | j)
+    static constexpr int ocross = opij + round4(NP);                         // ints: canonical pair -> dense pair with its cross block
+    static constexpr int oadjoff = ocross + round4(NP);                      // ints: N + 1
+    static constexpr int oadj = oadjoff + round4(NF + 1);                    // ints: 2 Pd <= 4 NP (an explicit list may name every ordered pair)
+    static constexpr int ops = oadj + 4 * NP;                                // reduced sparse pair sums [P][44] ...
+    static constexpr int fixed = ops;                                        // ... and behind them the dense ones [Pd][28] (model frame: dense_epilogue): at ops + P * 44
+};
+__host__ inline size_t small_solve_lds_floats(int N, int Pd, int cpl)
+{
+    const size_t fixed = cpl == 4 ? SmallLayout<4>::fixed : cpl == 8 ? SmallLayout<8>::fixed : cpl == 12 ? SmallLayout<12>::fixed : SmallLayout<16>::fixed;
+    return fixed + (size_t)(N * (N - 1) / 2) * kSparseVals + (size_t)Pd * kDenseVals + 8 * kSparseVals + 16;      // (+ eight records of slack: the frame sums' unconditional loads run past the last pair)
+}
+
+template <int CPL>
+__global__ void __launch_bounds__(kSmallBlock) k_solve_small(const SmallSolveArgs S)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using L = SmallLayout<CPL>;
+    constexpr unsigned nthr = kSmallBlock;
+    constexpr int lda = L::lda;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef btba_f4v v4;                                                    // (the native vector type: one global_load_dwordx4 / ds_write_b128 each)
+    const unsigned tid = threadIdx.x, b = blockIdx.x;
+    const int N = S.n_frames, P = S.n_pairs, Pd = S.n_dense_pairs, na = 6 * (N - 1);
+    float *A = lds + L::oA, *vp = lds + L::op, *vAp = lds + L::oAp, *vb = lds + L::ob, *vM = lds + L::oM, *vd = lds + L::od;
+    float *vT = lds + L::oT, *vE = lds + L::oE, *x_l = lds + L::ox, *F = lds + L::oF;
+    int *pair_ij_l = reinterpret_cast<int *>(lds + L::opij), *cross_l = reinterpret_cast<int *>(lds + L::ocross);
+    int *adj_off_l = reinterpret_cast<int *>(lds + L::oadjoff), *adj_l = reinterpret_cast<int *>(lds + L::oadj);
+    float *ps = lds + L::ops, *pd = ps + __umul24(P, kSparseVals);
+
+    float *tr = S.trace ? S.trace + (size_t)b * (size_t)S.trace_instance + (size_t)S.iter * S.trace_record : nullptr;
+#if BTBA_SOLVE_REPEAT > 1
+    for (int rep = 0; rep < BTBA_SOLVE_REPEAT; rep++) {
+    __syncthreads();
+#endif
+    const long long clk0 = tr ? (long long)clock64() : 0;
+#define BTBA_SSTAMP(slot) do { if (tr && tid == 0) tr[S.tr_clk + (slot)] = (float)((long long)clock64() - clk0); } while (0)
+
+    // ---- phase 1: everything this solve reads from global memory, issued at once (every load is a fabric-latency miss: the sweeps
+    // of other XCDs wrote the partials, the previous launch the poses).  Loads and stores WITHOUT conditions around them (see above):
+    // a dead slot repeats the last live one.
+    const float *T_in = S.T + __umul24(b, (unsigned)S.pose_stride), *x_in = S.x + __umul24(b, (unsigned)S.x_stride);
+    const v4 *sp4 = reinterpret_cast<const v4 *>(S.sparse_partials + (size_t)b * S.sp_stride);
+    const v4 *dp4 = reinterpret_cast<const v4 *>(S.dense_partials + (size_t)b * S.dp_stride);
+    // thread constants.  Entry role: lanes 0 .. 1007 keep one (row r, column c) of the 6 x 6 block pattern ([trans, rot] order) and one of 28
+    // pair groups; the two descriptors of that entry -- value = c1 rec[i1] + c2 rec[i2] -- come from the host's table
+    const unsigned grp = tid / 36u, rc = tid - 36u * grp, r6 = rc / 6u, c6 = rc - 6u * r6;
+    const int4 lut_d = *reinterpret_cast<const int4 *>(S.entry_lut + 4 * rc), lut_x = *reinterpret_cast<const int4 *>(S.entry_lut + 4 * (36 + rc));
+    // small arrays: one trip covers every window of this kernel
+    const float st_T = T_in[min(tid, 16u * N - 1u)];
+    const float st_x = x_in[min(tid, 6u * N - 1u)];
+    const int st_pij = S.pair_ij[min(tid, (unsigned)P - 1u)];
+    const int st_cross = Pd ? S.cross[min(tid, (unsigned)P - 1u)] : -1;
+    const int st_ao = Pd ? S.adj_off[min(tid, (unsigned)N)] : 0;
+    const int st_adj = Pd ? S.adj[min(tid, 2u * Pd - 1u)] : 0;
+    constexpr int kS4 = kSparseVals / 4, kD4 = kDenseVals / 4;
+    const int ns4 = S.use_sparse ? P * kS4 : 0, nd4 = Pd * kD4, n4 = ns4 + nd4;
+    v4 *ps4 = reinterpret_cast<v4 *>(ps), *pd4 = reinterpret_cast<v4 *>(pd);
+    if (S.sparse_chunks == 1 && S.dense_tiles == 1) {
+        // one partial per sum (every chip-filling batch): the reduced arrays ARE the partial arrays
+        for (int e0 = (int)tid; e0 < n4; e0 += 2 * nthr) {
+            const int ea = e0, eb = min(e0 + (int)nthr, n4 - 1);
+            const v4 fa = *(ea < ns4 ? sp4 + ea : dp4 + (ea - ns4)), fb = *(eb < ns4 ? sp4 + eb : dp4 + (eb - ns4));
+            *(ea < ns4 ? ps4 + ea : pd4 + (ea - ns4)) = fa;
+            *(eb < ns4 ? ps4 + eb : pd4 + (eb - ns4)) = fb;
+        }
+    } else {
+        // several partials per sum (small batches: up to 16 chunks / 8 tiles): two slots per lane, eight partials of each in flight; sums in partial order
+        const int max_parts = max(S.sparse_chunks, S.dense_tiles);
+        for (int e0 = (int)tid; e0 < n4; e0 += 2 * nthr) {
+            const v4 *src[2]; int per[2], parts[2], e_[2];
+            v4 acc[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int e = min(e0 + u * (int)nthr, n4 - 1);
+                const bool sp = e < ns4;
+                const int q = sp ? e : e - ns4, rec = sp ? q / kS4 : q / kD4;
+                e_[u] = e; per[u] = sp ? kS4 : kD4; parts[u] = sp ? S.sparse_chunks : S.dense_tiles;
+                src[u] = (sp ? sp4 : dp4) + __umul24(__umul24(rec, parts[u]), per[u]) + (q - rec * per[u]);
+                acc[u] = (v4){ 0.f, 0.f, 0.f, 0.f };
+            }
+            for (int c0 = 0; c0 < max_parts; c0 += 8) {
+                v4 g[2][8];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) g[u][c] = src[u][__umul24(c0 + c < parts[u] ? c0 + c : 0, per[u])];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) { const float live = c0 + c < parts[u] ? 1.0f : 0.0f; acc[u] += live * g[u][c]; }      // (a dead partial adds an exact zero)
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) *(e_[u] < ns4 ? ps4 + e_[u] : pd4 + (e_[u] - ns4)) = acc[u];
+        }
+    }
+    if (!S.use_sparse) for (int e = (int)tid; e < P * kS4; e += nthr) ps4[e] = (v4){ 0.f, 0.f, 0.f, 0.f };      // (read with weight 0 below)
+    vT[min(tid, 16u * N - 1u)] = st_T;
+    x_l[min(tid, 6u * N - 1u)] = st_x;
+    pair_ij_l[min(tid, (unsigned)P - 1u)] = st_pij; cross_l[min(tid, (unsigned)P - 1u)] = st_cross;
+    if (Pd) { adj_off_l[min(tid, (unsigned)N)] = st_ao; adj_l[min(tid, 2u * Pd - 1u)] = st_adj; }
+    // zero what the assembly does not write and the PCG reads: the matrix columns na .. 8 CPL - 1 and p beyond na
+    {
+        const int padc = 8 * CPL - na;
+        if (padc > 0) for (int e = (int)tid; e < na * padc; e += nthr) { const int row = e / padc, q = e - row * padc; A[row * lda + na + q] = 0.0f; }
+        if (tid < (unsigned)(lda - na)) vp[na + tid] = 0.0f;
+    }
+    BTBA_SSTAMP(0);
+    __syncthreads();
+    BTBA_SSTAMP(1);
+
+    const float w_s = S.use_sparse ? S.w_sparse : 0.0f;
+    const unsigned t21 = tri21((int)r6, (int)c6);
+    // ---- phase 2a: off-diagonal blocks.  Lane (group g, entry rc) walks the canonical pairs (N - 1) + g, + 28, ... (the pairs with i >= 1):
+    //   A_ij[r][c] = -(w_s (J_i^T J_j)[r][c] + S_dense[r][c]),  A_ji = A_ij^T     (SolverBundlingDenseUtil.h:349-385; FlipJtJ keeps the (target lower) listing)
+    if (tid < 1008u) {
+        const unsigned xi1 = lut_x.x & 255, xi2 = lut_x.y;
+        const float xc1 = __int_as_float(lut_x.z), xc2 = __int_as_float(lut_x.w);
+        constexpr int kU = 4;                                                // pairs per lane and batch: their table entries, then their sums, are read together
+        for (int p0 = (N - 1) + (int)grp; p0 < P; p0 += 28 * kU) {
+            int pij[kU], dq[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) { const int p = min(p0 + 28 * u, P - 1); pij[u] = pair_ij_l[p]; dq[u] = cross_l[p]; }      // (a dead slot repeats pair P - 1: the same values to the same places)
+            float m1[kU], m2[kU], sd[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const float *rec = ps + __umul24(min(p0 + 28 * u, P - 1), kSparseVals);
+                m1[u] = rec[xi1]; m2[u] = rec[xi2];
+                sd[u] = Pd ? pd[__umul24(max(dq[u], 0), kDenseVals) + t21] : 0.0f;       // (no dense pair for this canonical pair: pair 0's value, dropped below)
+            }
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const unsigned i = (pij[u] >> 8) - 1, j = (pij[u] & 255) - 1;
+                const float v = -(w_s * (xc1 * m1[u] + xc2 * m2[u])) - (dq[u] >= 0 ? sd[u] : 0.0f);
+                A[__umul24(6u * i + r6, lda) + 6u * j + c6] = v;
+                A[__umul24(6u * j + c6, lda) + 6u * i + r6] = v;
+            }
+        }
+    }
+    // ---- phase 2b: frame sums.  Sum v of frame k over the frame's pairs in ascending partner order: (m, k) for m < k -- canonical index
+    // k - 1, then + (N - m - 2) per step -- and (k, m) for m > k: consecutive indices from k N - k (k + 1) / 2.
+    //   sparse (record slots of btba_kernels.hpp): 0 n | 1..3 s | 4..9 M | 10..12 rhs trans | 13..15 rhs rot | 16 prec trans | 17..19 prec rot
+    //   dense: 20 + (0..20 S upper triangle, 21..26 g)
+    // (sparse sums: one per lane on lanes 0 .. 20 (N - 1) - 1; dense sums: four per lane -- a 16-byte slot of the 28-float record -- on lanes
+    // 576 .. 576 + 7 (N - 1) - 1 (behind the 400 sparse lanes of a 21-frame window): a wave runs one of the two loops, the heavy waves sit on different SIMDs)
+    if (tid < 20u * (N - 1)) {
+        const unsigned fk1 = tid / 20u, fv = tid - 20u * fk1;                // frame fk1 + 1
+        const int fk = (int)fk1 + 1;
+        // record slot when the frame is the pair's i / j end
+        unsigned off_i, off_j;
+        float sg_i = 1.0f;
+        if (fv == 0) { off_i = off_j = 0; }
+        else if (fv < 4) { off_i = fv; off_j = fv + 3; }
+        else if (fv < 10) { off_i = fv + 3; off_j = fv + 9; }
+        else if (fv < 13) { off_i = off_j = fv + 18; sg_i = -1.0f; }
+        else if (fv < 16) { off_i = fv + 18; off_j = fv + 21; sg_i = -1.0f; }
+        else if (fv == 16) { off_i = off_j = 37; }
+        else { off_i = fv + 21; off_j = fv + 24; }
+        // partner slot q = 0 .. N - 2: m = q (q < k: the frame is the j end of pair (m, k)) or q + 1 (the i end of pair (k, m)).  BOTH candidates are
+        // loaded for every slot -- the j one along the running index, the i one at a fixed stride (an immediate offset) -- and one is selected:
+        // eight instructions per term instead of fourteen.  Slots beyond the frame's pairs read a live address (or the slack behind the records)
+        // and are dropped by the select.
+        const unsigned lim = __umul24((unsigned)P - 1u, kSparseVals) + off_j;
+        unsigned aj = __umul24((unsigned)fk - 1u, kSparseVals) + off_j;      // pair (0, k)
+        const float *pi = ps + __umul24((unsigned)(fk * N - fk * (fk + 1) / 2 - fk), kSparseVals) + off_i;      // pair (k, q + 1) at + 44 q
+        int stride = kSparseVals * (N - 2);
+        float acc_j = 0.0f, acc_i = 0.0f;
+        for (int q0 = 0; q0 < N - 1; q0 += 8) {
+            float vj[8], vi[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { vj[u] = ps[min(aj, lim)]; vi[u] = pi[kSparseVals * (q0 + u)]; aj += stride; stride -= kSparseVals; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int q = q0 + u; acc_j += (q < fk) ? vj[u] : 0.0f; acc_i += (q >= fk && q < N - 1) ? vi[u] : 0.0f; }
+        }
+        F[__umul24(fk1, kFrameSums) + fv] = acc_j + sg_i * acc_i;
+    } else if (tid >= 576u && tid < 576u + 7u * (N - 1)) {
+        const unsigned t = tid - 576u, fk1 = t / 7u, sl = t - 7u * fk1;      // slot sl of frame fk1 + 1: record floats 4 sl .. 4 sl + 3 (S: 0 .. 20, g: 21 .. 26, count: 27)
+        v4 acc = (v4){ 0.f, 0.f, 0.f, 0.f };
+        if (Pd) {
+            const int qa = adj_off_l[fk1 + 1], qb = adj_off_l[fk1 + 2];
+            const v4 *pd4s = reinterpret_cast<const v4 *>(pd) + sl;
+            for (int q0 = qa; q0 < qb; q0 += 8) {
+                int a[8];
+                v4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) a[u] = adj_l[min(q0 + u, qb - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = pd4s[__umul24(a[u] >> 1, kDenseVals / 4)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    // g: + for the source frame (row_j = a), - for the target frame (row_i = -a); S: + for both.  (a dead slot repeats the last entry with weight 0)
+                    const float live = q0 + u < qb ? 1.0f : 0.0f, sg = (a[u] & 1) ? live : -live;
+                    const float wx = sl == 6u ? sg : live, wr = sl >= 5u ? sg : live;
+                    acc.x += wx * v[u].x; acc.y += wr * v[u].y; acc.z += wr * v[u].z; acc.w += wr * v[u].w;
+                }
+            }
+        }
+        *reinterpret_cast<v4 *>(F + __umul24(fk1, kFrameSums) + 20u + 4u * sl) = acc;
+    }
+    __syncthreads();
+    BTBA_SSTAMP(2);
+
+    // ---- phase 2c: diagonal blocks, right-hand side, Jacobi diagonal from the frame sums
+    if (tid < 36u * (N - 1)) {
+        const unsigned i1 = lut_d.x & 255, i2 = lut_d.y;                     // indices into (n, s[3], -, M[6]) of endpoint i -> frame sums 0, 1..3, 4..9
+        const unsigned di1 = i1 < 4 ? i1 : i1 - 3, di2 = i2 < 4 ? i2 : i2 - 3;
+        const float dc1 = __int_as_float(lut_d.z), dc2 = __int_as_float(lut_d.w);
+        const float *Fk = F + __umul24(grp, kFrameSums);                     // frame grp + 1
+        float v = w_s * (dc1 * Fk[di1] + dc2 * Fk[di2]);
+        if (Pd) v += Fk[20 + t21];
+        A[__umul24(6u * grp + r6, lda) + 6u * grp + c6] = v;
+    } else if (tid < 36u * (N - 1) + na) {
+        const unsigned a = tid - 36u * (N - 1), k1 = a / 6u, r = a - 6u * k1;
+        const float *Fk = F + __umul24(k1, kFrameSums);
+        // b = -J^T r: sparse part weighted (SolverBundlingEquationsLie.h:60-137), dense part from the sweep's g;  M^-1 = 1 / diag of the UNWEIGHTED sparse J^T J (Lie.h:107-108)
+        const float rhs = w_s * Fk[10 + r] - (Pd ? Fk[41 + r] : 0.0f);
+        const float md = Fk[r < 3 ? 16 : 14 + r];
+        const float minv = (md > kEps) ? 1.0f / md : 1.0f;
+        vb[a] = rhs;
+        vM[a] = minv;
+        vp[a] = minv * rhs;                                                  // p_0 = M^-1 r_0
+    }
+    __syncthreads();
+    BTBA_SSTAMP(3);
+    if (tr) {
+        // trace order (rot, trans) per frame; internal [trans, rot]; frame 0's entries are zero
+        const int n = 6 * N;
+        for (int e = (int)tid; e < n; e += nthr) {
+            const int k = e / 6, r = e % 6, o = k * 6 + (r < 3 ? r + 3 : r - 3);
+            tr[S.tr_rhs + o] = k ? vb[e - 6] : 0.0f;
+            tr[S.tr_prec + o] = k ? vM[e - 6] : 0.0f;
+        }
+        for (int e = (int)tid; e < n * n; e += nthr) { const int row = e / n, col = e - row * n; tr[S.tr_A + e] = (row < 6 || col < 6) ? 0.0f : A[(row - 6) * lda + col - 6]; }
+        for (int e = (int)tid; e < Pd * kDenseVals; e += nthr) tr[S.tr_dpair + e] = pd[e];
+    }
+    BTBA_SSTAMP(4);
+
+    // ---- phase 3: Jacobi-preconditioned CG (SolverBundling.cu:575-818; the absolute epsilon guards of :746-818 as they stand).
+    // A step = the matrix-vector product on every wave that owns rows (8 rows x 8 lanes each: ~20 instructions, ~3 waves per SIMD), a barrier,
+    // the two dot products and the vector updates on wave 0 ALONE (a chain of ~60 dependent instructions: a wave that shares its SIMD with
+    // others running the same chain retires it slower -- eleven waves doing it redundantly measured 8.2 k cycles for the five steps, three
+    // waves 7.3 k), a barrier.
+    const int wave = (int)(tid >> 6), lane = (int)(tid & 63u);
+    const int n_pw = (na + 7) >> 3;                                          // waves that own matrix rows
+    const bool pw = wave < n_pw;
+    {
+        const int a_row = 8 * wave + (lane >> 3), h = lane & 7;
+        const bool row_live = pw && a_row < na;
+        f2 Ar[CPL / 2];
+        float r_[2], m_[2], p_[2], d_[2];
+        float rz = 0.0f;
+        if (pw) {
+            const float4 *src = reinterpret_cast<const float4 *>(A + min(a_row, na - 1) * lda + h * CPL);
+#pragma unroll
+            for (int k = 0; k < CPL / 4; k++) { const float4 v = src[k]; Ar[2 * k] = (f2){ v.x, v.y }; Ar[2 * k + 1] = (f2){ v.z, v.w }; }
+        }
+        if (wave == 0) {
+            float part = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int idx = lane + 64 * j;
+                const bool live = idx < na;
+                r_[j] = live ? vb[idx] : 0.0f; m_[j] = live ? vM[idx] : 0.0f; d_[j] = 0.0f;
+                p_[j] = m_[j] * r_[j];                                      // (= what phase 2c stored in vp)
+                part += r_[j] * p_[j];
+            }
+            rz = wave_sum_all(part);
+        }
+        for (int li = 0; li < S.n_pcg; li++) {
+            if (pw) {
+                const float4 *p4 = reinterpret_cast<const float4 *>(vp + h * CPL);
+                f2 qa = (f2){ 0.f, 0.f }, qb = qa, qc = qa, qd = qa;
+#pragma unroll
+                for (int k = 0; k < CPL / 4; k++) {
+                    const float4 pc = p4[k];
+                    if (k & 1) { qc = __builtin_elementwise_fma(Ar[2 * k], (f2){ pc.x, pc.y }, qc); qd = __builtin_elementwise_fma(Ar[2 * k + 1], (f2){ pc.z, pc.w }, qd); }
+                    else { qa = __builtin_elementwise_fma(Ar[2 * k], (f2){ pc.x, pc.y }, qa); qb = __builtin_elementwise_fma(Ar[2 * k + 1], (f2){ pc.z, pc.w }, qb); }
+                }
+                if (CPL > 4) { qa += qc; qb += qd; }
+                float s = (qa.x + qa.y) + (qb.x + qb.y);
+                s = dpp_add<0xB1, 0xf>(s);                                  // + the row's other seven lanes: quad_perm [1,0,3,2],
+                s = dpp_add<0x4E, 0xf>(s);                                  //   quad_perm [2,3,0,1],
+                s = dpp_add<0x141, 0xf>(s);                                 //   row_half_mirror
+                if (h == 0 && row_live) vAp[a_row] = s;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                float ap_[2], z_[2];
+                float part = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; j++) { const int idx = lane + 64 * j; ap_[j] = idx < na ? vAp[idx] : 0.0f; part += p_[j] * ap_[j]; }
+                const float pAp = wave_sum_all(part);
+                const float alpha = (pAp > kEps) ? rz * __builtin_amdgcn_rcpf(pAp) : 0.0f;
+                part = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    d_[j] = d_[j] + alpha * p_[j];
+                    r_[j] = r_[j] - alpha * ap_[j];
+                    z_[j] = m_[j] * r_[j];
+                    part += z_[j] * r_[j];
+                }
+                const float rz_new = wave_sum_all(part);
+                const float beta = (rz > kEps) ? rz_new * __builtin_amdgcn_rcpf(rz) : 0.0f;
+                if (tr && tid == 0) { float *sc = tr + S.tr_pcg + 4 * li; sc[0] = pAp; sc[1] = alpha; sc[2] = rz_new; sc[3] = beta; }
+                rz = rz_new;
+#pragma unroll
+                for (int j = 0; j < 2; j++) { p_[j] = z_[j] + beta * p_[j]; if (lane + 64 * j < na) vp[lane + 64 * j] = p_[j]; }
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) if (lane + 64 * j < na) vd[lane + 64 * j] = d_[j];
+        }
+    }
+    __syncthreads();
+    BTBA_SSTAMP(5);
+
+    // ---- phase 4: x_k <- Log(Exp(delta_k) Exp(x_k)), the next iterate's T (SolverBundling.cu:805-815, 890-897), one lane per frame ...
+    if (tid < (unsigned)N) {
+        const int k = (int)tid;
+        float *xk = S.x + __umul24(b, (unsigned)S.x_stride) + 6 * k;
+        const float *xl = x_l + 6 * k;
+        float rot[3] = { xl[0], xl[1], xl[2] }, trans[3] = { xl[3], xl[4], xl[5] };
+        if (k > 0) {
+            const float *dk = vd + 6 * (k - 1);
+            const float dW[3] = { dk[3], dk[4], dk[5] }, dT[3] = { dk[0], dk[1], dk[2] };
+            const Mat4 U = pose_to_matrix(dW, dT);
+            Mat4 C = load_mat4(vT + 16 * k);                                // = Exp(x_k), from the previous launch: a pose_to_matrix result,
+            C.m[12] = 0.0f; C.m[13] = 0.0f; C.m[14] = 0.0f; C.m[15] = 1.0f;   // whose last row is these constants (the product's dead terms fold away, same bits)
+            matrix_to_pose(mat_mul(U, C), rot, trans);
+            xk[0] = rot[0]; xk[1] = rot[1]; xk[2] = rot[2]; xk[3] = trans[0]; xk[4] = trans[1]; xk[5] = trans[2];
+        }
+        const Mat4 E = pose_to_matrix(rot, trans);
+        store_mat4(S.T + __umul24(b, (unsigned)S.pose_stride) + 16 * k, E);
+        if (S.poses_out) store_mat4(S.poses_out + 16 * (b * N + k), E);      // last iterate: convertPosesToMatricesCU (SBA.cpp:115)
+        store_mat4(vE + 16 * k, E);
+        if (tr) {
+            for (int q = 0; q < 3; q++) { tr[S.tr_x + 6 * k + q] = rot[q]; tr[S.tr_x + 6 * k + 3 + q] = trans[q]; }
+            for (int q = 0; q < 16; q++) tr[S.tr_T + 16 * k + q] = E.m[q];
+            for (int q = 0; q < 3; q++) { tr[S.tr_delta + 6 * k + q] = k ? vd[6 * (k - 1) + 3 + q] : 0.0f; tr[S.tr_delta + 6 * k + 3 + q] = k ? vd[6 * (k - 1) + q] : 0.0f; }
+        }
+    }
+    BTBA_SSTAMP(6);
+    __syncthreads();
+    // ... and its generic cofactor inverse (float4x4::getInverse, cuda_SimpleMatrixUtil.h:978-1104; btba_device.hpp: mat_inverse) on sixteen lanes
+    // per frame: lane (R, C) forms adjugate entry (R, C) = cofactor of element (C, R) from the same six triple products, the determinant is the
+    // first row against the adjugate's first column (lanes 0, 4, 8, 12 of the group)
+    if (tid < 16u * N) {
+        const unsigned f = tid >> 4, e = tid & 15u, R = e >> 2, Cc = e & 3u;
+        const float *m = vE + 16 * f;
+        const int r0 = (Cc == 0) ? 1 : 0, r1 = (Cc <= 1) ? 2 : 1, r2 = (Cc <= 2) ? 3 : 2;
+        const int c0 = (R == 0) ? 1 : 0, c1 = (R <= 1) ? 2 : 1, c2 = (R <= 2) ? 3 : 2;
+        const float m00 = m[4 * r0 + c0], m01 = m[4 * r0 + c1], m02 = m[4 * r0 + c2];
+        const float m10 = m[4 * r1 + c0], m11 = m[4 * r1 + c1], m12 = m[4 * r1 + c2];
+        const float m20 = m[4 * r2 + c0], m21 = m[4 * r2 + c1], m22 = m[4 * r2 + c2];
+        const float t1 = m00 * m11 * m22, t2 = m00 * m12 * m21, t3 = m10 * m01 * m22, t4 = m10 * m02 * m21, t5 = m20 * m01 * m12, t6 = m20 * m02 * m11;
+        const float even = ((((t1 - t2) - t3) + t4) + t5) - t6;
+        const float adj = ((R + Cc) & 1) ? -even : even;
+        const int g0 = lane & ~15;
+        const float a0 = __shfl(adj, g0, 64), a4 = __shfl(adj, g0 + 4, 64), a8 = __shfl(adj, g0 + 8, 64), a12 = __shfl(adj, g0 + 12, 64);
+        const float det = m[0] * a0 + m[1] * a4 + m[2] * a8 + m[3] * a12;
+        const float rdet = 1.0f / det;
+        S.Tinv[__umul24(b, (unsigned)S.pose_stride) + tid] = adj * rdet;
+    }
+    BTBA_SSTAMP(7);
+#undef BTBA_SSTAMP
+#if BTBA_SOLVE_REPEAT > 1
+    }
+#endif
+}
+
+}  // namespace btba

@@ -292,6 +292,20 @@ class BatchSolver:
                 raise ValueError(f"{name}: expected {n} weights")
             self._w_it.append(a)
             setattr(self.params, name, a.ctypes.data)
+        self.params.n_weights_per_iter = n if self._w_it else 0
+
+    def _check_iteration_weights(self):
+        """btba_params carries raw host pointers and no length: the arrays handed to set_iteration_weights must still hold n_gn_iters weights when a
+        solve is enqueued (a caller that raises params.n_gn_iters afterwards would make the library read past their end)."""
+        n = int(self.params.n_gn_iters)
+        arrays = getattr(self, "_w_it", [])
+        for name in ("weights_sparse_per_iter", "weights_dense_per_iter"):
+            ptr = getattr(self.params, name)
+            if not ptr:
+                continue
+            a = next((w for w in arrays if w.ctypes.data == ptr), None)
+            if a is None or a.shape != (n,):
+                raise ValueError(f"{name}: set for {'?' if a is None else a.shape[0]} iterations, params.n_gn_iters is {n} -- call set_iteration_weights again")
 
     @staticmethod
     def pack_correspondences(corr_list, n_frames):
@@ -316,6 +330,7 @@ class BatchSolver:
         pair_offsets_dev: CUDA int32/uint32 [B,P+1]; poses_dev: CUDA float32 [B,N,4,4] updated in place.
         Asynchronous; call .ws.sync() / .ws.collect_stats().  Returns a device trace tensor or None."""
         torch = _torch()
+        self._check_iteration_weights()
         B, N, Hd, Wd = campos.shape[:4]
         intr = np.ascontiguousarray(intr, np.float32)
         stride = corr_dev.shape[1] if corr_dev is not None else 0
@@ -381,6 +396,7 @@ class BatchSolver:
         keep their caches across solves (None: derived inside every solve).  With aux["corr24"] (pack_correspondences24) corr_dev may be None;
         corr_stride then gives the entries per instance block of the array that was packed."""
         torch = _torch()
+        self._check_iteration_weights()
         B, N = zn.shape[:2]
         Kf = np.ascontiguousarray(K, np.float32).reshape(9)
         stride = corr_dev.shape[1] if corr_dev is not None else int(corr_stride or 0)

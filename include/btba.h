@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BTBA_VERSION 104     /* 104: chained launch (BTBA_OPT_CHAIN*, BTBA_ESCHED, btba_stats.chain_iterations), btba_params.weights_*_per_iter, btba_workspace_live_blocks; 103: btba_params.reduction_mode, BTBA_FLAG_KEYED_CORR = 4096,
+#define BTBA_VERSION 105     /* 105: BTBA_OPT_SOLVE_SMALL, btba_params.n_weights_per_iter; 104: chained launch (BTBA_OPT_CHAIN*, BTBA_ESCHED, btba_stats.chain_iterations), btba_params.weights_*_per_iter, btba_workspace_live_blocks; 103: btba_params.reduction_mode, BTBA_FLAG_KEYED_CORR = 4096,
                                 btba_workspace_set_option, btba_zn_aux.corr24 + btba_pack_correspondences24.  A caller built against another version's structs must not
                                 call in: check btba_version() == BTBA_VERSION once after loading the library (the Python and C++ host layers do). */
 
@@ -129,6 +129,8 @@ typedef struct btba_params {
      * no weight, SolverBundlingEquationsLie.h:107-108) while right-hand side and operator take the factor 0. */
     const float *weights_sparse_per_iter;
     const float *weights_dense_per_iter;
+    int32_t n_weights_per_iter;   /* length of the arrays above as the caller allocated them: with either pointer set it must equal n_gn_iters (BTBA_EINVAL
+                                   * otherwise -- the library never reads past what was stated); ignored when both are NULL.  btba_params_default: 0 */
 } btba_params;
 
 /* Timing / diagnostics filled by the solve entry points (all times in milliseconds, measured
@@ -228,9 +230,12 @@ enum {
                                            fit beside the frames are read with NON-TEMPORAL loads, so that the read-once stream does not evict the frames the dense items
                                            re-read every iteration (c3 x 32: 185 -> 198 k GN it/s; never on object-masked frames); 0: plain loads always; 1: non-temporal
                                            always.  A cache policy: same bits.                                                    env BTBA_CORR_NT */
-    BTBA_OPT_COUNT_LIVE           = 13  /* 1: the dense sweep's block-walk workgroups add the number of 8 x 8 pixel blocks they actually walk (the blocks the hull
+    BTBA_OPT_COUNT_LIVE           = 13, /* 1: the dense sweep's block-walk workgroups add the number of 8 x 8 pixel blocks they actually walk (the blocks the hull
                                            test could not prove dead) to a counter of the workspace -- setting the option clears it, btba_workspace_live_blocks
                                            reads it.  Measurement aid (bench.py: roofline.executed); one atomic per workgroup while it is on. */
+    BTBA_OPT_SOLVE_SMALL          = 16  /* 1 (default): windows of <= 21 frames run the per-instance system solve k_solve_small (round 5: register-resident
+                                           multi-wave PCG, frame-sum assembly, sixteen-lane inverse); 0: k_system_solve, the kernel of rounds 1-4, as for larger
+                                           windows.  Same sums in another order: results agree to rounding (tests/test_gpu_parity.py).   env BTBA_SOLVE_LEGACY=1 = 0 */
 };
 BTBA_API int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value);
 /* Blocks walked by the dense sweeps enqueued since BTBA_OPT_COUNT_LIVE was last set to 1 (synchronises with the workspace stream). */

@@ -15,11 +15,11 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.btba_version() == 104
+    assert L.btba_version() == 105
 
 
 def test_struct_sizes_match_header():
-    assert C.sizeof(_lib.Params) == 16 * 4 + 2 * 8        # 15 words, 4 bytes of padding, two host pointers (weights_*_per_iter)
+    assert C.sizeof(_lib.Params) == 16 * 4 + 2 * 8 + 8    # 15 words, 4 bytes of padding, two host pointers (weights_*_per_iter), their length + 4 bytes of tail padding
     assert _lib.ENTRYJ_DTYPE.itemsize == 32          # struct EntryJ, SIFTImageManager.h:44-59
     L = _lib.TraceLayout()
     _lib.lib().btba_trace_layout_get(15, 105, 5, C.byref(L))
@@ -160,7 +160,7 @@ def test_python_constants_match_the_header():
         assert getattr(_lib, "FLAG_" + name) == v, name
     assert defines["BTBA_MAX_FRAMES"] == 85 and defines["BTBA_MAX_FRAMES_LDS"] == 31     # the reference's MAX_NUM_IMAGES; the LDS-resident limit
     opts = {k[len("BTBA_OPT_"):]: v for k, v in enums.items() if k.startswith("BTBA_OPT_")}
-    assert len(opts) == 15 and all(getattr(_lib, "OPT_" + name) == v for name, v in opts.items())
+    assert len(opts) == 16 and all(getattr(_lib, "OPT_" + name) == v for name, v in opts.items())
     assert enums["BTBA_REDUCE_DETERMINISTIC"] == _lib.REDUCE_DETERMINISTIC and enums["BTBA_REDUCE_ATOMIC"] == _lib.REDUCE_ATOMIC
     assert 128 not in flags.values()                    # the bit that was BTBA_FLAG_FUSE stays without a meaning
     assert C.sizeof(_lib.Stats) == 104      # (chain_iterations took the struct's tail padding)

@@ -27,11 +27,14 @@ class Batch:
         self.poses0 = torch.from_numpy(np.stack([pb.poses_init for pb in pbs])).to(self.dev)
         self.masked = masked
 
-    def solve(self, chain, corr24=False, aux=False, tiles=0, period=0, timeout_ms=None, relayout=True, corr_nt=None):
-        """-> (poses [B, N, 4, 4], stats).  chain: BTBA_OPT_CHAIN (-1 library's choice, 0 plain schedule, 1 chained wherever supported)."""
+    def solve(self, chain, corr24=False, aux=False, tiles=0, period=0, timeout_ms=None, relayout=True, corr_nt=None, legacy_solve=False):
+        """-> (poses [B, N, 4, 4], stats).  chain: BTBA_OPT_CHAIN (-1 library's choice, 0 plain schedule, 1 chained wherever supported).
+        legacy_solve: the plain schedule's system solves by k_system_solve (BTBA_OPT_SOLVE_SMALL = 0) -- the sums, in the order, that the chained
+        launch's in-launch solve items reproduce bit for bit (round 5's k_solve_small forms the same sums in another order)."""
         from bundletrack_amd.optimizer import BatchSolver, Workspace
         ws = Workspace()
         ws.set_option(_lib.OPT_CHAIN, chain)
+        ws.set_option(_lib.OPT_SOLVE_SMALL, 0 if legacy_solve else 1)
         ws.set_option(_lib.OPT_CHAIN_SPARSE_PERIOD, period)
         ws.set_option(_lib.OPT_RELAYOUT, 1 if relayout else 0)
         if timeout_ms is not None:
@@ -67,8 +70,8 @@ class Batch:
 def test_chained_launch_has_the_bits_of_the_plain_schedule(name, B, K, m, masked, tiles, period):
     pbs = [S.make_problem(K, m, 900 + 17 * b, background=not masked, full_res=False) for b in range(B)]
     bt = Batch(pbs, masked)
-    plain, st0 = bt.solve(0, tiles=tiles)
-    chained, st1 = bt.solve(1, tiles=tiles, period=period)
+    plain, st0 = bt.solve(0, tiles=tiles, legacy_solve=True)
+    chained, st1 = bt.solve(1, tiles=tiles, period=period, legacy_solve=True)      # (the last iteration's solve is a launch of its own: the same kernel as the plain schedule's)
     assert st0["chain_iterations"] == 0 and st1["chain_iterations"] == 7, (st0, st1)
     assert np.isfinite(chained).all()
     assert np.array_equal(plain, chained), f"{name}: worst difference {np.abs(plain - chained).max():.3e}"
@@ -94,8 +97,12 @@ def test_the_benched_path_is_pinned(c3x32):
     assert np.array_equal(benched, plain), f"worst difference {np.abs(benched - plain).max():.3e}"
     wire, _ = bt.solve(0, relayout=False)                        # ... and with every iteration reading the 32-byte wire format (the default; what bench.py's value_incl_pack times)
     assert np.array_equal(benched, wire)
-    chained, st1 = bt.solve(1, corr24=True, aux=True)            # ... and the chained launch of the same batch, same tile count
-    assert st1["chain_iterations"] == 7 and np.array_equal(benched, chained)
+    legacy, _ = bt.solve(-1, corr24=True, aux=True, legacy_solve=True)      # the same batch with rounds 1-4's system solve (k_system_solve) ...
+    chained, st1 = bt.solve(1, corr24=True, aux=True, legacy_solve=True)    # ... whose sums the chained launch of the same batch reproduces bit for bit
+    assert st1["chain_iterations"] == 7 and np.array_equal(legacy, chained)
+    worst = max(max(S.pose_error(benched[b, k], legacy[b, k])) for b in range(bt.B) for k in range(15))
+    print(f"k_solve_small vs k_system_solve on the benched batch: worst final pose difference {worst:.2e}")
+    assert worst < 1e-4
     from oracle import reference as R
     if not os.path.exists(R.SO_SOLVER):
         pytest.skip("oracle/_ref/libbtba_ref_solver.so not built")
@@ -127,9 +134,9 @@ def test_chained_launch_is_reproducible_under_load(c3x32):
     solves of the full c3 x 32 batch -- 1 536 resident workgroups, every compute unit's L1 and scalar cache warm with the previous
     iterations' lines -- all carry the bits of the first one (which test_the_benched_path_is_pinned holds against the plain schedule)."""
     bt = c3x32
-    first, _ = bt.solve(1, corr24=True, aux=True)
+    first, _ = bt.solve(1, corr24=True, aux=True, legacy_solve=True)
     for rep in range(24):
-        again, st = bt.solve(1, corr24=True, aux=True, period=(3 if rep % 2 else 0))
+        again, st = bt.solve(1, corr24=True, aux=True, period=(3 if rep % 2 else 0), legacy_solve=True)
         assert st["chain_iterations"] == 7
         assert np.array_equal(first, again), f"run {rep}: worst difference {np.abs(first - again).max():.3e}"
 
@@ -137,10 +144,10 @@ def test_chained_launch_is_reproducible_under_load(c3x32):
 def test_c3_masked_batch_chained_equals_plain():
     pbs = [S.make_problem(15, 2000, S.config_seed(5, b), background=False, full_res=False) for b in range(32)]
     bt = Batch(pbs, masked=True)
-    plain, st0 = bt.solve(0, aux=True)
-    auto, st2 = bt.solve(-1, aux=True)              # the library's own choice for object-masked frames is the plain schedule (their sweeps are shorter than an in-launch solve)
+    plain, st0 = bt.solve(0, aux=True, legacy_solve=True)
+    auto, st2 = bt.solve(-1, aux=True, legacy_solve=True)              # the library's own choice for object-masked frames is the plain schedule (their sweeps are shorter than an in-launch solve)
     assert st2["chain_iterations"] == 0 and np.array_equal(plain, auto)
-    chained, st1 = bt.solve(1, aux=True)
+    chained, st1 = bt.solve(1, aux=True, legacy_solve=True)
     assert st0["chain_iterations"] == 0 and st1["chain_iterations"] == 7 and st1["dense_tiles"] == 1, (st0, st1)
     assert np.array_equal(plain, chained), f"worst difference {np.abs(plain - chained).max():.3e}"
 

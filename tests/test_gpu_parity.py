@@ -818,3 +818,42 @@ def test_randomised_windows_are_explained(gpu, oracle):
         assert rec["unexplained_iterates"] == [], rec
         n_tight += max(rec["per_iterate"]) < 1e-4
     assert n_tight >= 7               # the well-posed half of the draw holds the plain 1e-4 bar on every iterate
+
+
+@pytest.mark.parametrize("K", [2, 3, 6, 7, 11, 12, 15, 17, 18, 21], ids=lambda k: f"K{k}")
+def test_small_solve_kernel_agrees_with_the_legacy_kernel(gpu, K):
+    """k_solve_small (round 5, BTBA_OPT_SOLVE_SMALL = 1, the default for windows of <= 21 frames) against k_system_solve (0) on the same inputs: the
+    same sums in another order.  Window sizes at both ends of each of its four instantiations (8 x 4 / 8 / 12 / 16 matrix columns per row group:
+    <= 6 / 11 / 17 / 21 frames), object-masked frames, two instances per batch (one partial per sum at K >= 15, several below), per iterate:
+    system matrix, right-hand side, Jacobi diagonal and accepted-pixel counts of the first linearisation to round-off, iterates within the 1e-4 bar
+    while the decisions are identical."""
+    from helpers import first_decision_divergence
+    insts = [S.make_problem(K, 40, seed=500 + 10 * K + b, background=False, full_res=False) for b in range(2)]
+    zn = np.stack([S.compact_cache(pb) for pb in insts])
+    pb0 = insts[0]
+    bs = gpu.BatchSolver(gpu.ws)
+    corr, offs, mx = bs.pack_correspondences([pb.corr for pb in insts], K)
+    zn_d = gpu.torch.from_numpy(zn).to(gpu.dev)
+    corr_d = gpu.torch.from_numpy(corr.view(np.uint8).reshape(2, -1, 32)).to(gpu.dev); offs_d = gpu.torch.from_numpy(offs.astype(np.int32)).to(gpu.dev)
+    views = {}
+    try:
+        for opt in (0, 1):
+            gpu.ws.set_option(_lib.OPT_SOLVE_SMALL, opt)
+            poses_d = gpu.torch.from_numpy(np.stack([pb.poses_init for pb in insts]).astype(np.float32)).to(gpu.dev)
+            views[opt] = bs.trace_view(bs.solve_zn(zn_d, pb0.H, pb0.W, pb0.K, corr_d, offs_d, mx, poses_d, trace=True))
+    finally:
+        gpu.ws.set_option(_lib.OPT_SOLVE_SMALL, 1)
+    a, b = views[0], views[1]
+    for inst in range(2):
+        A0, A1 = a.A[inst, 0], b.A[inst, 0]
+        assert np.abs(A0 - A1).max() <= 2e-5 * np.abs(A0).max(), "system matrix of the first linearisation"
+        assert np.abs(a.rhs[inst, 0] - b.rhs[inst, 0]).max() <= 1e-4 * max(np.abs(a.rhs[inst, 0]).max(), 1e-6)
+        assert np.abs(a.precond[inst, 0] - b.precond[inst, 0]).max() <= 1e-5 * np.abs(a.precond[inst, 0]).max()
+        assert np.array_equal(a.dense_pair[inst, 0, :, 27], b.dense_pair[inst, 0, :, 27])
+        div = first_decision_divergence(b.pcg_scalars[inst], b.dense_pair[inst][..., 27], a.pcg_scalars[inst], np.rint(a.dense_pair[inst][..., 27]))
+        first = div[0] if div is not None else a.T_after.shape[1]
+        for it in range(first):
+            for k in range(K):
+                r, t = S.pose_error(a.T_after[inst, it, k], b.T_after[inst, it, k])
+                assert r < 1e-4 and t < 1e-4, f"K={K} instance {inst} iterate {it} frame {k}: {r:.2e} rad / {t:.2e} m (first differing decision: {div})"
+        assert np.isfinite(b.T_after[inst]).all()
