@@ -81,6 +81,31 @@ def aggregate(per_rank):
     return total / slowest if slowest > 0 else float("nan"), slowest
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (/sys/fs/cgroup/cpu.max, v2; cpu.cfs_quota_us, v1).
+    os.cpu_count() reports the machine (256 on a gpurun box whose container is allowed 16): sizing worker pools from it oversubscribes."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            quota = None
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
+
+
 def bind_rank_to_cpus(local_rank: int, local_world: int, gpu_index: int | None = None):
     """Give every rank of a node its own CPUs, preferably on the NUMA node of its GPU: each rank is one launcher thread issuing ~10 k kernel
     launches per second, and eight of them sharing one CPU quota (or bouncing across sockets) would make the host the bottleneck of an

@@ -74,3 +74,26 @@ def test_bench_spawns_its_own_ranks():
     assert sum(r["gn_iters"] for r in d["per_rank"]) == 2 * 4 * 7 * 3
     # --same-instances: both ranks solved the same seeds -> the same poses, bit for bit
     assert d["per_rank"][0]["pose_checksum"] > 0 and d["per_rank"][0]["pose_checksum"] == d["per_rank"][1]["pose_checksum"]
+
+
+def test_eight_ranks_first_run():
+    """What the driver's 8-GPU box runs first, as far as a one-GPU box can show it: `bench.py --gpus 8` spawning EIGHT ranks (sharing the one device, gather
+    on gloo), each with its own worker pool sized from the CPUs the container really has (sharding.usable_cpus), the same two instances on every rank:
+    eight equal pose checksums, eight per-rank records, the whole-job value = all iterations / the slowest rank."""
+    env = dict(os.environ, BTBA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BTBA_BENCH_NPROC"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--instances", "2", "--distinct", "2", "--no-cpu-baseline",
+           "--no-tracker-call", "--same-instances", "--settle-ms", "0", "--baseline-n1", "1000"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and len(d["per_rank"]) == 8 and d["scaling"] == "weak"
+    assert sum(r["gn_iters"] for r in d["per_rank"]) == 8 * 2 * 7 * 2
+    sums = {r["pose_checksum"] for r in d["per_rank"]}
+    assert len(sums) == 1 and next(iter(sums)) > 0, d["per_rank"]
+    assert d["rank_spread"]["ms_per_step_min"] <= d["rank_spread"]["ms_per_step_max"]
+    assert abs(d["efficiency_vs_n1"]["value"] - d["value"] / 8000.0) < 1e-3 * max(1.0, d["value"] / 8000.0)
+    assert d["collective"]["backend"] == "gloo" and d["collective"]["rccl_ranks"] == 0          # (RCCL refuses eight ranks on one device; a real node reports 8)

@@ -249,3 +249,21 @@ def test_per_iteration_weights_match_the_reference_seam(name, ws, wd):
     print(f"{name}: HIP vs the reference's solver {worst:.2e}; the schedule moves the result by {moved:.2e} against constant weights")
     assert worst < 1e-4, worst
     assert moved > 2e-4, "the weight schedule must matter for this to test anything"
+
+
+def test_c3_every_gauss_newton_iterate_against_the_reference():
+    """north_star's tolerance is PER Gauss-Newton iterate against the reference.  One instance of the benched batch (c3: K = 15, 2 000 matches per pair,
+    dense + Huber, seed of instance 0): the HIP path's traced iterates T_after[n] against solveBundlingStub (SolverBundling.cu:931-1003, the reference's
+    own code through the CPU launch emulator) stopped after n + 1 iterations, n = 0 ... 6 -- 28 emulated iterations, about a minute.  Closes the chain
+    HIP <-> oracle per iterate (test_gpu_fullsize.py), oracle <-> reference per iterate on small windows, HIP <-> reference final poses only."""
+    K = 15
+    pb = S.make_problem(K, 2000, S.config_seed(5, 0), background=True, full_res=False)
+    campos, normals, intr = S.analytic_cache(pb)
+    _, tv = hip_solve(pb, 1.0, want_trace=True)
+    worst = []
+    for n in range(7):
+        ref, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, n_gn=n + 1, weight_dense=1.0)
+        w = max(max(S.pose_error(tv.T_after[0, n, k], ref[k])) for k in range(K))
+        worst.append(w)
+        assert w < 1e-4, (n, worst)
+    print("c3 instance 0, HIP vs the reference's own solver per Gauss-Newton iterate: " + " ".join(f"{w:.1e}" for w in worst))

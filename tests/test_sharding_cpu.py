@@ -88,3 +88,17 @@ def test_rank_cpu_binding_is_disjoint_and_reversible():
         assert not (got[0] & got[1])
     finally:
         os.sched_setaffinity(0, allowed)
+
+
+def test_usable_cpus_respects_affinity_and_quota():
+    """bench.py sizes its generator pools from sharding.usable_cpus(): never more than the affinity mask, never more than the cgroup quota."""
+    import os
+    from bundletrack_amd import sharding
+    n = sharding.usable_cpus()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            assert n <= max(1, int(float(q) / float(period) + 0.5))
+    except OSError:
+        pass
