@@ -99,6 +99,7 @@ struct btba_workspace {
         int chain_solve_prio = 0;      // env BTBA_CHAIN_SOLVE_PRIO (developer A/B): s_setprio of the solve items' waves
         int chain_debug_skip = 0;      // env BTBA_CHAIN_DEBUG_SKIP (developer TIMING experiments, wrong results): ChainDims::debug_skip
         bool solve_small = true;       // BTBA_OPT_SOLVE_SMALL (env BTBA_SOLVE_LEGACY=1 turns it off): k_solve_small for windows of <= 21 frames
+        int prepare_keep_T = 0;        // env BTBA_PREPARE_KEEP_T (developer / experiment builds): a solve's incoming matrices are its first iterate's T as they are (k_prepare)
         int debug_lds_pad = 0;         // env BTBA_DEBUG_LDS_PAD (developer): extra dynamic LDS bytes per sweep workgroup -- what a larger LDS footprint costs the fused sweep
         std::string chain_trace_file;  // env BTBA_CHAIN_TRACE_FILE (developer, scripts/chain_trace.py): every chained solve synchronises and dumps its workgroup timeline there
     } tune;
@@ -240,6 +241,9 @@ static int workspace_create(btba_workspace **out, void *stream, bool use_given)
         if (const char *e = std::getenv("BTBA_LLC_MB")) t.last_level_cache = (long long)std::atoll(e) << 20;
         if (const char *e = std::getenv("BTBA_CORR_NT_PARTIAL")) t.corr_nt_partial = std::atoi(e);
         if (const char *e = std::getenv("BTBA_CHAIN_TIMEOUT_MS")) t.chain_timeout_ms = std::max(1, std::atoi(e));
+#if defined(BTBA_DEV_EXPERIMENTS) || defined(BTBA_REFERENCE_ORDER)
+        t.prepare_keep_T = on("BTBA_PREPARE_KEEP_T") ? 1 : 0;
+#endif
 #ifdef BTBA_DEV_EXPERIMENTS      // developer builds only (scripts/chain_trace.py and the timing experiments of profiles/r04): these change schedules in ways a product build never does
         if (const char *e = std::getenv("BTBA_CHAIN_GROUP")) t.chain_group = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("BTBA_CHAIN_TRACE_FILE")) t.chain_trace_file = e;
@@ -843,7 +847,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     {
         const int total = B * N;
         if (chain) k_prepare_strided<<<(total + 63) / 64, 64, 0, ws->stream>>>(total, N, D.pose_stride, D.x_stride, poses, ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>());
-        else k_prepare<<<(total + 63) / 64, 64, 0, ws->stream>>>(total, poses, ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>());
+        else k_prepare<<<(total + 63) / 64, 64, 0, ws->stream>>>(total, poses, ws->x.as<float>(), ws->T.as<float>(), ws->Tinv.as<float>(), ws->tune.prepare_keep_T);
     }
     // per-frame valid-pixel lists for the compact dense sweep (once per solve; the frames do not change across iterations)
     const uint32_t *lists_base = Z.lists;

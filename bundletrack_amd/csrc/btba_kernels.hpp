@@ -24,6 +24,9 @@
 #ifndef BTBA_FUSED_WAVES
 #define BTBA_FUSED_WAVES 6      // waves per SIMD the fused sweep is compiled for (80 VGPRs)
 #endif
+#if defined(BTBA_REFERENCE_ORDER) && !defined(BTBA_EXACT_DIV)
+#define BTBA_EXACT_DIV 1        // the reference-order experiment build (tests/tools/reference_order_experiment.py) divides and takes roots exactly, like the oracle
+#endif
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -147,7 +150,9 @@ __device__ __forceinline__ void store_mat4(float *p, const Mat4 &m)
 }
 
 // ---- prepare: Log of the input matrices, then Exp and inverse (SBA.cu:71-79, SolverBundling.cu:890-897)
-__global__ void __launch_bounds__(64) k_prepare(int total, const float *__restrict__ poses, float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv)
+// keep_T (developer / experiment builds only, tests/tools/reference_order_experiment.py): the incoming matrix IS the first iterate's T -- no Exp(Log(.)) through
+// the device's libm in between --, so that an experiment can start this path and the oracle from bit-identical matrices
+__global__ void __launch_bounds__(64) k_prepare(int total, const float *__restrict__ poses, float *__restrict__ x, float *__restrict__ T, float *__restrict__ Tinv, int keep_T = 0)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -156,7 +161,7 @@ __global__ void __launch_bounds__(64) k_prepare(int total, const float *__restri
     matrix_to_pose(M, rot, trans);
     if (x) { float *o = x + 6 * (size_t)idx; o[0] = rot[0]; o[1] = rot[1]; o[2] = rot[2]; o[3] = trans[0]; o[4] = trans[1]; o[5] = trans[2]; }
     if (T || Tinv) {
-        const Mat4 E = pose_to_matrix(rot, trans);
+        const Mat4 E = keep_T ? M : pose_to_matrix(rot, trans);
         if (T) store_mat4(T + 16 * (size_t)idx, E);
         if (Tinv) store_mat4(Tinv + 16 * (size_t)idx, mat_inverse(E));
     }
@@ -567,6 +572,82 @@ __device__ __forceinline__ void pixel_accumulate(const DenseCtx &C, const PixelG
     acc[27] += masked(1.0f);
 }
 
+#ifdef BTBA_REFERENCE_ORDER
+// ---- TEST-ONLY build (-DBTBA_REFERENCE_ORDER, never the product; speed irrelevant): one pixel of the dense term evaluated in the REFERENCE's order --
+// findDenseCorr (SolverBundlingDenseUtil.h:78-110): float4x4 * float3 / float4 as cuda_SimpleMatrixUtil.h:923-942 multiplies them, cameraToDepth with a
+// division, the in-image test on the ROUNDED coordinates, bilinearInterpolationFloat4 (ICPUtil.h:83-110) with its weights renormalised per row and
+// then per column, the distance as a square root against the threshold -- fused multiply-add contraction off, IEEE division and square root.  It is the
+// oracle's find_dense_corr (oracle/btba_oracle.c) statement by statement.  What it is for: round 4's verdict asked whether the ORDER of the per-pixel
+// arithmetic is what makes this path's accept decisions differ from the oracle's on identical inputs; with this pixel they must not differ at all
+// (profiles/r05/reference_order_experiment.json).
+__device__ __attribute__((noinline)) bool bilinear4_reference(float x, float y, const float4 *__restrict__ img, int W, int H, float out[4])
+{
+#pragma clang fp contract(off)
+    const int p00x = (int)floorf(x), p00y = (int)floorf(y);
+    const int p01x = p00x, p01y = p00y + 1, p10x = p00x + 1, p10y = p00y, p11x = p00x + 1, p11y = p00y + 1;
+    const float alpha = x - (float)p00x, beta = y - (float)p00y;
+    const float MINF = -INFINITY;
+    float s0[4] = { 0.f, 0.f, 0.f, 0.f }, w0 = 0.0f;
+    if ((unsigned)p00x < (unsigned)W && (unsigned)p00y < (unsigned)H) { const float4 q = img[(size_t)p00y * W + p00x]; const float v[4] = { q.x, q.y, q.z, q.w }; if (v[0] != MINF) { for (int k = 0; k < 4; k++) s0[k] += (1.0f - alpha) * v[k]; w0 += (1.0f - alpha); } }
+    if ((unsigned)p10x < (unsigned)W && (unsigned)p10y < (unsigned)H) { const float4 q = img[(size_t)p10y * W + p10x]; const float v[4] = { q.x, q.y, q.z, q.w }; if (v[0] != MINF) { for (int k = 0; k < 4; k++) s0[k] += alpha * v[k]; w0 += alpha; } }
+    float s1[4] = { 0.f, 0.f, 0.f, 0.f }, w1 = 0.0f;
+    if ((unsigned)p01x < (unsigned)W && (unsigned)p01y < (unsigned)H) { const float4 q = img[(size_t)p01y * W + p01x]; const float v[4] = { q.x, q.y, q.z, q.w }; if (v[0] != MINF) { for (int k = 0; k < 4; k++) s1[k] += (1.0f - alpha) * v[k]; w1 += (1.0f - alpha); } }
+    if ((unsigned)p11x < (unsigned)W && (unsigned)p11y < (unsigned)H) { const float4 q = img[(size_t)p11y * W + p11x]; const float v[4] = { q.x, q.y, q.z, q.w }; if (v[0] != MINF) { for (int k = 0; k < 4; k++) s1[k] += alpha * v[k]; w1 += alpha; } }
+    float ss[4] = { 0.f, 0.f, 0.f, 0.f }, ww = 0.0f;
+    if (w0 > 0.0f) { for (int k = 0; k < 4; k++) ss[k] += (1.0f - beta) * (s0[k] / w0); ww += (1.0f - beta); }
+    if (w1 > 0.0f) { for (int k = 0; k < 4; k++) ss[k] += beta * (s1[k] / w1); ww += beta; }
+    if (ww > 0.0f) { for (int k = 0; k < 4; k++) out[k] = ss[k] / ww; return true; }
+    out[0] = out[1] = out[2] = out[3] = MINF;
+    return false;
+}
+
+__device__ __attribute__((noinline)) void pixel_reference_order(const DenseCtx &C, float dist_thresh, const float4 &cs, const float4 &ns, float (&acc)[kDenseVals])
+{
+#pragma clang fp contract(off)
+    const float *T = C.Tij.m;
+    bool ok = (cs.z > C.depth_min && cs.z < C.depth_max) && (ns.x != -INFINITY);
+    float q[3] = { 0.f, 0.f, 0.f }, ci[4] = { 0.f, 0.f, 0.f, 0.f }, ni[4] = { 0.f, 0.f, 0.f, 0.f };
+    if (ok) {
+        const float nt[4] = { T[0] * ns.x + T[1] * ns.y + T[2] * ns.z + T[3] * ns.w, T[4] * ns.x + T[5] * ns.y + T[6] * ns.z + T[7] * ns.w,
+                              T[8] * ns.x + T[9] * ns.y + T[10] * ns.z + T[11] * ns.w, T[12] * ns.x + T[13] * ns.y + T[14] * ns.z + T[15] * ns.w };
+        q[0] = T[0] * cs.x + T[1] * cs.y + T[2] * cs.z + T[3] * 1.0f;
+        q[1] = T[4] * cs.x + T[5] * cs.y + T[6] * cs.z + T[7] * 1.0f;
+        q[2] = T[8] * cs.x + T[9] * cs.y + T[10] * cs.z + T[11] * 1.0f;
+        const float u = q[0] * C.fx / q[2] + C.cx, v = q[1] * C.fy / q[2] + C.cy;      // cameraToDepth, CUDACameraUtil.h:9-14
+        const int sx = (int)roundf(u), sy = (int)roundf(v);
+        ok = sx >= 0 && sy >= 0 && sx < C.W && sy < C.H;
+        if (ok) {
+            bilinear4_reference(u, v, C.cam_t, C.W, C.H, ci);
+            ok = ci[2] > C.depth_min && ci[2] < C.depth_max;
+        }
+        if (ok) {
+            bilinear4_reference(u, v, C.nrm_t, C.W, C.H, ni);
+            ok = ni[0] != -INFINITY;
+        }
+        if (ok) {
+            const float d[3] = { q[0] - ci[0], q[1] - ci[1], q[2] - ci[2] };
+            const float dist = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            const float dNormal = nt[0] * ni[0] + nt[1] * ni[1] + nt[2] * ni[2] + nt[3] * ni[3];
+            ok = dNormal >= C.normal_thresh && dist <= dist_thresh;
+        }
+    }
+    if (!ok) return;
+    // the accepted pixel's contribution: the product's row and residual (pixel_accumulate) from these points
+    const float dx = q[0] - ci[0], dy = q[1] - ci[1], dz = q[2] - ci[2];
+    const float res = -(dx * ni[0] + dy * ni[1] + dz * ni[2]);
+    const float e = res * res;
+    const float wgt = C.w_dense * ((e <= C.delta2) ? 1.0f : C.delta / sqrtf(e));
+    const float a[6] = { -ni[0], -ni[1], -ni[2], ni[1] * q[2] - ni[2] * q[1], ni[2] * q[0] - ni[0] * q[2], ni[0] * q[1] - ni[1] * q[0] };
+    int k = 0;
+    for (int r = 0; r < 6; r++) {
+        const float wa = wgt * a[r];
+        for (int c = r; c < 6; c++) acc[k++] += wa * a[c];
+        acc[21 + r] += wa * res;
+    }
+    acc[27] += 1.0f;
+}
+#endif
+
 // index of (r, c), r <= c, in the 21-entry upper-triangle row-major packing of a symmetric 6x6
 __device__ __forceinline__ int tri21(int r, int c) { if (r > c) { const int t = r; r = c; c = t; } return r * 6 - r * (r - 1) / 2 + (c - r); }
 
@@ -685,6 +766,10 @@ __device__ __forceinline__ void dense_block(const SolveDims &D, const float4 *__
         for (; s < hi; s += kBlock) {
             const float4 cs = cs_n, ns = ns_n;
             if (s + kBlock < hi) { cs_n = cam_s[s + kBlock]; ns_n = nrm_s[s + kBlock]; }      // next pixel's stream loads
+#ifdef BTBA_REFERENCE_ORDER
+            pixel_reference_order(C, D.dist_thresh, cs, ns, acc);
+            continue;
+#endif
             const PixelGeom g = pixel_geom(C, cs, ns);
             // a wave whose 64 source pixels are all rejected (masked scenes: ~95 % of the image) skips the gathers
             if (__builtin_amdgcn_ballot_w64(g.valid) == 0ull) continue;
@@ -1045,7 +1130,9 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     const int r0 = min(bh, rows_per * tile), r1 = min(bh, rows_per * (tile + 1));
     const int nb = (WALK == 2) ? (r1 - r0) * bw : 0;      // blocks of this band (the host keeps it <= 4 x 256)
     const float2 *rng = (WALK == 2 && D.block_ranges) ? D.block_ranges + slot_s * (size_t)(bw * bh) + (size_t)r0 * bw : nullptr;
-    const float2 zr0 = (rng && (int)tid < nb) ? rng[tid] : make_float2(0.0f, 0.0f);      // (bands of more than 256 blocks fetch the rest in the compaction loop)
+    const float2 zr0 = (rng && (int)tid < nb) ? rng[tid] : make_float2(0.0f, 0.0f);
+    const float2 zr1 = (rng && (int)tid + kBlock < nb) ? rng[tid + kBlock] : make_float2(0.0f, 0.0f);      // a one-tile band of a 160 x 120 cache holds 300 blocks: both ranges of a lane in the SAME round of loads
+                                                                                                           // (bands of more than 512 blocks fetch the rest in the compaction loop)
     const Mat4 Tij = mat_mul(Tinv_i, T_j);                // source camera -> target camera
     PinholeCtx C;
 #pragma unroll
@@ -1075,24 +1162,40 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         // into an ordered list in LDS (ballot + mbcnt, block order: deterministic) that the four waves share round-robin.
         __syncthreads();                                      // the ray tables are read by the test
         const int lane_c = (int)tid & 63, wave_c = __builtin_amdgcn_readfirstlane((int)tid >> 6);
-        for (int c0 = 0; c0 < nb; c0 += kBlock) {
-            const int idx = c0 + (int)tid;
-            bool live = false;
-            unsigned code = 0;
-            if (idx < nb) {
-                const int byl = idx / bw, bxl = idx - byl * bw, byg = r0 + byl;
-                code = ((unsigned)byg << 16) | (unsigned)bxl;
-                live = rng ? block_is_live_planes(D, colA, rowB, C.t, c0 ? rng[idx] : zr0, bxl, byg) : true;
+        // Two blocks per lane and pass (idx, idx + 256): every band of a 160 x 120 cache -- 300 blocks at one tile -- is tested and compacted in ONE pass,
+        // one exchange of wave totals, two barriers (round 4: two passes of 256, the second with a fresh round of range loads in front of it and two more
+        // barriers: ~2 of a one-tile item's 9 us of set-up).  The list keeps its order -- blocks 0 .. 255 of the pass, then 256 .. 511 -- so the walk
+        // and every sum are what they were.
+        for (int c0 = 0; c0 < nb; c0 += 2 * kBlock) {
+            const int idx0 = c0 + (int)tid, idx1 = idx0 + kBlock;
+            bool live0 = false, live1 = false;
+            unsigned code0 = 0, code1 = 0;
+            if (idx0 < nb) {
+                const int byl = idx0 / bw, bxl = idx0 - byl * bw, byg = r0 + byl;
+                code0 = ((unsigned)byg << 16) | (unsigned)bxl;
+                live0 = rng ? block_is_live_planes(D, colA, rowB, C.t, c0 ? rng[idx0] : zr0, bxl, byg) : true;
             }
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(live);
-            if (lane_c == 0) hdr[wave_c] = __popcll(bal);
+            if (idx1 < nb) {
+                const int byl = idx1 / bw, bxl = idx1 - byl * bw, byg = r0 + byl;
+                code1 = ((unsigned)byg << 16) | (unsigned)bxl;
+                live1 = rng ? block_is_live_planes(D, colA, rowB, C.t, c0 ? rng[idx1] : zr1, bxl, byg) : true;
+            }
+            const unsigned long long bal0 = __builtin_amdgcn_ballot_w64(live0), bal1 = __builtin_amdgcn_ballot_w64(live1);
+            if (lane_c == 0) { hdr[wave_c] = __popcll(bal0); hdr[4 + wave_c] = __popcll(bal1); }
             __syncthreads();
-            int base = n_live, total = 0;
+            int base0 = n_live, total0 = 0, base1 = 0, total1 = 0;
 #pragma unroll
-            for (int w = 0; w < kBlock / 64; w++) { const int tt = hdr[w]; if (w < wave_c) base += tt; total += tt; }
-            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-            if (live) blist[base + before] = code;
-            n_live += total;
+            for (int w = 0; w < kBlock / 64; w++) {
+                const int t0 = hdr[w], t1 = hdr[4 + w];
+                if (w < wave_c) { base0 += t0; base1 += t1; }
+                total0 += t0; total1 += t1;
+            }
+            base1 += n_live + total0;
+            const int before0 = __builtin_amdgcn_mbcnt_hi((unsigned)(bal0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal0, 0));
+            const int before1 = __builtin_amdgcn_mbcnt_hi((unsigned)(bal1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal1, 0));
+            if (live0) blist[base0 + before0] = code0;
+            if (live1) blist[base1 + before1] = code1;
+            n_live += total0 + total1;
             __syncthreads();
         }
     } else __syncthreads();

@@ -117,7 +117,11 @@ __global__ void __launch_bounds__(kSmallBlock) k_solve_small(const SmallSolveArg
     __syncthreads();
 #endif
     const long long clk0 = tr ? (long long)clock64() : 0;
+#ifdef BTBA_SOLVE_PCG_STAMPS
+#define BTBA_SSTAMP(slot) do { } while (0)
+#else
 #define BTBA_SSTAMP(slot) do { if (tr && tid == 0) tr[S.tr_clk + (slot)] = (float)((long long)clock64() - clk0); } while (0)
+#endif
 
     // ---- phase 1: everything this solve reads from global memory, issued at once (every load is a fabric-latency miss: the sweeps
     // of other XCDs wrote the partials, the previous launch the poses).  Loads and stores WITHOUT conditions around them (see above):
@@ -349,7 +353,13 @@ __global__ void __launch_bounds__(kSmallBlock) k_solve_small(const SmallSolveArg
             }
             rz = wave_sum_all(part);
         }
+#ifdef BTBA_SOLVE_PCG_STAMPS      // developer experiment: the trace's eight clock slots = seven points inside PCG step 1 (wave 0's view)
+#define BTBA_PSTAMP(slot) do { if (tr && tid == 0 && li == 1) tr[S.tr_clk + (slot)] = (float)((long long)clock64() - clk0); } while (0)
+#else
+#define BTBA_PSTAMP(slot) do { } while (0)
+#endif
         for (int li = 0; li < S.n_pcg; li++) {
+            BTBA_PSTAMP(0);
             if (pw) {
                 const float4 *p4 = reinterpret_cast<const float4 *>(vp + h * CPL);
                 f2 qa = (f2){ 0.f, 0.f }, qb = qa, qc = qa, qd = qa;
@@ -366,13 +376,16 @@ __global__ void __launch_bounds__(kSmallBlock) k_solve_small(const SmallSolveArg
                 s = dpp_add<0x141, 0xf>(s);                                 //   row_half_mirror
                 if (h == 0 && row_live) vAp[a_row] = s;
             }
+            BTBA_PSTAMP(1);
             __syncthreads();
+            BTBA_PSTAMP(2);
             if (wave == 0) {
                 float ap_[2], z_[2];
                 float part = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 2; j++) { const int idx = lane + 64 * j; ap_[j] = idx < na ? vAp[idx] : 0.0f; part += p_[j] * ap_[j]; }
                 const float pAp = wave_sum_all(part);
+                BTBA_PSTAMP(3);
                 const float alpha = (pAp > kEps) ? rz * __builtin_amdgcn_rcpf(pAp) : 0.0f;
                 part = 0.0f;
 #pragma unroll
@@ -383,14 +396,18 @@ __global__ void __launch_bounds__(kSmallBlock) k_solve_small(const SmallSolveArg
                     part += z_[j] * r_[j];
                 }
                 const float rz_new = wave_sum_all(part);
+                BTBA_PSTAMP(4);
                 const float beta = (rz > kEps) ? rz_new * __builtin_amdgcn_rcpf(rz) : 0.0f;
                 if (tr && tid == 0) { float *sc = tr + S.tr_pcg + 4 * li; sc[0] = pAp; sc[1] = alpha; sc[2] = rz_new; sc[3] = beta; }
                 rz = rz_new;
 #pragma unroll
                 for (int j = 0; j < 2; j++) { p_[j] = z_[j] + beta * p_[j]; if (lane + 64 * j < na) vp[lane + 64 * j] = p_[j]; }
             }
+            BTBA_PSTAMP(5);
             __syncthreads();
+            BTBA_PSTAMP(6);
         }
+#undef BTBA_PSTAMP
         if (wave == 0) {
 #pragma unroll
             for (int j = 0; j < 2; j++) if (lane + 64 * j < na) vd[lane + 64 * j] = d_[j];

@@ -730,11 +730,19 @@ ORC_API int orc_solve(const orc_params *prm, int N, int Wd, int Hd, const float 
     /* convertMatricesToPosesCU, SBA.cu:71-79 (all images valid, SBA.cpp:99-101) */
     for (int k = 0; k < N; k++) orc_matrix_to_pose(poses + 16 * k, xRot + 3 * k, xTrans + 3 * k);
 
+    /* ORC_KEEP_T=1 (tests/tools/reference_order_experiment.py only): the first iterate's T is the INPUT matrix as it stands instead of Exp(Log(.)) of it, so that
+     * an experiment can start this oracle and the HIP path (same switch there: BTBA_PREPARE_KEEP_T) from bit-identical matrices -- host and device libm differ
+     * in the last bits of sinf / cosf / asinf.  Not the reference's behaviour; never set by the tests. */
+    const int keep_T = getenv("ORC_KEEP_T") != NULL;
     for (int it = 0; it < prm->n_gn_iters; it++) {
         const float wS = prm->weight_sparse, wD = prm->weight_dense_depth;   /* constant per iteration, SBA.cpp:27-32 */
         int use_dense = (wD > 0);
         /* convertLiePosesToMatricesCU_Kernel, SolverBundling.cu:890-897 */
-        for (int k = 0; k < N; k++) { orc_pose_to_matrix(xRot + 3 * k, xTrans + 3 * k, T + 16 * k); m4_inverse(T + 16 * k, Tinv + 16 * k); }
+        for (int k = 0; k < N; k++) {
+            if (it == 0 && keep_T) memcpy(T + 16 * k, poses + 16 * k, 16 * sizeof(float));
+            else orc_pose_to_matrix(xRot + 3 * k, xTrans + 3 * k, T + 16 * k);
+            m4_inverse(T + 16 * k, Tinv + 16 * k);
+        }
         if (use_dense) {
             if (P == 0) use_dense = 0;                           /* "no overlapping images", :280-283 */
             else build_dense_system(prm, N, Wd, Hd, intr, campos, normals, pairs, P, T, Tinv, JtJ, Jtr, cnts);

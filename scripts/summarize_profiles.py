@@ -7,7 +7,7 @@ import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ROUND = "r04"
+ROUND = "r05"
 
 
 def agg(path):

@@ -14,9 +14,9 @@ from bundletrack_amd.optimizer import BatchSolver, OptimizerGpu, Workspace
 from oracle import oracle as O
 
 
-def run_cases(n_cases, explain_always=False, only=None, hook=None):
+def run_cases(n_cases, explain_always=False, only=None, hook=None, prepare=None):
     """Yields one record per case (see the module docstring).  only: solve just that case (the others still draw their random numbers);
-    hook(rec, pb, corr, caches, ref, tv): called for explained cases with the problem and both traces."""
+    hook(rec, pb, corr, caches, ref, tv): called for explained cases with the problem and both traces; prepare(pb): may edit the problem before it is solved."""
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(20260925)
     opt = OptimizerGpu()
@@ -39,6 +39,8 @@ def run_cases(n_cases, explain_always=False, only=None, hook=None):
             corr["imgIdx_i"][sel[sel < off[thin + 1]]] = 0xFFFFFFFF
         if only is not None and case != only:
             continue
+        if prepare is not None:                 # (experiments: e.g. replace the starting poses by a fixed point of Exp(Log(.)) -- after all random draws)
+            prepare(pb)
         depths = [torch.from_numpy(pb.depth[k]).to(dev) for k in range(K)]
         normals = [torch.from_numpy(pb.normals[k]).to(dev) for k in range(K)]
         poses = pb.poses_init.copy()
