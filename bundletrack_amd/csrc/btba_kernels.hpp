@@ -161,7 +161,10 @@ __global__ void __launch_bounds__(64) k_prepare(int total, const float *__restri
     matrix_to_pose(M, rot, trans);
     if (x) { float *o = x + 6 * (size_t)idx; o[0] = rot[0]; o[1] = rot[1]; o[2] = rot[2]; o[3] = trans[0]; o[4] = trans[1]; o[5] = trans[2]; }
     if (T || Tinv) {
-        const Mat4 E = keep_T ? M : pose_to_matrix(rot, trans);
+        Mat4 E = pose_to_matrix(rot, trans);
+#if defined(BTBA_DEV_EXPERIMENTS) || defined(BTBA_REFERENCE_ORDER)
+        if (keep_T) E = M;
+#endif
         if (T) store_mat4(T + 16 * (size_t)idx, E);
         if (Tinv) store_mat4(Tinv + 16 * (size_t)idx, mat_inverse(E));
     }
