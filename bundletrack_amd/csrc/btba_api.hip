@@ -736,7 +736,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // the solve has to clear), not for the chained launch's last solve, and only while everything fits the CU's LDS
     const int small_cpl_v = small_cpl(N);
     const size_t small_lds = sizeof(float) * small_solve_lds_floats(N, D.n_dense_pairs, small_cpl_v);
-    const bool small_solve = ws->tune.solve_small && N <= kSmallMaxFrames && !atomic_sums && !a_global && !D.pre_assembled && small_lds <= lds_limit;
+    const bool small_solve = ws->tune.solve_small && N <= kSmallMaxFrames && !atomic_sums && !a_global && !D.pre_assembled && 2 * D.n_dense_pairs <= kSmallBlock && small_lds <= lds_limit;
     if (small_solve && !ws->small_attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));

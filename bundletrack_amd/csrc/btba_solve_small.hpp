@@ -11,7 +11,8 @@
 // dependent phases (k_system_solve: 44 k cycles = reduce 10.6 k + assemble 11.2 k + PCG 13.5 k + update 7.9 k, profiles/r03/
 // system_solve_experiments.json).  Measured while writing this kernel:
 //   * a wave ALONE on its SIMD retires one instruction per ~10-12 cycles (dependent issue + LDS round trips it cannot hide): phases
-//     with work for everybody run on all 16 waves (4 per SIMD: one instruction per 4 cycles per SIMD), whatever their set-up costs;
+//     with work for everybody run on all 16 waves (4 per SIMD: one instruction per 4 cycles per SIMD), whatever their set-up costs --
+//     a 256-thread version of this kernel took 35 k cycles against 24 k -- and only the truly serial chains run on one wave;
 //   * every vector instruction that all 16 waves execute costs 16 cycles of the compute unit: per-lane set-up and index arithmetic
 //     are what the throughput phases consist of, so they are cut to the bone (descriptors from the host's table, compile-time LDS
 //     offsets, 24-bit multiplies, no 64-bit address arithmetic, no divisions);
@@ -20,11 +21,12 @@
 //   * a cold instruction cache is NOT what bounds it (the body run twice: the second pass is no faster).
 //
 //   reduce     16-byte loads -> 16-byte LDS stores; source index = destination index when there is one partial per sum (every
-//              chip-filling batch): ONE fabric round trip; up to four partials of two slots per lane in flight otherwise.
+//              chip-filling batch): ONE fabric round trip; up to eight partials of two slots per lane in flight otherwise.
 //   assemble   a lane keeps ONE (row, column) of the 6 x 6 block pattern for its lifetime and walks pairs -- no per-entry decode
 //              (e / 36, pair_index, tri21).  Diagonal blocks: the sparse blocks are LINEAR in the pair's moment sums, so a frame's 20
-//              sparse and 27 dense sums over its pairs are formed first (47 (N - 1) lanes, loads batched) and expanded once, instead
-//              of expanding every pair's block and summing 36 entries x 14 pairs.
+//              sparse and 27 dense sums over its pairs are formed first (20 (N - 1) lanes with one sparse sum each, 7 (N - 1) lanes with
+//              four dense sums each, loads batched) and expanded once, instead of expanding every pair's block and summing 36 entries
+//              x 14 pairs.
 //   PCG        the matrix is read from LDS ONCE into registers -- eight lanes per row, CPL columns each, 8 rows per wave -- and a
 //              step is: packed FMAs against p (broadcast reads), three DPP adds, A p through LDS, a barrier, the two dot products
 //              and vector updates on ONE wave alone on its SIMD, a barrier.  alpha and beta by v_rcp_f32 (1 ulp; the reference is
@@ -42,7 +44,8 @@
 
 namespace btba {
 
-constexpr int kSmallMaxFrames = 21;      // 6 (N - 1) <= 128 unknowns: two vector entries per lane of a PCG wave, four waves x 32 rows
+constexpr int kSmallMaxFrames = 21;      // 6 (N - 1) <= 128 unknowns: two vector entries per lane of the wave that runs the PCG's serial part, 16 waves x 8 matrix rows;
+                                         // every per-window table of the kernel fits one trip of its 1 024 lanes (2 Pd <= 2 N (N - 1) = 840 adjacency entries)
 constexpr int kSmallBlock = 1024;
 constexpr int kFrameSums = 48;           // floats per frame of the frame-sum table (20 sparse + 27 dense used)
 
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(kSmallBlock) k_solve_small(const SmallSolveArg
             *(eb < ns4 ? ps4 + eb : pd4 + (eb - ns4)) = fb;
         }
     } else {
-        // several partials per sum (small batches: up to 16 chunks / 8 tiles): two slots per lane, eight partials of each in flight; sums in partial order
+        // several partials per sum (small batches: up to 16 chunks / 8 tiles): two slots per lane, four or eight partials of each in flight; sums in partial order
         const int max_parts = max(S.sparse_chunks, S.dense_tiles);
         for (int e0 = (int)tid; e0 < n4; e0 += 2 * nthr) {
             const v4 *src[2]; int per[2], parts[2], e_[2];
@@ -166,17 +169,22 @@ __global__ void __launch_bounds__(kSmallBlock) k_solve_small(const SmallSolveArg
                 src[u] = (sp ? sp4 : dp4) + __umul24(__umul24(rec, parts[u]), per[u]) + (q - rec * per[u]);
                 acc[u] = (v4){ 0.f, 0.f, 0.f, 0.f };
             }
-            for (int c0 = 0; c0 < max_parts; c0 += 8) {
-                v4 g[2][8];
+            // rounds of four partials per slot while that covers the sums (a single tracker window: 4 chunks x 3 tiles -- eight-wide rounds would issue
+            // as many clamped repeats as loads), of eight beyond (8 tiles at B = 1 on full frames)
+            auto round = [&](auto width_c, int c0) {
+                constexpr int kW = decltype(width_c)::value;
+                v4 g[2][kW];
 #pragma unroll
                 for (int u = 0; u < 2; u++)
 #pragma unroll
-                    for (int c = 0; c < 8; c++) g[u][c] = src[u][__umul24(c0 + c < parts[u] ? c0 + c : 0, per[u])];
+                    for (int c = 0; c < kW; c++) g[u][c] = src[u][__umul24(c0 + c < parts[u] ? c0 + c : 0, per[u])];
 #pragma unroll
                 for (int u = 0; u < 2; u++)
 #pragma unroll
-                    for (int c = 0; c < 8; c++) { const float live = c0 + c < parts[u] ? 1.0f : 0.0f; acc[u] += live * g[u][c]; }      // (a dead partial adds an exact zero)
-            }
+                    for (int c = 0; c < kW; c++) { const float live = c0 + c < parts[u] ? 1.0f : 0.0f; acc[u] += live * g[u][c]; }      // (a dead partial adds an exact zero)
+            };
+            if (max_parts <= 4) round(std::integral_constant<int, 4>{}, 0);
+            else for (int c0 = 0; c0 < max_parts; c0 += 8) round(std::integral_constant<int, 8>{}, c0);
 #pragma unroll
             for (int u = 0; u < 2; u++) *(e_[u] < ns4 ? ps4 + e_[u] : pd4 + (e_[u] - ns4)) = acc[u];
         }
