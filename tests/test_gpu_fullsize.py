@@ -225,3 +225,38 @@ def test_one_tracker_window_stays_inside_its_recorded_budget():
     med = float(np.median(ms))
     print(f"one masked c3 window: ms_solve median {med:.4f} (budget {budget['ms_solve']} + {100 * budget['tolerance']:.0f} %)")
     assert med <= budget["ms_solve"] * (1.0 + budget["tolerance"]), (med, budget)
+
+
+def test_large_caches_keep_the_block_walk_in_chip_filling_batches(gpu):
+    """A 320 x 240 cache (image_downscale 2) has 1 200 8 x 8 blocks; the dead-block test handles bands of up to 1 024.  Once a batch fills the chip the tile
+    policy asks for ONE tile per pair (measured on 160 x 120 caches) -- which would drop the hull-culled block walk for row strips here (round 4's advisor
+    finding).  pick_tiles keeps two tiles in that case: the walk's counter must move, and the poses must equal the same instance solved alone."""
+    pb = S.make_problem(4, 60, seed=77, background=True, full_res=False, downscale=2)
+    zn1 = S.compact_cache(pb)
+    assert zn1.shape[1:3] == (240, 320)
+    B = 256                                         # 256 instances x 6 pairs = 1 536 pair-instances: the one-tile regime
+    bs = gpu.BatchSolver(gpu.ws, image_downscale=2.0)
+    corr, offs, mx = bs.pack_correspondences([pb.corr], 4)
+    zn_d = gpu.torch.from_numpy(zn1[None]).to(gpu.dev).repeat(B, 1, 1, 1, 1).contiguous()
+    corr_d = gpu.torch.from_numpy(corr.view(np.uint8).reshape(1, -1, 32)).to(gpu.dev).repeat(B, 1, 1).contiguous()
+    offs_d = gpu.torch.from_numpy(offs.astype(np.int32)).to(gpu.dev).repeat(B, 1).contiguous()
+    poses_d = gpu.torch.from_numpy(pb.poses_init[None].astype(np.float32)).to(gpu.dev).repeat(B, 1, 1, 1).contiguous()
+    gpu.ws.set_option(_lib.OPT_COUNT_LIVE, 1)
+    try:
+        bs.solve_zn(zn_d, pb.H, pb.W, pb.K, corr_d, offs_d, mx, poses_d)
+        walked = gpu.ws.live_blocks()
+    finally:
+        gpu.ws.set_option(_lib.OPT_COUNT_LIVE, 0)
+    st = gpu.ws.collect_stats()
+    assert st["dense_tiles"] == 2, st
+    assert walked > 0, "the block walk was dropped"
+    assert walked <= 7 * B * 6 * 1200
+    out = poses_d.cpu().numpy()
+    assert np.isfinite(out).all() and all(np.array_equal(out[0], out[b]) for b in (1, B // 2, B - 1))
+    one = gpu.torch.from_numpy(pb.poses_init[None].astype(np.float32)).to(gpu.dev)
+    bs1 = gpu.BatchSolver(gpu.ws, image_downscale=2.0)
+    bs1.solve_zn(zn_d[:1], pb.H, pb.W, pb.K, corr_d[:1], offs_d[:1], mx, one)
+    gpu.ws.sync()
+    worst = max(max(S.pose_error(out[0, k], one.cpu().numpy()[0, k])) for k in range(4))
+    print(f"320x240 cache, 256 instances at two tiles vs one instance at its own tile count: worst pose difference {worst:.2e}")
+    assert worst < 1e-3, worst                      # (other tile / chunk counts = another summation order on a four-frame 100 %-valid window: the class held to 1e-3, test_gpu_parity.py)
