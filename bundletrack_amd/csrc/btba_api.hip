@@ -470,11 +470,21 @@ static int time_end(btba_workspace *ws, size_t slot, hipStream_t st = nullptr)
     return BTBA_OK;
 }
 
-static int pick_chunks(const btba_params *prm, int B, int P, uint32_t max_corr_per_pair)
+static int pick_chunks(const btba_params *prm, int B, int P, uint32_t max_corr_per_pair, bool with_dense)
 {
     if (prm->sparse_chunks > 0) return prm->sparse_chunks;
     if (max_corr_per_pair == 0) return 1;
     const long blocks = (long)B * P;
+    if (with_dense) {
+        // The sparse items ride in the dense items' launch (k_fused_sweeps needs >= 64 of each): as FEW partials per sum as keep it fused -- every extra chunk is
+        // another record per pair for the system solve to fetch and add, and the sparse items are not what the launch waits for.  Round 5, one window with
+        // k_solve_small (scripts/dev/single_window_tiles.py, ms per solve for 1 / 2 / 4 chunks): c3 masked at one tile 0.126 / 0.138 / 0.145, c3 full frames at
+        // eight tiles 0.1765 / 0.1773 / 0.1793; a 10-frame window (45 pairs) needs two chunks to stay fused: 0.116 against 0.142 unfused.
+        const int cap = std::min(16, (int)((max_corr_per_pair + 2 * kBlock - 1) / (2 * kBlock)));
+        const int want = (int)((64 + blocks - 1) / blocks);
+        if (want <= cap) return std::max(1, want);
+        // (too few pairs to fuse even at the cap: the sparse sweep is a launch of its own -- the rule below)
+    }
     int want = (int)((512 + blocks - 1) / blocks);
     // a chunk is at least one full trip of its workgroup (two entries per lane): a single c3 window measured 0.2191 / 0.2145 / 0.2143 / 0.2283 ms
     // per solve for 5 / 4 / 2 / 8 chunks of its 2 000-entry segments (scripts/latency_tiles.py, r03 call 58)
@@ -501,7 +511,9 @@ static int pick_tiles(const btba_params *prm, int B, int Pd, int npix, bool list
     const long blocks = (long)B * Pd;
     // object-masked frames walked through their valid-pixel lists (~5 % of the image): 1 / 2 / 3 / 5 tiles  B = 1: 0.219 / 0.216 / 0.215 / 0.221,
     // B = 8: 0.274 / 0.288 / 0.306 / 0.348,  B = 32: 0.494 / 0.554 / 0.624 / 0.785
-    if (lists) return blocks >= 384 ? 1 : 3;
+    // (round 5, with k_solve_small: one masked window 0.1263 / 0.1362 / 0.1331 / 0.141 ms per solve for 1 / 2 / 3 / 4 tiles at one chunk, two windows 0.1355 / 0.1493 /
+    // 0.1507 -- one tile from the point where the dense items alone keep the launch fused (>= 64 of them); a 10-frame window's 45 pairs: 3 tiles, 0.116 against 0.145)
+    if (lists) return blocks >= 64 ? 1 : 3;
     int want = blocks >= 1536 ? 1 : blocks >= 768 ? 2 : blocks >= 192 ? 4 : 8;
     const int cap = (npix + kBlock - 1) / kBlock;
     if (want > cap) want = cap;
@@ -588,7 +600,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         // nothing to optimise: poses still go through Log/Exp like the reference (SBA.cpp:106,115)
     }
     const int npix = Hd * Wd;
-    const int chunks = use_sparse ? pick_chunks(prm, B, P, max_corr_per_pair) : 1;
+    const int chunks = use_sparse ? pick_chunks(prm, B, P, max_corr_per_pair, use_dense && !(prm->flags & BTBA_FLAG_NO_FUSE)) : 1;
     const int tiles = use_dense ? pick_tiles(prm, B, Pd, npix, use_zn && (prm->flags & BTBA_FLAG_COMPACTION), Wd, Hd) : 1;
     const bool timing = (prm->flags & BTBA_FLAG_TIME_KERNELS) != 0;
     const int timed_iteration = (prm->flags & BTBA_FLAG_TIME_SAMPLED) ? (int)(ws->solves_enqueued++ % (uint64_t)std::max(1, prm->n_gn_iters)) : -1;      // -1: all
