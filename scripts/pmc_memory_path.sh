@@ -1,6 +1,6 @@
 #!/bin/bash
-# Memory-path and LDS counters of the bench workload's kernels (round 4's build) -- each set its own rocprofv3 run (--kernel-trace + --pmc only).
-# usage: scripts/pmc_memory_path.sh <tag> [bench args]      then: python scripts/summarize_pmc.py gpurun_out/pmc_<tag> profiles/r04/memory_path_counters_<tag>.json
+# Memory-path and LDS counters of the bench workload's kernels (rounds 4-5) -- each set its own rocprofv3 run (--kernel-trace + --pmc only).
+# usage: scripts/pmc_memory_path.sh <tag> [bench args]      then: python scripts/summarize_pmc.py gpurun_out/pmc_<tag> profiles/r05/memory_path_counters_<tag>.json
 set -u
 TAG=${1:-mem}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -11,7 +11,7 @@ cd /tmp
 export BTBA_BENCH_CACHE=/tmp/bench_instances_pmc_$TAG.npz
 BTBA_BENCH_NPROC=8 timeout 300 python "$REPO/bench.py" --no-cpu-baseline --steps 2 --warmup 1 --settle-ms 0 $* > "$OUT/pre.log" 2>&1
 export BTBA_BENCH_NPROC=1
-ARGS="--steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-incl-pack --no-kernel-timing $*"
+ARGS="--steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-tracker-call --no-incl-pack --no-kernel-timing $*"
 echo "bench args: $ARGS" > "$OUT/args.txt"
 i=0
 for SET in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \

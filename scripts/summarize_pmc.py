@@ -32,7 +32,7 @@ def main():
     res = {}
     for kern, counters in acc.items():
         short = kern.split("(")[0]
-        if not any(k in short for k in ("k_fused_sweeps", "k_system_solve", "k_sparse_sweep", "k_dense_sweep")):
+        if not any(k in short for k in ("k_fused_sweeps", "k_system_solve", "k_solve_small", "k_sparse_sweep", "k_dense_sweep", "k_big_")):
             continue
         res[short] = {c: round(sum(v) / len(v), 1) for c, v in sorted(counters.items())}
         res[short]["launches"] = max(len(v) for v in counters.values())
