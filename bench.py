@@ -358,7 +358,9 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before the timed region
     n_distinct = max(1, min(args.distinct, B))
-    ids = [(0 if args.same_instances else rank * B) + i for i in range(n_distinct)]       # global instance ids of this rank's distinct seeds
+    # the partition SURVEY.md 8(e) / DESIGN.md 6 state: global instance n of the job's world x B instances runs on rank n mod world
+    # (sharding.instances_for_rank); --same-instances gives every rank rank 0's share
+    ids = sharding.instances_for_rank(world * B, 0 if args.same_instances else rank, world)[:n_distinct]       # global instance ids of this rank's distinct seeds
     note(f"generating {n_distinct} synthetic instances")
     inst = generate_instances(cfg, ids, args.masked)
     note("instances ready; uploading")
@@ -429,7 +431,7 @@ def main():
     note(f"timed region done: {seconds:.3f} s")
     st = ws.collect_stats()
     out_poses = poses_d.cpu().numpy()
-    assert np.isfinite(out_poses).all(), "non-finite poses"
+    # (non-finite poses: caught below through the gathered pose checksums, so that every rank leaves together instead of one rank hanging the gather)
     # What a tracker pays: its correspondences are NEW on every call, so nothing about them can be prepared outside the call.  Same steps again,
     # handing the solve the EntryJ array (already in HBM) as it is -- the library's default for fresh matches reads the 32-byte wire format in
     # every iteration (an in-sweep re-layout, BTBA_OPT_RELAYOUT, and a separate pack pass both measured no better: profiles/r04/relayout.json).
@@ -467,6 +469,12 @@ def main():
     per_rank = sharding.gather_throughput(seconds, gn_iters, device=gather_dev, checksum=float(np.abs(out_poses.astype(np.float64)).sum()))
     value, slowest = sharding.aggregate(per_rank)
     checksums = list(sharding.gather_throughput.checksums)
+    if not all(np.isfinite(c) for c in checksums):          # a rank that produced non-finite poses: no line (every rank sees the same gathered list and stops)
+        print(f"bench.py: non-finite pose checksum on rank(s) {[r for r, c in enumerate(checksums) if not np.isfinite(c)]} -- no result line", file=sys.stderr)
+        if backend is not None:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        raise SystemExit(4)
     value_incl_pack = None
     if seconds_incl_pack is not None:
         pr2 = sharding.gather_throughput(seconds_incl_pack, gn_iters, device=gather_dev)
@@ -493,6 +501,7 @@ def main():
             "ms_per_step_incl_pack": round(1e3 * seconds_incl_pack / args.steps, 4) if seconds_incl_pack else None,
             "per_rank": [{"seconds": round(s, 6), "gn_iters": g, "ms_per_step": round(1e3 * s / args.steps, 4), "pose_checksum": round(c, 6)} for (s, g), c in zip(per_rank, checksums)],
             "rank_spread": {"ms_per_step_min": round(1e3 * min(s for s, _ in per_rank) / args.steps, 4), "ms_per_step_max": round(1e3 * max(s for s, _ in per_rank) / args.steps, 4)},
+            "instance_ids_rank0": {"first": ids[:4], "rule": "global instance n -> rank n mod n_gpus (sharding.instances_for_rank)"},
             "collective": {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
                            "what": "one all-gather of {seconds, GN iterations, pose checksum} per rank after the timed region; no data-path collective"},
             "cpu_binding_rank0": cpu_binding,
@@ -594,7 +603,9 @@ def main():
                                "algorithmic_32B_GBps": round(32 * n_corr / (avg_ms * 1e-3) / 1e9, 1),
                                "layout_bytes_per_launch": (24 if use_c24 else 32) * n_corr,
                                "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_sparse_launches"]}
-        if args.latency:
+        if args.latency or world == 1:
+            # BASELINE.json's metric read literally -- ONE K=15 x 2k problem at a time (B = 1), resident inputs, pose in -> pose out: always in the
+            # single-GPU line (10 ms of GPU time); `value` above is the batch of 32 such problems per GPU that SURVEY.md 8(d) names for the headline
             bs1 = BatchSolver(ws, weight_dense_depth=cfg["w_dense"])
             c1, o1, m1 = bs1.pack_correspondences([pick[0]["corr"]], K)
             c1d = torch.from_numpy(c1.view(np.uint8).reshape(1, -1, 32)).to(dev)
@@ -618,7 +629,8 @@ def main():
                 p1.copy_(poses0[:1]); one(p1)
             torch.cuda.synchronize()
             tb = time.perf_counter()
-            res["single_instance"] = {"gn_iters_per_s": round(7 * reps / (tb - ta), 1), "ms_per_solve": round(1e3 * (tb - ta) / reps, 4)}
+            res["single_instance"] = {"gn_iters_per_s": round(7 * reps / (tb - ta), 1), "ms_per_solve": round(1e3 * (tb - ta) / reps, 4), "solves": reps,
+                                      "what": f"ONE {args.config} problem per solve (B = 1: {cfg['desc']}), inputs resident in HBM, 7 GN x 5 PCG, back to back on one stream"}
         if world == 1 and not args.no_tracker_call:
             note("tracker-mode call (btba_optimize_frames_keyed, one masked c3 window)")
             res["tracker_call"] = tracker_call(dev)

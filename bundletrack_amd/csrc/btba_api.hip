@@ -75,6 +75,7 @@ struct btba_workspace {
     bool count_live = false;
     int *chain_error = nullptr;                             // pinned host word the chained launch's watchdog raises (checked at every host synchronisation)
     bool chain_failed = false;                              // a watchdog fired on this workspace: chaining stays off from then on
+    bool chain_reported = false;                            // ... and an enqueue has already returned BTBA_ESCHED for it (the word itself is cleared only after a sync)
     uint64_t chain_launches = 0;
     // Developer / tuning switches.  Read from the environment ONCE, when the workspace is created (never on the solve path), and settable
     // per workspace through btba_workspace_set_option (include/btba.h: BTBA_OPT_*).  None of them changes what is computed.
@@ -313,9 +314,9 @@ int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
     case BTBA_OPT_COUNT_LIVE:
         ws->count_live = value != 0;
         if (ws->count_live) {
-            int rc = ws->live_blocks.ensure(sizeof(unsigned long long));
+            int rc = ws->live_blocks.ensure(8 * sizeof(unsigned long long));       // [0] walked blocks; [1 .. 8): the lane census of developer builds (-DBTBA_CENSUS)
             if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(ws->live_blocks.p, 0, sizeof(unsigned long long), ws->stream));
+            HIP_TRY(hipMemsetAsync(ws->live_blocks.p, 0, 8 * sizeof(unsigned long long), ws->stream));
         }
         break;
     case 1000:      // not part of the ABI.  64 = the watchdog's self-test (solve items never publish: the launch runs into the watchdog, the solve is REPORTED failed,
@@ -337,9 +338,11 @@ int btba_workspace_set_option(btba_workspace *ws, int option, int64_t value)
 static int chain_check(btba_workspace *ws)
 {
     if (!ws->chain_error || !*ws->chain_error) return BTBA_OK;
-    *ws->chain_error = 0;
+    *ws->chain_error = 0;                                   // the stream has just been synchronised: the poison kernel of the failed launch has run
     ws->chain_failed = true;
-    return BTBA_ESCHED;
+    const bool already = ws->chain_reported;
+    ws->chain_reported = false;
+    return already ? BTBA_OK : BTBA_ESCHED;
 }
 
 int btba_workspace_live_blocks(btba_workspace *ws, uint64_t *blocks)
@@ -354,6 +357,21 @@ int btba_workspace_live_blocks(btba_workspace *ws, uint64_t *blocks)
     *blocks = v;
     return BTBA_OK;
 }
+
+#ifdef BTBA_CENSUS
+// Developer builds only (scripts/sweep_census.py): the lane census of the dense block walk since BTBA_OPT_COUNT_LIVE was set --
+// out[0] walked blocks (= wave trips), [1] lanes with a usable source depth, [2] lanes whose projection lands in the target image (`valid`),
+// [3] wave trips that end at ballot(valid) == 0, [4] lanes in the trips that go on (64 per trip), [5] lanes accepted after the tap tests,
+// [6] lanes valid but rejected by the target depth range, [7] lanes valid, depth fine, rejected by the normal / distance tests.
+extern "C" BTBA_API int btba_dev_census(btba_workspace *ws, uint64_t *out)
+{
+    DeviceGuard device_guard(ws);
+    if (!ws || !out || !ws->live_blocks.p) return BTBA_EINVAL;
+    HIP_TRY(hipStreamSynchronize(ws->stream));
+    HIP_TRY(hipMemcpy(out, ws->live_blocks.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return BTBA_OK;
+}
+#endif
 
 int btba_workspace_sync(btba_workspace *ws)
 {
@@ -554,7 +572,11 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // A watchdog of an EARLIER chained launch fired and nobody has synchronised through the library since (a caller that orders its own stream with
     // btba_workspace_signal_stream never passes btba_workspace_sync): report it now -- that solve's poses were poisoned with NaN by the kernel (k_chain),
     // this and every later solve of the workspace runs unchained.
-    if (ws->chain_error && *ws->chain_error) { *ws->chain_error = 0; ws->chain_failed = true; return BTBA_ESCHED; }
+    // The device-visible word stays SET here: this path has not synchronised the stream, and the poison kernel queued behind the failed launch may not
+    // have run yet -- clearing the word now would let it read 0 and leave that solve's garbage poses finite.  The word is cleared only behind a host
+    // synchronisation (chain_check); `chain_reported` latches that the caller has been told, chaining is off from here on (only chained launches queue
+    // poison kernels, so a sticky word cannot poison a later solve).
+    if (ws->chain_error && *ws->chain_error && !ws->chain_reported) { ws->chain_reported = true; ws->chain_failed = true; return BTBA_ESCHED; }
     if (prm->reduction_mode != BTBA_REDUCE_DETERMINISTIC && prm->reduction_mode != BTBA_REDUCE_ATOMIC) return BTBA_EINVAL;
     const bool atomic_sums = prm->reduction_mode == BTBA_REDUCE_ATOMIC;      // the reference's way of summing (float atomics, order not fixed)
     if (atomic_sums && trace) return BTBA_EINVAL;                            // the decision traces are defined on the reproducible sums
@@ -600,8 +622,15 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         // nothing to optimise: poses still go through Log/Exp like the reference (SBA.cpp:106,115)
     }
     const int npix = Hd * Wd;
-    const int chunks = use_sparse ? pick_chunks(prm, B, P, max_corr_per_pair, use_dense && !(prm->flags & BTBA_FLAG_NO_FUSE)) : 1;
-    const int tiles = use_dense ? pick_tiles(prm, B, Pd, npix, use_zn && (prm->flags & BTBA_FLAG_COMPACTION), Wd, Hd) : 1;
+    // the launches are per instance GROUP when BTBA_FLAG_OVERLAP splits the batch over streams (below): the fuse test (>= 64 items of each kind) and the
+    // chip-filling rules see a group's instances, so the partial counts are chosen for the smallest group
+    int B_launch = B;
+    if (B >= 8 && (prm->flags & BTBA_FLAG_OVERLAP)) {
+        const int groups = std::max(1, std::min({ ws->tune.overlap_groups, (int)btba_workspace::kMaxGroups, B / 2 }));
+        B_launch = B / groups;
+    }
+    const int chunks = use_sparse ? pick_chunks(prm, B_launch, P, max_corr_per_pair, use_dense && !(prm->flags & BTBA_FLAG_NO_FUSE)) : 1;
+    const int tiles = use_dense ? pick_tiles(prm, B_launch, Pd, npix, use_zn && (prm->flags & BTBA_FLAG_COMPACTION), Wd, Hd) : 1;
     const bool timing = (prm->flags & BTBA_FLAG_TIME_KERNELS) != 0;
     const int timed_iteration = (prm->flags & BTBA_FLAG_TIME_SAMPLED) ? (int)(ws->solves_enqueued++ % (uint64_t)std::max(1, prm->n_gn_iters)) : -1;      // -1: all
 

@@ -1157,7 +1157,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         else rowB[e - D.width] = make_float4(C.R[1] * l + C.R[2], C.R[4] * l + C.R[5], C.R[7] * l + C.R[8], 0.0f);
     }
     if (tid >= 64 && tid < 64 + 36) red[4 * kDenseVals + kDenseVals + 4 + ((int)tid - 64)] = m_stage;
-    int *hdr = reinterpret_cast<int *>(rowB + D.height);                  // [0 .. 4) wave totals of the list compaction
+    int *hdr = reinterpret_cast<int *>(rowB + D.height);                  // [0 .. 8) wave totals of the list compaction (two blocks per lane and pass: [0 .. 4) first halves, [4 .. 8) second)
     unsigned *blist = reinterpret_cast<unsigned *>(hdr + 8);
     int n_live = 0;
     if (WALK == 2) {
@@ -1222,6 +1222,9 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     unsigned long long tt_a = 0, tt_b = 0, tt_c = 0, tt_live = 0, tt_dead = 0;       // shader-clock sums of this wave: top of the trip / taps in flight / blend + accumulate
     auto stamp_after = [](float dep) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory"); return t; };
 #endif
+#ifdef BTBA_CENSUS
+    unsigned cen[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };      // wave-uniform lane counts (scripts/sweep_census.py)
+#endif
     auto pixel = [&](const float4 &zs, unsigned ox, unsigned oy) {
 #ifdef BTBA_TRIP_TRACE
         unsigned long long tt0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt0) :: "memory");
@@ -1236,6 +1239,10 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const float u = qx * C.fx * rqz + C.cx, v = qy * C.fy * rqz + C.cy;
         const float uc = clamp0_s(u, C.wm1), vc = clamp0_s(v, C.hm1);      // NaN -> 0: addresses stay in the frame
         const bool valid = src_ok & (fabsf(u - uc) < 0.5f) & (fabsf(v - vc) < 0.5f);
+#ifdef BTBA_CENSUS
+        cen[1] += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(src_ok)); cen[2] += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(valid));
+        if (__builtin_amdgcn_ballot_w64(valid) == 0ull) cen[3] += 1u; else cen[4] += 64u;
+#endif
 #ifdef BTBA_TRIP_TRACE
         const unsigned long long tt1 = stamp_after(valid ? uc : vc);
         tt_a += tt1 - tt0;
@@ -1280,6 +1287,13 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const float dist2 = fma_nd(dz, dz, fma_nd(dx, dx, dy * dy));
         const float dn = fma_nd(nqz, niz, fma_nd(nqx, nix, nqy * niy));
         const bool ok = valid & ((__float_as_uint(ciz) - C.zmin_bits) < C.zrange_bits) & (dn >= C.normal_thresh) & (dist2 <= C.dist2_thresh);
+#ifdef BTBA_CENSUS
+        {
+            const bool depth_ok = (__float_as_uint(ciz) - C.zmin_bits) < C.zrange_bits;
+            cen[5] += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(ok)); cen[6] += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(valid & !depth_ok));
+            cen[7] += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(valid & depth_ok & !ok));
+        }
+#endif
         // rejected pixels contribute exact zeros: AND with 0 / ~0 (one select, then 2-cycle v_and_b32; NaN-safe, unlike a multiply)
         const unsigned keep = opaque_vgpr(ok ? 0xFFFFFFFFu : 0u);
         auto masked = [keep](float x) { return __uint_as_float(__float_as_uint(x) & keep); };
@@ -1355,6 +1369,9 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
                 if (++i >= nt) break;
             }
         }
+#ifdef BTBA_CENSUS
+        if (D.live_blocks && lane == 0) for (int k = 1; k < 8; k++) atomicAdd(D.live_blocks + k, (unsigned long long)cen[k]);
+#endif
 #ifdef BTBA_WG_TRACE
         if (tid == 0) wg_dbg[1] = wall_clock64();
 #endif

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(kSmallBlock) k_solve_small(const SmallSolveArg
 #pragma unroll
                 for (int u = 0; u < 2; u++)
 #pragma unroll
-                    for (int c = 0; c < kW; c++) { const float live = c0 + c < parts[u] ? 1.0f : 0.0f; acc[u] += live * g[u][c]; }      // (a dead partial adds an exact zero)
+                    for (int c = 0; c < kW; c++) { const bool live = c0 + c < parts[u]; acc[u] += (v4){ live ? g[u][c].x : 0.0f, live ? g[u][c].y : 0.0f, live ? g[u][c].z : 0.0f, live ? g[u][c].w : 0.0f }; }      // (a dead partial adds an exact zero -- a select, as everywhere in this kernel: a non-finite partial 0 must not leak through 0 x inf)
             };
             if (max_parts <= 4) round(std::integral_constant<int, 4>{}, 0);
             else for (int c0 = 0; c0 < max_parts; c0 += 8) round(std::integral_constant<int, 8>{}, c0);

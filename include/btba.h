@@ -218,7 +218,9 @@ enum {
                                            over inside the launch while the other instances' sweeps run (btba_kernels.hpp: k_chain).  0 (default) / -1: the
                                            plain schedule (two launches per iteration) -- it measured faster once one tile per pair became the better
                                            choice; 1: every batch the launch supports (pinhole compact cache, sparse + dense terms,
-                                           <= 15 frames, no trace, deterministic sums).  Same bits as the plain schedule with the same tile count.  env BTBA_CHAIN */
+                                           <= 15 frames, no trace, deterministic sums).  Same bits as the plain schedule with the same tile count AND BTBA_OPT_SOLVE_SMALL = 0 (the in-launch
+                                           solve items reproduce k_system_solve's sums); against the default plain schedule (k_solve_small: the same sums in another
+                                           order) the poses agree to the 1e-4 bar, not bit for bit.                                 env BTBA_CHAIN */
     BTBA_OPT_CHAIN_SPARSE_PERIOD  = 11, /* chained launch: 0 (default) an instance's sparse items follow its dense items; R >= 2: every R-th item of an
                                            instance is a sparse one.                                                               env BTBA_CHAIN_PERIOD */
     BTBA_OPT_CHAIN_TIMEOUT_MS     = 12, /* watchdog of the waits inside the chained launch (default 500 ms): see BTBA_ESCHED.        env BTBA_CHAIN_TIMEOUT_MS */

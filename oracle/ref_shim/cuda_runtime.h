@@ -95,16 +95,105 @@ static inline cudaError_t cudaEventElapsedTime(float *ms, cudaEvent_t, cudaEvent
  * and gridDim.y enlarged by the block size: the same set of pixels, and the block-wide reduction degenerates to the
  * thread's own value.  Sums are therefore formed sequentially in launch order (the GPU's order is arbitrary). */
 #include <string.h>
+#include <vector>
+/* ---- execution order (round 6) -----------------------------------------------------------------------------------
+ * The reference sums with float atomicAdd everywhere (SolverBundlingDenseUtil.h:217-285, SolverBundling.cu:575-818): on a GPU
+ * the order in which the threads of a launch reach their atomics is arbitrary, and its own results move from run to run.
+ * BTBA_REF_ORDER (environment, read at every launch; or ref_set_order() of the solver wrapper) chooses the order in which
+ * the emulator walks the (block, thread) cells of EVERY launch:
+ *     forward (default)   blocks then threads ascending -- the one order rounds 1-5 used
+ *     reverse             the same walk backwards
+ *     shuffle:<seed>      a seeded Fisher-Yates permutation of all cells, a fresh one per launch (seed advanced by a launch counter
+ *                         that restarts at every ref_solve*, so a run is reproducible)
+ * Any of these is a legal execution: the solve path's kernels meet only through atomics (see above).  Because the pair list
+ * (FindImageImageCorr_Kernel) and the frame -> correspondence rows (BuildVariablesToCorrespondencesTableDevice) are handed out by
+ * atomicAdd as well, their order moves too -- exactly as it may on the GPU. */
+static int btba_order_mode = -1;            /* -1: not set by ref_set_order -> read BTBA_REF_ORDER; 0 forward, 1 reverse, 2 shuffle */
+static unsigned long long btba_order_seed = 0, btba_launch_counter = 0;
+static void (*btba_launch_hook)(const char *name) = 0;      /* called before every launch (the solver wrapper records the iterates with it) */
+static inline unsigned long long btba_splitmix(unsigned long long &s) { unsigned long long z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+static inline void btba_current_order(int &mode, unsigned long long &seed)
+{
+    mode = btba_order_mode; seed = btba_order_seed;
+    if (mode < 0) {
+        const char *e = getenv("BTBA_REF_ORDER");
+        mode = 0;
+        if (e && !strcmp(e, "reverse")) mode = 1;
+        else if (e && !strncmp(e, "shuffle", 7)) { mode = 2; seed = e[7] == ':' ? strtoull(e + 8, 0, 10) : 1; }
+    }
+}
 template <class F>
 static void btba_emulate(const char *name, F body, dim3 grid, dim3 block, size_t = 0, void * = 0)
 {
     if (strstr(name, "BuildDenseSystem_Kernel") || strstr(name, "FindDenseCorrespondences_Kernel")) { grid = dim3(grid.x, grid.y * block.x, 1); block = dim3(1, 1, 1); }
     gridDim = grid; blockDim = block;
-    for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned bx = 0; bx < grid.x; bx++) for (unsigned by = 0; by < grid.y; by++)
-        for (unsigned tz = 0; tz < block.z; tz++) for (unsigned ty = 0; ty < block.y; ty++) for (unsigned tx = 0; tx < block.x; tx++) {
-            blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz; threadIdx.x = tx; threadIdx.y = ty; threadIdx.z = tz;
-            body();
-        }
+    if (btba_launch_hook) btba_launch_hook(name);
+    int mode; unsigned long long seed;
+    btba_current_order(mode, seed);
+    const unsigned long long launch = btba_launch_counter++;
+    const size_t nthr = (size_t)block.x * block.y * block.z, nblk = (size_t)grid.x * grid.y * grid.z, total = nthr * nblk;
+    /* cell c (forward order): block = c / nthr walked as (bz, bx, by), thread = c % nthr as (tz, ty, tx) -- the nesting rounds 1-5 had */
+    auto run_cell = [&](size_t c) {
+        size_t b = c / nthr, t = c % nthr;
+        blockIdx.y = (unsigned)(b % grid.y); b /= grid.y; blockIdx.x = (unsigned)(b % grid.x); blockIdx.z = (unsigned)(b / grid.x);
+        threadIdx.x = (unsigned)(t % block.x); t /= block.x; threadIdx.y = (unsigned)(t % block.y); threadIdx.z = (unsigned)(t / block.y);
+        body();
+    };
+    if (mode == 0) { for (size_t c = 0; c < total; c++) run_cell(c); }
+    else if (mode == 1) { for (size_t c = total; c-- > 0;) run_cell(c); }
+    else {
+        std::vector<unsigned> perm(total);
+        for (size_t c = 0; c < total; c++) perm[c] = (unsigned)c;
+        unsigned long long s = seed * 0xD1342543DE82EF95ull + launch * 0x2545F4914F6CDD1Dull + 1;
+        for (size_t c = total; c > 1; c--) { size_t j = (size_t)(btba_splitmix(s) % c); unsigned tmp = perm[c - 1]; perm[c - 1] = perm[j]; perm[j] = tmp; }
+        for (size_t c = 0; c < total; c++) run_cell(perm[c]);
+    }
 }
 #define BTBA_LAUNCH(name, call, ...) btba_emulate(name, [&]() { call; }, __VA_ARGS__)
+
+/* ---- a model of the reference's build flags (round 6; -DBTBA_REF_FASTMATH, the `_fm` libraries of oracle/Makefile) ------------
+ * The reference is compiled with -use_fast_math (CMakeLists.txt:7) = --ftz=true --prec-div=false --prec-sqrt=false --fmad=true plus the
+ * sin/cos intrinsics: its arithmetic is NOT IEEE.  The `_fm` build models what those flags license, with the host compiler's own
+ * means where it has them and a seeded perturbation where it has not:
+ *   fmad          -ffp-contract=fast -mfma                      (the compiler contracts a*b+c as nvcc does by default)
+ *   prec-div=0,   -mrecip=all under -funsafe-math-optimizations -fno-associative-math -ffinite-math-only -fno-trapping-math:
+ *   prec-sqrt=0   x / y = x * rcp(y), sqrt via rsqrt, each with one Newton step from the 12-bit estimate (~1-2 ulp) -- no reassociation
+ *   ftz           MXCSR FTZ | DAZ for the duration of a ref_solve* call (ref_solver_wrap.h)
+ *   sin / cos     the float result rounded from double, then moved by up to +-2 ulp chosen by a hash of (argument bits, BTBA_REF_FM_SEED):
+ *                 __sinf / __cosf are less accurate than that (2^-21.4 absolute), so this UNDERSTATES the licence
+ *   asin / acos   +-1 ulp likewise (software sequences built on the approximate division)
+ * Different seeds are different, equally legal, libdevice builds. */
+#ifdef BTBA_REF_FASTMATH
+#include <cmath>
+#include <iostream>
+#include <algorithm>
+#include <vector>
+static unsigned long long btba_fm_seed = ~0ull;
+static inline float btba_fm_perturb(float r, float arg, int max_ulp)
+{
+    if (btba_fm_seed == ~0ull) { const char *e = getenv("BTBA_REF_FM_SEED"); btba_fm_seed = e ? strtoull(e, 0, 10) : 1; }
+    if (!(r == r) || r == 0.0f || fabsf(r) > 3.0e38f) return r;
+    unsigned a; memcpy(&a, &arg, 4);
+    unsigned long long s = btba_fm_seed * 0x9E3779B97F4A7C15ull + a;
+    const int k = (int)(btba_splitmix(s) % (unsigned)(2 * max_ulp + 1)) - max_ulp;
+    int bits; memcpy(&bits, &r, 4); bits += (bits < 0) ? -k : k; memcpy(&r, &bits, 4);      /* k ulp away from zero (k > 0) or towards it: the sign does not matter for a bound */
+    return r;
+}
+static inline float  btba_fm_sin(float x)   { return btba_fm_perturb((float)::sin((double)x), x, 2); }
+static inline float  btba_fm_cos(float x)   { return btba_fm_perturb((float)::cos((double)x), x, 2); }
+static inline float  btba_fm_asin(float x)  { return btba_fm_perturb((float)::asin((double)x), x, 1); }
+static inline float  btba_fm_acos(float x)  { return btba_fm_perturb((float)::acos((double)x), x, 1); }
+static inline double btba_fm_sin(double x)  { return ::sin(x); }
+static inline double btba_fm_cos(double x)  { return ::cos(x); }
+static inline double btba_fm_asin(double x) { return ::asin(x); }
+static inline double btba_fm_acos(double x) { return ::acos(x); }
+#define sin(x)   btba_fm_sin(x)
+#define cos(x)   btba_fm_cos(x)
+#define asin(x)  btba_fm_asin(x)
+#define acos(x)  btba_fm_acos(x)
+#define sinf(x)  btba_fm_sin((float)(x))
+#define cosf(x)  btba_fm_cos((float)(x))
+#define asinf(x) btba_fm_asin((float)(x))
+#define acosf(x) btba_fm_acos((float)(x))
+#endif
 #endif

@@ -18,12 +18,52 @@ static float4x4 rs_load4(const float *m) { float4x4 M; for (int r = 0; r < 4; r+
 // cudaMalloc per frame in a fresh CUDACache typically yields (ascending: target = higher index, every dense cross block written
 // above the diagonal and erased by FlipJtJ_Kernel, :49-59 -- BTBA_PAIRS_TARGET_HIGHER); any other permutation gives the
 // corresponding explicit orientation (BTBA_PAIRS_TARGET_MORE_VALID, BTBA_PAIRS_EXPLICIT).
+// ---- round 6: execution order, build-flag model, per-iterate record ---------------------------------------------------------
+// ref_set_order(mode, seed): 0 forward, 1 reverse, 2 seeded shuffle of every launch's (block, thread) cells, -1 = follow the
+// environment variable BTBA_REF_ORDER (ref_shim/cuda_runtime.h).  ref_build_flags(): 1 for the `_fm` library (-DBTBA_REF_FASTMATH).
+extern "C" __attribute__((visibility("default"))) void ref_set_order(int mode, unsigned long long seed) { btba_order_mode = mode; btba_order_seed = seed; }
+extern "C" __attribute__((visibility("default"))) int ref_build_flags(void)
+{
+#ifdef BTBA_REF_FASTMATH
+    return 1;
+#else
+    return 0;
+#endif
+}
+#ifdef BTBA_REF_FASTMATH
+extern "C" __attribute__((visibility("default"))) void ref_set_fastmath_seed(unsigned long long seed) { btba_fm_seed = seed; }
+#include <xmmintrin.h>
+#endif
+// The iterates: solveBundlingStub launches convertLiePosesToMatricesCU_Kernel at the top of every Gauss-Newton iteration
+// (SolverBundling.cu:953) with the CURRENT (d_xRot, d_xTrans); the emulator's launch hook copies them, so x_iter[n] = the unknowns
+// after iteration n (the copy taken at the top of iteration n + 1; the last one after the stub returns).
+static const float3 *rs_trace_rot = nullptr, *rs_trace_trans = nullptr;
+static float *rs_trace_out = nullptr;
+static int rs_trace_n = 0, rs_trace_seen = 0, rs_trace_max = 0;
+static void rs_trace_hook(const char *name)
+{
+    if (!rs_trace_out || !strstr(name, "convertLiePosesToMatricesCU_Kernel")) return;
+    if (rs_trace_seen > 0 && rs_trace_seen <= rs_trace_max) {
+        float *o = rs_trace_out + (size_t)(rs_trace_seen - 1) * rs_trace_n * 6;
+        for (int k = 0; k < rs_trace_n; k++) { o[6 * k] = rs_trace_rot[k].x; o[6 * k + 1] = rs_trace_rot[k].y; o[6 * k + 2] = rs_trace_rot[k].z;
+                                               o[6 * k + 3] = rs_trace_trans[k].x; o[6 * k + 4] = rs_trace_trans[k].y; o[6 * k + 5] = rs_trace_trans[k].z; }
+    }
+    rs_trace_seen++;
+}
+
 extern "C" __attribute__((visibility("default")))
-int ref_solve3(int N, int Wd, int Hd, const float *intr, const float *campos, const float *normals, const float *corr_in, int C,
+int ref_solve4(int N, int Wd, int Hd, const float *intr, const float *campos, const float *normals, const float *corr_in, int C,
                float *poses_io /* [N][16] row-major, camera -> model */, int n_gn, int n_pcg, float w_sparse, float w_dense, float robust_delta,
                float dist_thresh, float normal_thresh, float depth_min, float depth_max, float *x_out /* [N][6] rot, trans; may be NULL */,
-               const int *addr_rank, const float *w_sparse_it /* [n_gn] or NULL: w_sparse in every iteration */, const float *w_dense_it /* likewise */)
+               const int *addr_rank, const float *w_sparse_it /* [n_gn] or NULL: w_sparse in every iteration */, const float *w_dense_it /* likewise */,
+               float *T_iter /* [n_gn][N][16]: poseToMatrix of the unknowns after every iteration; may be NULL */)
 {
+    btba_launch_counter = 0;                                 // a run is reproducible whatever ran before it in this process
+#ifdef BTBA_REF_FASTMATH
+    const unsigned csr_saved = _mm_getcsr();
+    _mm_setcsr(csr_saved | 0x8040u);                         // --ftz=true: flush-to-zero + denormals-are-zero
+#endif
+    std::vector<float> x_iter(T_iter ? (size_t)n_gn * N * 6 : 0);
     const size_t npix = (size_t)Wd * Hd;
     const unsigned maxCorrPerImage = C > 0 ? (unsigned)C : 1u, maxPairs = (unsigned)(N * (N - 1) / 2 > 0 ? N * (N - 1) / 2 : 1);
     // frames: CUDACachedFrame[] with the float4 camPos / normal maps; the orientation of a dense pair is decided by comparing the
@@ -78,7 +118,19 @@ int ref_solve3(int N, int Wd, int Hd, const float *intr, const float *campos, co
 
     if (C > 0) buildVariablesToCorrespondencesTableCUDA(corr.data(), (unsigned)C, maxCorrPerImage, v2c.data(), nrows.data(), nullptr);
     SolverStateAnalysis analysis; memset(&analysis, 0, sizeof analysis);
+    rs_trace_rot = xRot.data(); rs_trace_trans = xTrans.data(); rs_trace_out = T_iter ? x_iter.data() : nullptr; rs_trace_n = N; rs_trace_seen = 0; rs_trace_max = n_gn;
+    btba_launch_hook = rs_trace_hook;
     solveBundlingStub(in, st, prm, analysis, nullptr, nullptr);
+    btba_launch_hook = nullptr;
+    if (T_iter) {
+        rs_trace_seen = n_gn; rs_trace_hook("convertLiePosesToMatricesCU_Kernel");                           // the last iterate
+        for (int it = 0; it < n_gn; it++) for (int k = 0; k < N; k++) {
+            const float *o = x_iter.data() + ((size_t)it * N + k) * 6;
+            const float4x4 M = poseToMatrix(make_float3(o[0], o[1], o[2]), make_float3(o[3], o[4], o[5]));
+            for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T_iter[((size_t)it * N + k) * 16 + 4 * r + c] = M(r, c);
+        }
+    }
+    rs_trace_out = nullptr;
 
     for (int k = 0; k < N; k++) {                                                                           // convertPosesToMatricesCU, SBA.cpp:115
         const float4x4 M = poseToMatrix(xRot[k], xTrans[k]);
@@ -90,7 +142,20 @@ int ref_solve3(int N, int Wd, int Hd, const float *intr, const float *campos, co
                         st.d_denseCorrCounts, st.d_xTransforms, st.d_xTransformInverses, st.d_denseOverlappingImages, st.d_numDenseOverlappingImages, st.d_corrCount,
                         st.d_corrCountColor, st.d_sumResidualColor };
     for (void *q : to_free) free(q);
+#ifdef BTBA_REF_FASTMATH
+    _mm_setcsr(csr_saved);
+#endif
     return 0;
+}
+
+extern "C" __attribute__((visibility("default")))
+int ref_solve3(int N, int Wd, int Hd, const float *intr, const float *campos, const float *normals, const float *corr_in, int C,
+               float *poses_io, int n_gn, int n_pcg, float w_sparse, float w_dense, float robust_delta,
+               float dist_thresh, float normal_thresh, float depth_min, float depth_max, float *x_out, const int *addr_rank,
+               const float *w_sparse_it, const float *w_dense_it)
+{
+    return ref_solve4(N, Wd, Hd, intr, campos, normals, corr_in, C, poses_io, n_gn, n_pcg, w_sparse, w_dense, robust_delta, dist_thresh, normal_thresh,
+                      depth_min, depth_max, x_out, addr_rank, w_sparse_it, w_dense_it, nullptr);
 }
 
 extern "C" __attribute__((visibility("default")))

@@ -178,35 +178,61 @@ def ransac_multi_pair(ptsA, ptsB, n_trials, dist_thres):
 
 # ---- the reference's WHOLE solver, emulated sequentially (oracle/_ref/libbtba_ref_solver.so) -----------------
 SO_SOLVER = os.path.join(_HERE, "_ref", "libbtba_ref_solver.so")
-_lib_s = None
+SO_SOLVER_FM = os.path.join(_HERE, "_ref", "libbtba_ref_solver_fm.so")      # the same sources under a model of the reference's own build flags (-use_fast_math)
+_lib_s = {}
 
 
-def lib_solver() -> C.CDLL:
-    global _lib_s
-    if _lib_s is None:
-        if not os.path.exists(SO_SOLVER):
+def lib_solver(fastmath: bool = False) -> C.CDLL:
+    so = SO_SOLVER_FM if fastmath else SO_SOLVER
+    if fastmath not in _lib_s:
+        if not os.path.exists(so):
             build(force=True)
-        _lib_s = C.CDLL(SO_SOLVER)
-    return _lib_s
+        L = C.CDLL(so)
+        L.ref_set_order.argtypes = [C.c_int, C.c_ulonglong]
+        assert L.ref_build_flags() == (1 if fastmath else 0)
+        if fastmath:
+            L.ref_set_fastmath_seed.argtypes = [C.c_ulonglong]
+        _lib_s[fastmath] = L
+    return _lib_s[fastmath]
+
+
+def _order_args(order):
+    """'forward' | 'reverse' | 'shuffle:<seed>' | None (= follow the environment variable BTBA_REF_ORDER) -> (mode, seed) of ref_set_order."""
+    if order is None:
+        return -1, 0
+    if order == "forward":
+        return 0, 0
+    if order == "reverse":
+        return 1, 0
+    if order.startswith("shuffle"):
+        return 2, int(order.split(":")[1]) if ":" in order else 1
+    raise ValueError(order)
 
 
 def solve(campos, normals, intr, corr, poses, n_gn=7, n_pcg=5, weight_sparse=1.0, weight_dense=1.0, robust_delta=0.005,
           dist_thresh=0.02, normal_thresh=float(np.cos(np.pi / 4)), depth_min=0.1, depth_max=9999.0, addr_rank=None,
-          weights_sparse=None, weights_dense=None):
+          weights_sparse=None, weights_dense=None, order="forward", fastmath=False, fastmath_seed=1, want_iterates=False):
     """solveBundlingStub (SolverBundling.cu:931-1003) and everything under it, run by the reference's own code.
-    Returns (poses [N,4,4] after n_gn Gauss-Newton iterations, x [N,6] = (rot, trans)).
+    Returns (poses [N,4,4] after n_gn Gauss-Newton iterations, x [N,6] = (rot, trans)); with want_iterates a third value,
+    T_iter [n_gn, N, 4, 4] = the reference's poseToMatrix of its unknowns after every iteration (recorded at the top of the next one).
     addr_rank: permutation of 0..N-1 ordering the frames' d_num_valid_points ADDRESSES, which is what orients the dense pairs in
     the reference (FindImageImageCorr_Kernel keeps (target i, source j) iff address_i > address_j): None = descending in frame
     order (target = lower index), np.arange(N) = ascending (target = higher index, cross blocks erased by FlipJtJ).
-    weights_sparse / weights_dense: per-iteration weights [n_gn] (input.weightsSparse / weightsDenseDepth, SolverBundling.cu:948-949) or None."""
+    weights_sparse / weights_dense: per-iteration weights [n_gn] (input.weightsSparse / weightsDenseDepth, SolverBundling.cu:948-949) or None.
+    order: the order in which the launch emulator runs the (block, thread) cells of every launch -- each a legal execution of kernels that
+    meet only through float atomics (ref_shim/cuda_runtime.h); fastmath: the library built under the model of -use_fast_math (oracle/Makefile)."""
     campos, normals = _f(campos, normals)
     N, Hd, Wd = campos.shape[:3]
     (intr,) = _f(intr)
     corr = np.ascontiguousarray(corr)
     P = np.ascontiguousarray(poses, np.float32).reshape(N, 16).copy()
     x = np.zeros((N, 6), np.float32)
-    f = lib_solver().ref_solve3
-    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 7 + [C.c_void_p] * 4
+    L = lib_solver(fastmath)
+    L.ref_set_order(*_order_args(order))
+    if fastmath:
+        L.ref_set_fastmath_seed(int(fastmath_seed))
+    f = L.ref_solve4
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 7 + [C.c_void_p] * 5
     wsi = np.ascontiguousarray(weights_sparse, np.float32) if weights_sparse is not None else None
     wdi = np.ascontiguousarray(weights_dense, np.float32) if weights_dense is not None else None
     assert (wsi is None or len(wsi) == n_gn) and (wdi is None or len(wdi) == n_gn)
@@ -215,10 +241,34 @@ def solve(campos, normals, intr, corr, poses, n_gn=7, n_pcg=5, weight_sparse=1.0
         rank = np.ascontiguousarray(addr_rank, np.int32)
         if sorted(rank.tolist()) != list(range(N)):
             raise ValueError("addr_rank must be a permutation of 0..N-1")
+    T_iter = np.zeros((n_gn, N, 4, 4), np.float32) if want_iterates else None
     f(N, Wd, Hd, _p(intr), _p(campos), _p(normals), _p(corr), len(corr), _p(P), n_gn, n_pcg, weight_sparse, weight_dense, robust_delta,
       dist_thresh, normal_thresh, depth_min, depth_max, _p(x), _p(rank) if rank is not None else None,
-      _p(wsi) if wsi is not None else None, _p(wdi) if wdi is not None else None)
+      _p(wsi) if wsi is not None else None, _p(wdi) if wdi is not None else None, _p(T_iter) if want_iterates else None)
+    if want_iterates:
+        return P.reshape(N, 4, 4), x, T_iter
     return P.reshape(N, 4, 4), x
+
+
+# (execution order, fast-math model) of the runs a self-spread measurement compares; the first entry is the run rounds 1-5 used
+VARIANTS = [("forward", False), ("reverse", False), ("shuffle:1", False), ("shuffle:2", False),
+            ("forward", True), ("reverse", True), ("shuffle:1", True), ("shuffle:2", True)]
+
+
+def self_spread(campos, normals, intr, corr, poses, pose_error, variants=None, **kw):
+    """THE REFERENCE AGAINST ITSELF: the same inputs through the reference's own solver under several legal execution orders of its float
+    atomics and, for the fast-math entries, under the model of its own -use_fast_math build.  Returns (spread [n_gn] = per iterate the largest
+    pose difference (rad | m) between any variant and the forward / IEEE run, the iterates of every run [n_variants, n_gn, N, 4, 4])."""
+    variants = VARIANTS if variants is None else variants
+    N = np.asarray(poses).reshape(-1, 4, 4).shape[0]
+    runs = [solve(campos, normals, intr, corr, poses, order=o, fastmath=fm, want_iterates=True, **kw)[2] for (o, fm) in variants]
+    base = runs[0]
+    G = base.shape[0]
+    spread = np.zeros(G)
+    for r in runs[1:]:
+        for it in range(G):
+            spread[it] = max(spread[it], max(max(pose_error(r[it, k], base[it, k])) for k in range(N)))
+    return spread, np.stack(runs)
 
 
 # ---- the reference's image kernels (oracle/_ref/libbtba_ref_image.so) ----------------------------------------

@@ -202,9 +202,12 @@ def test_c5_shape_batch_properties(gpu):
 
 
 def test_one_tracker_window_stays_inside_its_recorded_budget():
-    """The operating point of the reference's tracker -- ONE object-masked window per call (Bundler.cpp:350-351) -- watched by the gate: the device time
-    of the solve inside btba_optimize_frames_keyed (btba_stats.ms_solve, median of 30 steady-state calls) must not exceed the recorded budget
-    (tests/golden/tracker_budget.json) by more than 10 %.  Round 4's verdict: this number regressed unnoticed while the batched headline improved."""
+    """The operating point of the reference's tracker -- ONE object-masked window per call (Bundler.cpp:350-351) -- watched by a gate: the device time of the
+    solve inside btba_optimize_frames_keyed (btba_stats.ms_solve, median of 30 steady-state calls).  Round 4's verdict: this number regressed unnoticed while
+    the batched headline improved.  A correctness suite must not fail on another GPU, a loaded box or under a profiler (round 5's advisor), so the gate that
+    always runs is a RATIO measured in this process: the default path must not be slower than the same call with rounds 1-4's system solve
+    (BTBA_OPT_SOLVE_SMALL = 0; recorded 0.134 against 0.209 ms).  The ABSOLUTE budget (tests/golden/tracker_budget.json + 10 %) is checked only on request
+    (BTBA_PERF_GATE=1: the builder's campaign on the recording box class)."""
     import json
     import torch
     from bundletrack_amd.optimizer import OptimizerGpu, Workspace
@@ -214,17 +217,24 @@ def test_one_tracker_window_stays_inside_its_recorded_budget():
     pb = S.make_problem(K, m, seed=S.config_seed(3, 0) + K, background=False)
     depths = [torch.from_numpy(pb.depth[k]).to(dev) for k in range(K)]
     normals = [torch.from_numpy(pb.normals[k]).to(dev) for k in range(K)]
-    opt = OptimizerGpu(workspace=Workspace())
-    ms = []
-    for rep in range(40):
-        poses = pb.poses_init.copy()
-        opt.optimizeFrames(pb.corr, pb.n_match_per_pair, K, pb.H, pb.W, depths, None, normals, poses, pb.K, frame_keys=list(range(K - 1)) + [1000 + rep])
-        if rep >= 10:
-            ms.append(opt.last_stats["ms_solve"])
-            assert opt.last_stats["cache_frames_built"] == 1
-    med = float(np.median(ms))
-    print(f"one masked c3 window: ms_solve median {med:.4f} (budget {budget['ms_solve']} + {100 * budget['tolerance']:.0f} %)")
-    assert med <= budget["ms_solve"] * (1.0 + budget["tolerance"]), (med, budget)
+
+    def median_ms_solve(solve_small):
+        ws = Workspace()
+        ws.set_option(_lib.OPT_SOLVE_SMALL, solve_small)
+        opt = OptimizerGpu(workspace=ws)
+        ms = []
+        for rep in range(40):
+            poses = pb.poses_init.copy()
+            opt.optimizeFrames(pb.corr, pb.n_match_per_pair, K, pb.H, pb.W, depths, None, normals, poses, pb.K, frame_keys=list(range(K - 1)) + [1000 + rep])
+            if rep >= 10:
+                ms.append(opt.last_stats["ms_solve"])
+                assert opt.last_stats["cache_frames_built"] == 1
+        return float(np.median(ms))
+    med, legacy = median_ms_solve(1), median_ms_solve(0)
+    print(f"one masked c3 window: ms_solve median {med:.4f} (rounds 1-4's system solve in the same process: {legacy:.4f}; recorded budget {budget['ms_solve']} + {100 * budget['tolerance']:.0f} %)")
+    assert med <= 1.02 * legacy, (med, legacy)
+    if os.environ.get("BTBA_PERF_GATE") == "1":
+        assert med <= budget["ms_solve"] * (1.0 + budget["tolerance"]), (med, budget)
 
 
 def test_large_caches_keep_the_block_walk_in_chip_filling_batches(gpu):

@@ -18,27 +18,11 @@ def run_cases(n_cases, explain_always=False, only=None, hook=None, prepare=None)
     """Yields one record per case (see the module docstring).  only: solve just that case (the others still draw their random numbers);
     hook(rec, pb, corr, caches, ref, tv): called for explained cases with the problem and both traces; prepare(pb): may edit the problem before it is solved."""
     dev = torch.device("cuda:0")
-    rng = np.random.default_rng(20260925)
     opt = OptimizerGpu()
     ws = Workspace()
-    for case in range(n_cases):
-        K = int(rng.integers(2, 10))
-        m = int(rng.choice([0, 5, 60, 200, 500]))
-        background = bool(rng.integers(0, 2))
-        perturb = float(rng.choice([0.5, 2.0, 4.0]))
-        pb = S.make_problem(K, m, seed=9000 + case, background=background, perturb_deg=perturb)
-        corr = pb.corr.copy()
-        counts = np.array(pb.n_match_per_pair, np.int64).copy()
-        # ragged pairs: empty a pair, thin another by invalidating entries (EntryJ::isValid: imgIdx_i == 0xFFFFFFFF)
-        if m and len(counts) > 1:
-            off = np.concatenate([[0], np.cumsum(counts)])
-            kill = int(rng.integers(0, len(counts)))
-            corr["imgIdx_i"][off[kill]:off[kill + 1]] = 0xFFFFFFFF
-            thin = int(rng.integers(0, len(counts)))
-            sel = off[thin] + rng.choice(max(1, counts[thin]), size=max(1, counts[thin] // 3), replace=False)
-            corr["imgIdx_i"][sel[sel < off[thin + 1]]] = 0xFFFFFFFF
-        if only is not None and case != only:
-            continue
+    from fuzz_cases import fuzz_cases              # the generator is shared with the CPU-side tools (tests/fuzz_cases.py)
+    for case, pb, corr, meta in fuzz_cases(n_cases, only=only):
+        K, m, background, perturb = meta["K"], meta["corr_per_pair"], meta["background"], meta["perturb_deg"]
         if prepare is not None:                 # (experiments: e.g. replace the starting poses by a fixed point of Exp(Log(.)) -- after all random draws)
             prepare(pb)
         depths = [torch.from_numpy(pb.depth[k]).to(dev) for k in range(K)]
