@@ -87,7 +87,7 @@ def _lib_entryj():
     return _lib.ENTRYJ_DTYPE
 
 
-SOLVER_SOURCES = ("btba_kernels.hpp", "btba_solve_small.hpp", "btba_device.hpp", "btba_api.hip")      # what the sweep / solve kernels are built from
+SOLVER_SOURCES = ("btba_kernels.hpp", "btba_solve_small.hpp", "btba_solve_mid.hpp", "btba_device.hpp", "btba_api.hip")      # what the sweep / solve kernels are built from
 
 
 def kernel_source_hash():

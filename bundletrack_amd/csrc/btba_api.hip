@@ -20,6 +20,7 @@
 #include "../../include/btba.h"
 #include "btba_kernels.hpp"
 #include "btba_solve_small.hpp"
+#include "btba_solve_mid.hpp"
 #include "btba_image.hpp"
 #include "btba_ransac.hpp"
 #include "btba_xorwow.hpp"
@@ -112,7 +113,7 @@ struct btba_workspace {
     std::vector<EventPair> events;                          // pending timed regions
     std::vector<hipEvent_t> event_pool;
     btba_stats stats{};
-    bool lds_attr_set = false, small_attr_set = false;
+    bool lds_attr_set = false, small_attr_set = false, mid_attr_set = false;
     int n_cus = 0;                     // compute units of the workspace's device (256 = all eight XCDs of an MI355X in SPX mode: what k_chain's item -> XCD mapping assumes)
     bool always_time_region = false;   // optimize_frames: ms_solve is part of its stats contract
     static constexpr int kMaxGroups = 8;
@@ -762,7 +763,11 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     // larger windows: reduce the partials and assemble the system on many workgroups (k_big_reduce, k_big_assemble); the traced solve
     // keeps the single-workgroup path, whose trace records the system.  Worth two extra launches per iteration from ~24 frames on
     // (one workgroup: 90 k of the 140 k cycles of a launch at N = 31 are reduction and assembly; at N = 15 19 k of 45 k, less than the launches)
-    D.pre_assembled = ((a_global || N >= 24) && !trace && ws->tune.big_assembly) ? 1 : 0;
+    // (round 6: windows of 22 ... 31 frames with at most one dense pair per canonical pair run k_solve_mid -- reduction, assembly, PCG and update in ONE launch,
+    // btba_solve_mid.hpp -- unless BTBA_OPT_SOLVE_SMALL = 0 or the reference's atomic summation is asked for)
+    const size_t mid_lds = sizeof(float) * mid_solve_lds_floats(N, D.n_dense_pairs);
+    const bool mid_solve = ws->tune.solve_small && N > kSmallMaxFrames && N <= kMidMaxFrames && !atomic_sums && !a_global && D.n_dense_pairs <= P && mid_lds <= lds_limit;
+    D.pre_assembled = ((a_global || N >= 24) && !trace && ws->tune.big_assembly && !mid_solve) ? 1 : 0;
     if (a_global || D.pre_assembled) { if ((rc = ws->big_A.ensure((size_t)B * (n + 2) * ld * sizeof(float)))) return rc; }      // per instance: A[n][ld], rhs[ld], prec[ld]
     if (D.pre_assembled && D.pairsum_in_lds) { D.pairsum_in_lds = 0; if ((rc = ws->pairsum.ensure((size_t)B * lds_pairs + 16))) return rc; }
     if (lds_bytes > 64 * 1024 || !ws->lds_attr_set) {
@@ -784,6 +789,10 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         ws->small_attr_set = true;
+    }
+    if (mid_solve && !ws->mid_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_mid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        ws->mid_attr_set = true;
     }
 
     // stats bookkeeping (collected after sync)
@@ -952,7 +961,7 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
     }
     const size_t pairsum_floats = lds_pairs / sizeof(float);
     S.chain_iterations = 0;
-    const size_t lut_bytes = sizeof(float) * (size_t)((Wd + Hd + 3) & ~3) + (zn_layout == 1 ? sizeof(float4) * (size_t)(Wd + Hd) : 0) + blist_bytes + (size_t)ws->tune.debug_lds_pad;         // coordinate look-up tables of the compact dense sweep (+ its list of live blocks)
+    const size_t lut_bytes = sizeof(float) * (size_t)((Wd + Hd + 3) & ~3) + (zn_layout == 1 ? sizeof(float4) * (size_t)(Wd + Hd + 4) : 0) + blist_bytes + (size_t)ws->tune.debug_lds_pad;         // coordinate look-up tables of the compact dense sweep (+ its list of live blocks)
     if (chain) {
         // ONE launch: 8 XCD sequences x n_gn iterations x (instances of the XCD) x (sweep items + 1 solve item)
         const size_t chain_lds = std::max(lut_bytes, lds_rest + 16 + sizeof(float) * chain_region_floats(N));
@@ -1127,8 +1136,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                 k_big_assemble<<<dim3((bt.total + 255u) / 256u, (unsigned)H.nb), 256, 0, H.st>>>(Di, ps_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, ws->solve_tab.as<int>(), A_h);
             }
 #define BTBA_SOLVE(LP, AG) k_system_solve<LP, AG><<<H.nb, kSolveBlock, lds_bytes, H.st>>>(Ds, it, sp_h, dp_h, ws->dense_pairs.as<int2>(), d_adj_off, d_adj, x_h, T_h, Ti_h, ps_h, tr_h, A_h, out_h, ws->solve_tab.as<int>())
-            if (small_solve) {
-                // tracker-sized windows: k_solve_small (btba_solve_small.hpp)
+            if (small_solve || mid_solve) {
+                // tracker-sized windows: k_solve_small (btba_solve_small.hpp); 22 ... 31 frames: k_solve_mid (btba_solve_mid.hpp)
                 SmallSolveArgs Sa{};
                 Sa.n_frames = N; Sa.n_pairs = P; Sa.n_dense_pairs = use_dense_it ? D.n_dense_pairs : 0;
                 Sa.sparse_chunks = Ds.sparse_chunks; Sa.dense_tiles = Ds.dense_tiles; Sa.n_pcg = D.n_pcg; Sa.use_sparse = use_sparse ? 1 : 0;
@@ -1140,7 +1149,8 @@ static int solve_enqueue(btba_workspace *ws, const btba_params *prm, int B, int 
                 Sa.sparse_partials = sp_h; Sa.dense_partials = dp_h;
                 Sa.adj_off = d_adj_off; Sa.adj = d_adj; Sa.cross = d_adj + 2 * (size_t)Pd; Sa.pair_ij = ws->solve_tab.as<int>(); Sa.entry_lut = ws->solve_tab.as<int>() + (((size_t)P + 288 + 3) & ~(size_t)3);
                 Sa.x = x_h; Sa.T = T_h; Sa.Tinv = Ti_h; Sa.poses_out = out_h; Sa.trace = D.trace_on ? tr_h : nullptr;
-                if (small_cpl_v == 4) k_solve_small<4><<<H.nb, kSmallBlock, small_lds, H.st>>>(Sa);
+                if (mid_solve) k_solve_mid<<<H.nb, kSmallBlock, mid_lds, H.st>>>(Sa);
+                else if (small_cpl_v == 4) k_solve_small<4><<<H.nb, kSmallBlock, small_lds, H.st>>>(Sa);
                 else if (small_cpl_v == 8) k_solve_small<8><<<H.nb, kSmallBlock, small_lds, H.st>>>(Sa);
                 else if (small_cpl_v == 12) k_solve_small<12><<<H.nb, kSmallBlock, small_lds, H.st>>>(Sa);
                 else k_solve_small<16><<<H.nb, kSmallBlock, small_lds, H.st>>>(Sa);

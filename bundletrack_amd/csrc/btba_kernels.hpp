@@ -989,6 +989,28 @@ struct PinholeCtx {
 __device__ __forceinline__ float lds_f32_at(const float *base, unsigned byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); }
 __device__ __forceinline__ float2 lds_f32x2_at(const float *base, unsigned byte_off) { const char *q = reinterpret_cast<const char *>(base) + byte_off; return make_float2(*reinterpret_cast<const float *>(q), *reinterpret_cast<const float *>(q + 4)); }
 __device__ __forceinline__ float4 gather16(const float4 *base, unsigned byte_off) { return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off); }
+// ... with the constant part of the address as the load's immediate offset (base + zext(byte_off) + IMM in 64 bits: a 32-bit `byte_off + IMM` may wrap, so the
+// compiler cannot fold it and spends a vector add per tap)
+template <int IMM> __device__ __forceinline__ float4 gather16_imm(const char *base, unsigned byte_off) { return *reinterpret_cast<const float4 *>(base + (size_t)byte_off + IMM); }
+#ifndef BTBA_POSE_LDS
+#define BTBA_POSE_LDS 1
+#endif
+#ifndef BTBA_TAP_BASES
+#define BTBA_TAP_BASES 1
+#endif
+#ifndef BTBA_STREAM_SADDR
+#define BTBA_STREAM_SADDR 1
+#endif
+#ifndef BTBA_LUT_ABS
+#define BTBA_LUT_ABS 1
+#endif
+#ifndef BTBA_LIST_LANES
+#define BTBA_LIST_LANES 1
+#endif
+// LDS byte address of a pointer into the workgroup's LDS, and two consecutive floats at an absolute LDS byte address: the table base rides in the fp32 address
+// arithmetic (exact below 2^24) instead of costing a vector add behind every float -> int conversion
+__device__ __forceinline__ unsigned lds_address(const void *p) { return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)p; }
+__device__ __forceinline__ float2 lds_f32x2_abs(unsigned addr) { const __attribute__((address_space(3))) float *q = (const __attribute__((address_space(3))) float *)(unsigned long)addr; return make_float2(q[0], q[1]); }
 // opaque copy: keeps a value in a VGPR the compiler cannot see through
 __device__ __forceinline__ unsigned opaque_vgpr(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 // v_min_f32 as the hardware does it: fminf() makes the compiler canonicalise its operands first (v_max_f32 x, x, x -- a half-rate
@@ -1157,7 +1179,17 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         else rowB[e - D.width] = make_float4(C.R[1] * l + C.R[2], C.R[4] * l + C.R[5], C.R[7] * l + C.R[8], 0.0f);
     }
     if (tid >= 64 && tid < 64 + 36) red[4 * kDenseVals + kDenseVals + 4 + ((int)tid - 64)] = m_stage;
-    int *hdr = reinterpret_cast<int *>(rowB + D.height);                  // [0 .. 8) wave totals of the list compaction (two blocks per lane and pass: [0 .. 4) first halves, [4 .. 8) second)
+    // Round 6: the pair's wave-uniform operands of the pixel loop -- relative pose and intrinsics -- ALSO in LDS, four 16-byte entries [R row | t] x 3,
+    // (fx, fy, cx, cy).  A VALU instruction with a scalar-register source issues at HALF rate on gfx950 (profiles/r02/valu_calibration.md, rows `y:`), and
+    // the loop has 16 of them per trip (3 translation FMAs, 4 projection multiply-adds, 9 for the normal rotation: 32 of a trip's 388 issue cycles); holding
+    // the 16 values in VGPRs for the whole loop costs a wave per SIMD (archive 4.2: 101 VGPRs, slower).  Read back per trip as broadcast LDS loads
+    // (LDS issue is not VALU issue) they live in VGPRs for a few instructions only.  Same operations on the same values: same bits.
+    float4 *pose_l = rowB + D.height;
+    if (tid == 0) {
+        pose_l[0] = make_float4(C.R[0], C.R[1], C.R[2], C.t[0]); pose_l[1] = make_float4(C.R[3], C.R[4], C.R[5], C.t[1]);
+        pose_l[2] = make_float4(C.R[6], C.R[7], C.R[8], C.t[2]); pose_l[3] = make_float4(D.fx, D.fy, D.cx, D.cy);
+    }
+    int *hdr = reinterpret_cast<int *>(pose_l + 4);                       // [0 .. 8) wave totals of the list compaction (two blocks per lane and pass: [0 .. 4) first halves, [4 .. 8) second)
     unsigned *blist = reinterpret_cast<unsigned *>(hdr + 8);
     int n_live = 0;
     if (WALK == 2) {
@@ -1225,6 +1257,10 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
 #ifdef BTBA_CENSUS
     unsigned cen[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };      // wave-uniform lane counts (scripts/sweep_census.py)
 #endif
+    typedef const volatile __attribute__((address_space(3))) btba_f4v lds_cv4;        // (an explicit LDS pointer: a volatile access through a generic one stays a flat_load)
+    lds_cv4 *pose_v = (lds_cv4 *)pose_l;
+    const char *tap_row0 = reinterpret_cast<const char *>(zn_t), *tap_row1 = tap_row0 + C.row16;
+    const float lut_addr_f = (float)lds_address(lut), ybase4_abs = C.ybase4 + lut_addr_f;
     auto pixel = [&](const float4 &zs, unsigned ox, unsigned oy) {
 #ifdef BTBA_TRIP_TRACE
         unsigned long long tt0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt0) :: "memory");
@@ -1234,9 +1270,18 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const bool src_ok = (__float_as_uint(d) - C.zmin_bits) < C.zrange_bits;
         // transform the point, project
         const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(colA) + ox), rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(colA) + oy);
+#if BTBA_POSE_LDS
+        const btba_f4v P0 = pose_v[0], P1 = pose_v[1], P2 = pose_v[2], PK = pose_v[3];      // volatile: re-read every trip, never hoisted into loop-long registers
+        // (fma_nd: with every operand in a VGPR the compiler overwrites the addend's register, and such a read-modify-write FMA issues at half rate when its
+        // two multiplicands share a register parity -- the allocator's luck; a fresh destination is full rate whatever it gets)
+        const float qx = fma_nd(ra.x + rb.x, d, P0.w), qy = fma_nd(ra.y + rb.y, d, P1.w), qz = fma_nd(ra.z + rb.z, d, P2.w);
+        const float rqz = fast_rcp(qz);
+        const float u = fma_nd(qx * PK.x, rqz, PK.z), v = fma_nd(qy * PK.y, rqz, PK.w);
+#else
         const float qx = (ra.x + rb.x) * d + C.t[0], qy = (ra.y + rb.y) * d + C.t[1], qz = (ra.z + rb.z) * d + C.t[2];
         const float rqz = fast_rcp(qz);
         const float u = qx * C.fx * rqz + C.cx, v = qy * C.fy * rqz + C.cy;
+#endif
         const float uc = clamp0_s(u, C.wm1), vc = clamp0_s(v, C.hm1);      // NaN -> 0: addresses stay in the frame
         const bool valid = src_ok & (fabsf(u - uc) < 0.5f) & (fabsf(v - vc) < 0.5f);
 #ifdef BTBA_CENSUS
@@ -1251,16 +1296,32 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
 #endif
         // rotate the normal (only the waves that go on need it: half of the block trips end above)
+#if BTBA_POSE_LDS
+        const float nqx = fma_nd(P0.z, zs.w, fma_nd(P0.y, zs.z, P0.x * zs.y));
+        const float nqy = fma_nd(P1.z, zs.w, fma_nd(P1.y, zs.z, P1.x * zs.y));
+        const float nqz = fma_nd(P2.z, zs.w, fma_nd(P2.y, zs.z, P2.x * zs.y));
+#else
         const float nqx = C.R[0] * zs.y + C.R[1] * zs.z + C.R[2] * zs.w;
         const float nqy = C.R[3] * zs.y + C.R[4] * zs.z + C.R[5] * zs.w;
         const float nqz = C.R[6] * zs.y + C.R[7] * zs.z + C.R[8] * zs.w;
+#endif
         // taps (x0, x0 + 1) x (y0, y0 + 1) with x0 = min(floor(uc), W - 2): at the right / bottom edge (uc = W - 1) the weights are (0, 1)
         // instead of (1, -) -- the same blend, and the four taps are always the 2 x 2 block at ONE computed address
         const float fx0 = min_raw_s(floorf(uc), C.wm2), fy0 = min_raw_s(floorf(vc), C.hm2);
         const float alpha = uc - fx0, beta = vc - fy0;
+#if BTBA_TAP_BASES
+        // one computed byte offset for the 2 x 2 block: the second row's base is a scalar add (wave-uniform), the + 16 the load's immediate offset field
+        const unsigned o00 = (unsigned)(fy0 * C.w16 + 16.0f * fx0);                             // byte offset, fp32-exact below 2^24
+        const float4 z00 = gather16_imm<0>(tap_row0, o00), z10 = gather16_imm<16>(tap_row0, o00), z01 = gather16_imm<0>(tap_row1, o00), z11 = gather16_imm<16>(tap_row1, o00);
+#else
         const unsigned o00 = (unsigned)(fy0 * C.w16 + 16.0f * fx0), o01 = o00 + C.row16;      // byte offsets, fp32-exact below 2^24
         const float4 z00 = gather16(zn_t, o00), z10 = gather16(zn_t, o00 + 16u), z01 = gather16(zn_t, o01), z11 = gather16(zn_t, o01 + 16u);
+#endif
+#if BTBA_LUT_ABS
+        const float2 xi2 = lds_f32x2_abs((unsigned)(4.0f * fx0 + lut_addr_f)), yi2 = lds_f32x2_abs((unsigned)(4.0f * fy0 + ybase4_abs));
+#else
         const float2 xi2 = lds_f32x2_at(lut, (unsigned)(4.0f * fx0)), yi2 = lds_f32x2_at(lut, (unsigned)(4.0f * fy0 + C.ybase4));
+#endif
         const float a0 = 1.0f - alpha, b0 = 1.0f - beta;
         // blend of the taps' camera-space points (x = column term * z, y = row term * z, z = gated depth) and normals; the
         // column / row terms are shared by the taps of a column / row, so they multiply the partial sums:
@@ -1341,6 +1402,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const unsigned lx = (unsigned)lane & 7u, ly = (unsigned)lane >> 3;
         const unsigned lane_px = ly * (unsigned)D.width + lx;          // pixel offset of the lane inside its block
         const unsigned ox_l = 16u * lx, oy_l = 16u * ly + 16u * (unsigned)D.width;
+        unsigned lane_off16 = 16u * lane_px;
         constexpr unsigned kBlockStep = 128u;            // 8 entries of 16 bytes
         // This wave's blocks: list entries wave, wave + 4, ... -- nt of them.  While block i is worked on, block i + 1's pixels are in flight.
         // The prefetch is UNCONDITIONAL (the last trip re-reads its own block): with a conditional one the number of loads in flight behind it
@@ -1351,9 +1413,29 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         // Two trips per loop iteration with the two register sets swapping roles: a single-trip loop rotates (next -> current) through
         // eight v_mov per trip, 5 % of its instructions.
         const int nt = (n_live > wave) ? (n_live - wave + kBlock / 64 - 1) / (kBlock / 64) : 0;
+#if BTBA_LIST_LANES
+        // this wave's list entries ride in a register, 64 at a time (lane l: entry 64 c + l of the wave), and a trip takes its entry with v_readlane_b32:
+        // no LDS round trip (address move, ds_read, wait, readfirstlane) at the top of every trip
+        int list_chunk = 0;
+        unsigned list_reg = nt > 0 ? blist[wave + (kBlock / 64) * min(lane, nt - 1)] : 0u;
+#endif
         auto fetch = [&](int i, unsigned &code, float4 &zs) {
+#if BTBA_LIST_LANES
+            const int idx = min(i, nt - 1);
+            if ((idx >> 6) != list_chunk) { list_chunk = idx >> 6; list_reg = blist[wave + (kBlock / 64) * min(64 * list_chunk + lane, nt - 1)]; }
+            code = (unsigned)__builtin_amdgcn_readlane((int)list_reg, idx & 63);
+#else
             code = (unsigned)__builtin_amdgcn_readfirstlane((int)blist[wave + (kBlock / 64) * min(i, nt - 1)]);
+#endif
+#if BTBA_STREAM_SADDR
+            // block base in the scalar address (wave-uniform), the lane's pixel inside the block as the constant vector offset: no vector add per trip
+            // (the lane offset goes through an opaque copy: seen as loop-invariant, `frame base + lane offset` is hoisted as a 64-bit VECTOR address and the block
+            // offset becomes a 64-bit vector add per trip)
+            asm volatile("" : "+v"(lane_off16));          // (in place: no copy)
+            zs = gather16_imm<0>(reinterpret_cast<const char *>(zn_s) + (size_t)(16u * ((code >> 16) * 8u * (unsigned)D.width + (code & 0xFFFFu) * 8u)), lane_off16);
+#else
             zs = gather16(zn_s, 16u * ((code >> 16) * 8u * (unsigned)D.width + (code & 0xFFFFu) * 8u + lane_px));
+#endif
         };
         auto work = [&](const float4 &zs, unsigned code) { pixel(zs, ox_l + kBlockStep * (code & 0xFFFFu), oy_l + kBlockStep * (code >> 16)); };
         if (nt > 0) {

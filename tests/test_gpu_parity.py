@@ -820,11 +820,11 @@ def test_randomised_windows_are_explained(gpu, oracle):
     assert n_tight >= 7               # the well-posed half of the draw holds the plain 1e-4 bar on every iterate
 
 
-@pytest.mark.parametrize("K", [2, 3, 6, 7, 11, 12, 15, 17, 18, 21], ids=lambda k: f"K{k}")
+@pytest.mark.parametrize("K", [2, 3, 6, 7, 11, 12, 15, 17, 18, 21, 22, 25, 30, 31], ids=lambda k: f"K{k}")
 def test_small_solve_kernel_agrees_with_the_legacy_kernel(gpu, K):
     """k_solve_small (round 5, BTBA_OPT_SOLVE_SMALL = 1, the default for windows of <= 21 frames) against k_system_solve (0) on the same inputs: the
     same sums in another order.  Window sizes at both ends of each of its four instantiations (8 x 4 / 8 / 12 / 16 matrix columns per row group:
-    <= 6 / 11 / 17 / 21 frames), object-masked frames, two instances per batch (one partial per sum at K >= 15, several below), per iterate:
+    <= 6 / 11 / 17 / 21 frames) and, round 6, of k_solve_mid (22 ... 31 frames: matrix rows gathered into registers, btba_solve_mid.hpp), object-masked frames, two instances per batch (one partial per sum at K >= 15, several below), per iterate:
     system matrix, right-hand side, Jacobi diagonal and accepted-pixel counts of the first linearisation to round-off, iterates within the 1e-4 bar
     while the decisions are identical."""
     from helpers import first_decision_divergence
