@@ -120,6 +120,23 @@ struct btba_workspace {
     uint64_t solves_enqueued = 0;      // rotates the sampled iteration of BTBA_FLAG_TIME_SAMPLED
     hipStream_t aux_streams[kMaxGroups - 1] = {};  // groups 1 .. G-1 of a batch run here (software pipelining across instances)
     hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {}, ev_order = nullptr;
+    // optimize_frames (round 6): the EntryJ / pose upload runs on a stream of its own while the frame cache is built on `stream`; small tables the cache build and
+    // the solve need (pointer tables, slot maps, valid counts) go through ONE pinned staging block, so that no call has to synchronise just to keep a local alive
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy = nullptr, ev_cache = nullptr;
+    void *pin = nullptr; size_t pin_cap = 0;
+    int pin_ensure(size_t bytes)
+    {
+        if (bytes <= pin_cap) return BTBA_OK;
+        if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
+        const size_t want = bytes + bytes / 2 + 4096;
+        hipError_t e = hipHostMalloc(&pin, want, hipHostMallocDefault);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; pin = nullptr; return e == hipErrorOutOfMemory ? BTBA_ENOMEM : BTBA_EHIP; }
+        pin_cap = want;
+        return BTBA_OK;
+    }
+    struct PendingSlot { int slot; uint64_t key; const float *depth, *normal; };
+    std::vector<PendingSlot> pool_pending;                  // frames cached by the call in flight: committed (live, n_valid) once their counts have come back
 
     // persistent frame cache (btba_optimize_frames_keyed): compact (z, n) frames, their valid-pixel lists and counts
     // live in pool slots that survive across calls; a keyframe is cached once, not once per BA call.
@@ -279,6 +296,10 @@ void btba_workspace_destroy(btba_workspace *ws)
     if (ws->corr_stage) (void)hipHostFree(ws->corr_stage);
     if (ws->chain_error) (void)hipHostFree(ws->chain_error);
     for (auto st : ws->aux_streams) if (st) (void)hipStreamDestroy(st);
+    if (ws->copy_stream) (void)hipStreamDestroy(ws->copy_stream);
+    if (ws->ev_copy) (void)hipEventDestroy(ws->ev_copy);
+    if (ws->ev_cache) (void)hipEventDestroy(ws->ev_cache);
+    if (ws->pin) (void)hipHostFree(ws->pin);
     if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
     for (auto e : ws->ev_join) if (e) (void)hipEventDestroy(e);
     if (ws->ev_order) (void)hipEventDestroy(ws->ev_order);
@@ -1289,7 +1310,10 @@ int btba_build_cache(btba_workspace *ws, int n_frames, int H, int W, const float
 }
 
 static int pool_resolve(btba_workspace *ws, int N, int H, int W, int Hd, int Wd, const float *K, float downscale, const uint64_t *keys,
-                        const float *const *depth_dev, const float *const *normal_dev, std::vector<int32_t> &nv_out, int *n_built);
+                        const float *const *depth_dev, const float *const *normal_dev, std::vector<int> &slot_of, int *n_built, const int32_t **nv_pinned);
+static void pool_commit(btba_workspace *ws, int N, const std::vector<int> &slot_of, const int32_t *nv_pinned, std::vector<int32_t> &nv_out);
+static int enqueue_frame_cache(btba_workspace *ws, int M, int H, int W, int Hd, int Wd, const float *const *ptrs_dev, const int *slots_dev,
+                               float4 *zn, int32_t *nvalid, uint32_t *lists, int *counts, float2 *ranges);
 
 static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params_in, int n_frames, int H, int W, const float *K,
                          const btba_entryj *corres_host, uint32_t n_corres, const int *n_match_per_pair,
@@ -1306,7 +1330,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     int rc = BTBA_OK;
     if (!ws) { if ((rc = btba_workspace_create_on_stream(&ws, nullptr))) return rc; }       // the reference's stream: the legacy NULL stream
     // an error return may leave asynchronous copies out of this function's locals (offsets, poses, descriptors) in flight: drain them
-    auto finish = [&](int code) { if (code != BTBA_OK && ws_in) (void)hipStreamSynchronize(ws->stream); if (!ws_in) btba_workspace_destroy(ws); return code; };
+    auto finish = [&](int code) { if (code != BTBA_OK && ws_in) { if (ws->copy_stream) (void)hipStreamSynchronize(ws->copy_stream); (void)hipStreamSynchronize(ws->stream); } if (!ws_in) btba_workspace_destroy(ws); return code; };
     for (auto &ep : ws->events) { ws->event_pool.push_back(ep.a); ws->event_pool.push_back(ep.b); }
     ws->events.clear();
 
@@ -1352,7 +1376,6 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     auto longest_segment = [&]() { uint32_t m = 0; for (int p = 0; p < P; p++) m = std::max(m, offsets[p + 1] - offsets[p]); return m; };
     max_per_pair = longest_segment();
 
-    const auto tu0 = std::chrono::steady_clock::now();
     if ((rc = ws->corr.ensure(sizeof(btba_entryj) * (size_t)(kept ? kept : 1)))) return finish(rc);
     if ((rc = ws->offsets.ensure(sizeof(uint32_t) * (P + 1)))) return finish(rc);
     if ((rc = ws->poses.ensure(sizeof(float) * (16 * (size_t)N + 1)))) return finish(rc);      // + the order flag
@@ -1381,6 +1404,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     std::vector<std::pair<std::pair<uint64_t, uint64_t>, btba_workspace::CorrSeg>> fresh_index;
     size_t fresh_entries = 0;
     bool corr_in_pool = false;
+    hipStream_t up_st = ws->stream;                             // the stream upload_inputs enqueues its copies on
     auto upload_inputs = [&]() -> hipError_t {
         hipError_t r;
         corr_in_pool = false;
@@ -1444,22 +1468,72 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
             offs_up[P] = 0;
             fresh_entries = staged;
             if (staged) {
-                if ((r = hipMemcpyAsync(ws->corr_stage_dev.p, ws->corr_stage, sizeof(btba_entryj) * staged, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+                if ((r = hipMemcpyAsync(ws->corr_stage_dev.p, ws->corr_stage, sizeof(btba_entryj) * staged, hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
                 if (ws->corr_desc.ensure(sizeof(uint32_t) * desc.size()) != BTBA_OK) return hipErrorOutOfMemory;
-                if ((r = hipMemcpyAsync(ws->corr_desc.p, desc.data(), sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+                if ((r = hipMemcpyAsync(ws->corr_desc.p, desc.data(), sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
             }
             if (ws->corr_lens.ensure(sizeof(uint32_t) * (size_t)P) != BTBA_OK) return hipErrorOutOfMemory;
-            if ((r = hipMemcpyAsync(ws->corr_lens.p, lens.data(), sizeof(uint32_t) * (size_t)P, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+            if ((r = hipMemcpyAsync(ws->corr_lens.p, lens.data(), sizeof(uint32_t) * (size_t)P, hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
             corr_in_pool = true;
             stage_longest_fresh = longest_fresh;
-        } else if (kept && (r = hipMemcpyAsync(ws->corr.p, upload, sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+        } else if (kept && (r = hipMemcpyAsync(ws->corr.p, upload, sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
         offsets_up.swap(offs_up);
-        if ((r = hipMemcpyAsync(ws->offsets.p, offsets_up.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return r;
+        if ((r = hipMemcpyAsync(ws->offsets.p, offsets_up.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
         std::memcpy(stage.data(), poses, sizeof(float) * 16 * N);
         stage[16 * (size_t)N] = 0.0f;
-        return hipMemcpyAsync(ws->poses.p, stage.data(), sizeof(float) * stage.size(), hipMemcpyHostToDevice, ws->stream);
+        return hipMemcpyAsync(ws->poses.p, stage.data(), sizeof(float) * stage.size(), hipMemcpyHostToDevice, up_st);
     };
+    // ---- round 6: frame cache FIRST, on the workspace's stream; the EntryJ / pose upload meanwhile on a stream of its own (a pageable hipMemcpyAsync blocks
+    // the host for the copy's ~0.13 ms at c3: the cache kernel runs under it); `stream` waits for the upload's event before anything reads the correspondences
+    float intr[4];
+    const bool compact = !(prm.flags & BTBA_FLAG_FLOAT4_CACHE);        // compact (z, n) cache: identical results, half the bytes
+    const bool keyed = frame_keys != nullptr;
+    if (keyed && (!compact || !ws_in)) return finish(BTBA_EINVAL);     // the persistent cache lives in a caller-owned workspace
+    if (!ws->copy_stream) {
+        if ((e = hipStreamCreateWithFlags(&ws->copy_stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e);
+        if ((e = hipEventCreateWithFlags(&ws->ev_copy, hipEventDisableTiming)) != hipSuccess) return hip_fail(e);
+        if ((e = hipEventCreateWithFlags(&ws->ev_cache, hipEventDisableTiming)) != hipSuccess) return hip_fail(e);
+    }
+    std::vector<int32_t> nv_host;                               // valid pixels per frame of the window (known to the host once ev_cache has passed)
+    std::vector<int> slot_of;
+    const int32_t *nv_pinned = nullptr;
+    int n_built = N;
+    bool have_aux = false;                                      // stateless compact path: lists / counts / block ranges built with the cache (one launch)
+    if (keyed) {
+        Mat4 Kinv_unused;
+        scaled_intrinsics(H, W, Hd, Wd, K, intr, &Kinv_unused);
+        rc = pool_resolve(ws, N, H, W, Hd, Wd, K, prm.image_downscale, frame_keys, depth_dev, normal_dev, slot_of, &n_built, &nv_pinned);
+    } else if (compact) {
+        Mat4 Kinv_unused;
+        scaled_intrinsics(H, W, Hd, Wd, K, intr, &Kinv_unused);
+        const size_t off_nv = (sizeof(void *) * 2 * (size_t)N + 15) & ~(size_t)15;
+        if ((rc = ws->pin_ensure(off_nv + sizeof(int32_t) * (size_t)N))) return finish(rc);
+        if ((rc = ws->ptrs.ensure(off_nv))) return finish(rc);
+        if ((rc = ws->valid_lists.ensure(sizeof(uint32_t) * (size_t)N * npix))) return finish(rc);
+        if ((rc = ws->valid_counts.ensure(sizeof(int) * (size_t)N))) return finish(rc);
+        if ((rc = ws->block_ranges.ensure(sizeof(float2) * (size_t)N * ((Wd / 8) * (Hd / 8) + 1)))) return finish(rc);
+        auto **pp = reinterpret_cast<const float **>(ws->pin);
+        for (int k = 0; k < N; k++) {
+            if (!depth_dev[k] || !normal_dev[k]) return finish(BTBA_EINVAL);
+            pp[k] = depth_dev[k]; pp[N + k] = normal_dev[k];
+        }
+        if ((e = hipMemcpyAsync(ws->ptrs.p, ws->pin, sizeof(void *) * 2 * (size_t)N, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
+        rc = enqueue_frame_cache(ws, N, H, W, Hd, Wd, ws->ptrs.as<const float *>(), nullptr, ws->campos.as<float4>(), ws->nvalid.as<int32_t>(),
+                                 ws->valid_lists.as<uint32_t>(), ws->valid_counts.as<int>(), ws->block_ranges.as<float2>());
+        if (!rc) {
+            nv_pinned = reinterpret_cast<const int32_t *>(static_cast<unsigned char *>(ws->pin) + off_nv);
+            if ((e = hipMemcpyAsync(static_cast<unsigned char *>(ws->pin) + off_nv, ws->nvalid.p, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) return hip_fail(e);
+            have_aux = true;
+        }
+    } else rc = btba_build_cache(ws, N, H, W, K, prm.image_downscale, depth_dev, normal_dev, ws->campos.as<float>(), ws->normals.as<float>(), ws->nvalid.as<int32_t>(), intr);
+    if (rc) return finish(rc);
+    if ((e = hipEventRecord(ws->ev_cache, ws->stream)) != hipSuccess) return hip_fail(e);
+
+    const auto tu0 = std::chrono::steady_clock::now();
+    up_st = ws->copy_stream;
     if ((e = upload_inputs()) != hipSuccess) return hip_fail(e);
+    if ((e = hipEventRecord(ws->ev_copy, ws->copy_stream)) != hipSuccess) return hip_fail(e);
+    if ((e = hipStreamWaitEvent(ws->stream, ws->ev_copy, 0)) != hipSuccess) return hip_fail(e);
     auto pack_fresh = [&]() -> hipError_t {                     // after upload_inputs: fresh segments staging -> pool (24 B), order check into the flag word
         if (!corr_in_pool) return hipSuccess;
         if (fresh_entries)
@@ -1474,23 +1548,14 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     };
     if ((e = pack_fresh()) != hipSuccess) return hip_fail(e);
     // the sources (caller's arrays, `offsets`, `scattered`, `stage`) outlive the synchronising end of this call; the sync only serves the upload timer
-    if ((prm.flags & BTBA_FLAG_TIME_KERNELS) && (e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
+    if ((prm.flags & BTBA_FLAG_TIME_KERNELS) && (e = hipStreamSynchronize(ws->copy_stream)) != hipSuccess) return hip_fail(e);
     const auto tu1 = std::chrono::steady_clock::now();
-
-    float intr[4];
-    const bool compact = !(prm.flags & BTBA_FLAG_FLOAT4_CACHE);        // compact (z, n) cache: identical results, half the bytes
-    const bool keyed = frame_keys != nullptr;
-    if (keyed && (!compact || !ws_in)) return finish(BTBA_EINVAL);     // the persistent cache lives in a caller-owned workspace
-    std::vector<int32_t> nv_keyed;
-    int n_built = N;
-    if (keyed) {
-        Mat4 Kinv_unused;
-        scaled_intrinsics(H, W, Hd, Wd, K, intr, &Kinv_unused);
-        rc = pool_resolve(ws, N, H, W, Hd, Wd, K, prm.image_downscale, frame_keys, depth_dev, normal_dev, nv_keyed, &n_built);
+    // the cache launch and the copy of its valid counts were enqueued before the upload started: long done
+    if (nv_pinned) {
+        if ((e = hipEventSynchronize(ws->ev_cache)) != hipSuccess) return hip_fail(e);
+        if (keyed) pool_commit(ws, N, slot_of, nv_pinned, nv_host);
+        else nv_host.assign(nv_pinned, nv_pinned + N);
     }
-    else if (compact) rc = btba_build_cache_zn(ws, N, H, W, K, prm.image_downscale, depth_dev, normal_dev, ws->campos.as<float>(), ws->nvalid.as<int32_t>(), intr);
-    else rc = btba_build_cache(ws, N, H, W, K, prm.image_downscale, depth_dev, normal_dev, ws->campos.as<float>(), ws->normals.as<float>(), ws->nvalid.as<int32_t>(), intr);
-    if (rc) return finish(rc);
 
     std::vector<int32_t> pairs;
     const int32_t *pairs_ptr = nullptr;
@@ -1499,7 +1564,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
         pairs_ptr = dense_pairs; n_pairs_dense = n_dense_pairs;
     } else if (prm.pair_policy == BTBA_PAIRS_TARGET_MORE_VALID) {
         std::vector<int32_t> nv(N);
-        if (keyed) nv = nv_keyed;
+        if (!nv_host.empty()) nv = nv_host;
         else {
             if ((e = hipMemcpyAsync(nv.data(), ws->nvalid.p, sizeof(int32_t) * N, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) return hip_fail(e);
             if ((e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
@@ -1521,11 +1586,12 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     if (compact) {
         Z.zn = keyed ? ws->pool_zn.as<float>() : ws->campos.as<float>(); Z.H = H; Z.W = W; Z.K = K;
         if (keyed) { Z.frame_slot = ws->pool_map.as<int>(); Z.lists = ws->pool_lists.as<uint32_t>(); Z.counts = ws->pool_counts.as<int>(); if (Wd % 8 == 0 && Hd % 8 == 0) Z.block_ranges = ws->pool_ranges.as<float>(); }
+        else if (have_aux) { Z.lists = ws->valid_lists.as<uint32_t>(); Z.counts = ws->valid_counts.as<int>(); if (Wd % 8 == 0 && Hd % 8 == 0) Z.block_ranges = ws->block_ranges.as<float>(); }
         if (!(prm.flags & (BTBA_FLAG_COMPACTION | BTBA_FLAG_NO_COMPACTION))) {
             // a tracker's frames are masked to the object: walk valid-pixel lists when under 60 % of the pixels carry a depth.
             // (the cache builder counted them; this call is synchronous anyway, so the 4*N-byte read-back costs nothing extra)
             std::vector<int32_t> nv(N);
-            if (keyed) nv = nv_keyed;
+            if (!nv_host.empty()) nv = nv_host;
             else {
                 if ((e = hipMemcpyAsync(nv.data(), ws->nvalid.p, sizeof(int32_t) * N, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) return hip_fail(e);
                 if ((e = hipStreamSynchronize(ws->stream)) != hipSuccess) return hip_fail(e);
@@ -1560,6 +1626,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
             if ((rc = bucket_on_host())) { ws->always_time_region = false; return finish(rc); }
             max_per_pair = longest_segment();
             if ((rc = ws->corr.ensure(sizeof(btba_entryj) * (size_t)(kept ? kept : 1)))) { ws->always_time_region = false; return finish(rc); }
+            up_st = ws->stream;
             if ((e = upload_inputs()) != hipSuccess || (e = pack_fresh()) != hipSuccess) { ws->always_time_region = false; return hip_fail(e); }
             rc = solve_and_read();
         }
@@ -1625,8 +1692,38 @@ int btba_frame_cache_evict(btba_workspace *ws, uint64_t frame_key)
 // yet (same key AND same device buffers) -- in a tracker that is the one new frame, the keyframes were cached by
 // earlier calls (the reference re-caches all K frames on every call, LossGPU.cu:74-78).  Least-recently-used slots
 // are recycled.  Leaves the slot map on the device (ws->pool_map) and the per-frame valid counts in nv_out.
+// The frame cache of M frames in ONE launch where k_frame_cache_fused covers the cache size (<= 32 768 cached pixels: compact cache, valid-pixel lists, counts and -- for
+// widths / heights that are multiples of 8 -- the per-block depth ranges), the three kernels of rounds 1-5 otherwise.  ptrs_dev: [M depth pointers][M normal pointers],
+// slots_dev: destination slot per frame or NULL (frame f -> slot f).  Enqueue only.
+static int enqueue_frame_cache(btba_workspace *ws, int M, int H, int W, int Hd, int Wd, const float *const *ptrs_dev, const int *slots_dev,
+                               float4 *zn, int32_t *nvalid, uint32_t *lists, int *counts, float2 *ranges)
+{
+    const int npix = Hd * Wd;
+    const bool blocks8 = (Wd % 8 == 0 && Hd % 8 == 0);
+    const int seg = (((npix + 15) / 16) + 63) & ~63;
+    int rc;
+    size_t tslot;
+    if ((rc = time_begin(ws, true, 4, &tslot))) return rc;
+    if (seg / 64 <= kListTrips) {
+        k_frame_cache_fused<<<M, 1024, 0, ws->stream>>>(W, H, Wd, Hd, ptrs_dev, ptrs_dev + M, zn, nvalid, slots_dev, lists, counts, blocks8 ? ranges : nullptr);
+    } else {
+        if (slots_dev) return BTBA_EINVAL;       // (the pool path sizes its slots for the fused kernel's range; pool_resolve falls back before it gets here)
+        HIP_TRY(hipMemsetAsync(nvalid, 0, sizeof(int32_t) * (size_t)M, ws->stream));
+        k_build_cache_zn<<<dim3((npix + kBlock - 1) / kBlock, M), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, ptrs_dev, ptrs_dev + M, zn, nvalid, nullptr);
+        k_valid_lists<<<M, 1024, 0, ws->stream>>>(npix, zn, lists, counts, nullptr);
+        if (blocks8) k_block_ranges<<<dim3((unsigned)(((Wd / 8) * (Hd / 8) + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)M), kBlock, 0, ws->stream>>>(Wd, Hd, zn, nullptr, ranges);
+    }
+    if ((rc = time_end(ws, tslot))) return rc;
+    HIP_TRY(hipGetLastError());
+    return BTBA_OK;
+}
+
+// Round 6: ENQUEUE ONLY -- no host synchronisation (rounds 3-5 synchronised twice in here, to keep two locals alive, and launched three kernels for the one new frame
+// of a tracker's call: the keyed path lost to re-caching all fifteen frames, profiles/r05/boundary_timing.jsonl).  Everything the device reads from the host goes through
+// the workspace's pinned block; the new frames' valid counts come back into it behind the launch; pool_commit() -- called once the caller has waited for that copy --
+// marks the new slots live.  pin layout: [2 M pointers][M slots][N slot map][cap counts].
 static int pool_resolve(btba_workspace *ws, int N, int H, int W, int Hd, int Wd, const float *K, float downscale, const uint64_t *keys,
-                        const float *const *depth_dev, const float *const *normal_dev, std::vector<int32_t> &nv_out, int *n_built)
+                        const float *const *depth_dev, const float *const *normal_dev, std::vector<int> &slot_of, int *n_built, const int32_t **nv_pinned)
 {
     const int npix = Hd * Wd;
     int rc;
@@ -1644,8 +1741,9 @@ static int pool_resolve(btba_workspace *ws, int N, int H, int W, int Hd, int Wd,
         ws->pool_H = H; ws->pool_W = W; ws->pool_npix = npix; ws->pool_downscale = downscale;
         std::memcpy(ws->pool_K, K, sizeof ws->pool_K);
     }
+    ws->pool_pending.clear();
     const size_t cap = ws->pool_slots.size();
-    std::vector<int> slot_of(N, -1);
+    slot_of.assign(N, -1);
     std::vector<char> taken(cap, 0);
     for (int k = 0; k < N; k++) {
         if (!depth_dev[k] || !normal_dev[k]) return BTBA_EINVAL;
@@ -1666,6 +1764,7 @@ static int pool_resolve(btba_workspace *ws, int N, int H, int W, int Hd, int Wd,
         }
         if (best == cap) return BTBA_ENOMEM;       // cannot happen: cap >= 2N
         slot_of[k] = (int)best; taken[best] = 1;
+        ws->pool_slots[best].live = false;         // (being overwritten: live again at the commit)
         miss.push_back(k);
         ws->pool_misses++;
     }
@@ -1673,40 +1772,53 @@ static int pool_resolve(btba_workspace *ws, int N, int H, int W, int Hd, int Wd,
     for (int k = 0; k < N; k++) ws->pool_slots[slot_of[k]].stamp = ws->pool_stamp;
     *n_built = (int)miss.size();
     const int M = (int)miss.size();
+    const size_t off_slots = sizeof(void *) * 2 * (size_t)M, off_map = off_slots + sizeof(int32_t) * (size_t)M, off_nv = (off_map + sizeof(int32_t) * (size_t)N + 15) & ~(size_t)15;
+    if ((rc = ws->pin_ensure(off_nv + sizeof(int32_t) * cap))) return rc;
+    unsigned char *pin = static_cast<unsigned char *>(ws->pin);
+    int32_t *pin_map = reinterpret_cast<int32_t *>(pin + off_map);
+    for (int k = 0; k < N; k++) pin_map[k] = slot_of[k];
+    *nv_pinned = reinterpret_cast<const int32_t *>(pin + off_nv);
     if (M > 0) {
-        // staging: [M depth pointers][M normal pointers][M int32 destination slots]
-        const size_t bytes = sizeof(void *) * 2 * (size_t)M + sizeof(int32_t) * (size_t)M;
-        if ((rc = ws->ptrs.ensure(bytes))) return rc;
-        std::vector<unsigned char> stage(bytes);
-        auto **pp = reinterpret_cast<const float **>(stage.data());
-        auto *ps = reinterpret_cast<int32_t *>(stage.data() + sizeof(void *) * 2 * (size_t)M);
+        if ((rc = ws->ptrs.ensure(off_map))) return rc;
+        auto **pp = reinterpret_cast<const float **>(pin);
+        auto *ps = reinterpret_cast<int32_t *>(pin + off_slots);
         for (int m = 0; m < M; m++) { pp[m] = depth_dev[miss[m]]; pp[M + m] = normal_dev[miss[m]]; ps[m] = slot_of[miss[m]]; }
-        HIP_TRY(hipMemcpyAsync(ws->ptrs.p, stage.data(), bytes, hipMemcpyHostToDevice, ws->stream));
-        for (int m = 0; m < M; m++) HIP_TRY(hipMemsetAsync(ws->pool_nvalid.as<int32_t>() + ps[m], 0, sizeof(int32_t), ws->stream));
-        const int *slots_dev = reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(ws->ptrs.p) + sizeof(void *) * 2 * (size_t)M);
-        size_t tslot;
-        if ((rc = time_begin(ws, true, 4, &tslot))) return rc;
-        k_build_cache_zn<<<dim3((npix + kBlock - 1) / kBlock, M), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, ws->ptrs.as<const float *>(), ws->ptrs.as<const float *>() + M,
-                                                                                        ws->pool_zn.as<float4>(), ws->pool_nvalid.as<int32_t>(), slots_dev);
-        k_valid_lists<<<M, 1024, 0, ws->stream>>>(npix, ws->pool_zn.as<const float4>(), ws->pool_lists.as<uint32_t>(), ws->pool_counts.as<int>(), slots_dev);
-        if (Wd % 8 == 0 && Hd % 8 == 0)          // the block walk's dead-block test: depth range of every 8 x 8 block of the new frames
-            k_block_ranges<<<dim3((unsigned)(((Wd / 8) * (Hd / 8) + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)M), kBlock, 0, ws->stream>>>(Wd, Hd, ws->pool_zn.as<const float4>(), slots_dev, ws->pool_ranges.as<float2>());
-        if ((rc = time_end(ws, tslot))) return rc;
-        HIP_TRY(hipGetLastError());
-        std::vector<int32_t> nvh(cap);
-        HIP_TRY(hipMemcpyAsync(nvh.data(), ws->pool_nvalid.p, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, ws->stream));
-        HIP_TRY(hipStreamSynchronize(ws->stream));          // also keeps `stage` alive until the copy has landed
-        for (int m = 0; m < M; m++) {
-            auto &sl = ws->pool_slots[ps[m]];
-            sl.live = true; sl.key = keys[miss[m]]; sl.depth = depth_dev[miss[m]]; sl.normal = normal_dev[miss[m]]; sl.n_valid = nvh[ps[m]];
+        HIP_TRY(hipMemcpyAsync(ws->ptrs.p, pin, off_map, hipMemcpyHostToDevice, ws->stream));
+        const int *slots_dev = reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(ws->ptrs.p) + off_slots);
+        const int seg = (((npix + 15) / 16) + 63) & ~63;
+        if (seg / 64 <= kListTrips) {
+            if ((rc = enqueue_frame_cache(ws, M, H, W, Hd, Wd, ws->ptrs.as<const float *>(), slots_dev, ws->pool_zn.as<float4>(), ws->pool_nvalid.as<int32_t>(),
+                                          ws->pool_lists.as<uint32_t>(), ws->pool_counts.as<int>(), ws->pool_ranges.as<float2>()))) return rc;
+        } else {      // large caches: the three kernels, with the slot indirection
+            for (int m = 0; m < M; m++) HIP_TRY(hipMemsetAsync(ws->pool_nvalid.as<int32_t>() + ps[m], 0, sizeof(int32_t), ws->stream));
+            size_t tslot;
+            if ((rc = time_begin(ws, true, 4, &tslot))) return rc;
+            k_build_cache_zn<<<dim3((npix + kBlock - 1) / kBlock, M), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, ws->ptrs.as<const float *>(), ws->ptrs.as<const float *>() + M,
+                                                                                            ws->pool_zn.as<float4>(), ws->pool_nvalid.as<int32_t>(), slots_dev);
+            k_valid_lists<<<M, 1024, 0, ws->stream>>>(npix, ws->pool_zn.as<const float4>(), ws->pool_lists.as<uint32_t>(), ws->pool_counts.as<int>(), slots_dev);
+            if (Wd % 8 == 0 && Hd % 8 == 0)
+                k_block_ranges<<<dim3((unsigned)(((Wd / 8) * (Hd / 8) + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)M), kBlock, 0, ws->stream>>>(Wd, Hd, ws->pool_zn.as<const float4>(), slots_dev, ws->pool_ranges.as<float2>());
+            if ((rc = time_end(ws, tslot))) return rc;
+            HIP_TRY(hipGetLastError());
         }
+        HIP_TRY(hipMemcpyAsync(pin + off_nv, ws->pool_nvalid.p, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, ws->stream));
+        for (int m = 0; m < M; m++) ws->pool_pending.push_back({ ps[m], keys[miss[m]], depth_dev[miss[m]], normal_dev[miss[m]] });
     }
+    if ((rc = ws->pool_map.ensure(sizeof(int) * (size_t)N))) return rc;
+    HIP_TRY(hipMemcpyAsync(ws->pool_map.p, pin_map, sizeof(int) * (size_t)N, hipMemcpyHostToDevice, ws->stream));
+    return BTBA_OK;
+}
+
+// After the caller has waited for the counts (ws->ev_cache): the frames cached by this call become live pool entries; nv_out = the window's valid counts.
+static void pool_commit(btba_workspace *ws, int N, const std::vector<int> &slot_of, const int32_t *nv_pinned, std::vector<int32_t> &nv_out)
+{
+    for (const auto &pe : ws->pool_pending) {
+        auto &sl = ws->pool_slots[pe.slot];
+        sl.live = true; sl.key = pe.key; sl.depth = pe.depth; sl.normal = pe.normal; sl.n_valid = nv_pinned[pe.slot];
+    }
+    ws->pool_pending.clear();
     nv_out.resize(N);
     for (int k = 0; k < N; k++) nv_out[k] = ws->pool_slots[slot_of[k]].n_valid;
-    if ((rc = ws->pool_map.ensure(sizeof(int) * (size_t)N))) return rc;
-    HIP_TRY(hipMemcpyAsync(ws->pool_map.p, slot_of.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice, ws->stream));
-    HIP_TRY(hipStreamSynchronize(ws->stream));              // slot_of is a local
-    return BTBA_OK;
 }
 
 int btba_matrices_to_poses(btba_workspace *ws, int n, const float *T_dev, float *x_dev)

@@ -868,6 +868,87 @@ __global__ void __launch_bounds__(1024) k_valid_lists(int npix, const float4 *__
     if (threadIdx.x == 0) counts[f] = total;
 }
 
+// Round 6: the WHOLE frame cache of a frame in ONE launch -- compact cache (k_build_cache_zn), ordered valid-pixel list and count (k_valid_lists) and the
+// per-block depth ranges (k_block_ranges).  One workgroup of 16 waves per frame.  A tracker caches ONE new frame per call: as three launches that cost
+// 21 us of device time against 14 us for fifteen frames in one k_build_cache_zn launch (profiles/r05/boundary_timing.jsonl: the keyed path was SLOWER
+// than re-caching everything).  Wave w builds the contiguous pixel segment the list phase of k_valid_lists gives it, so the validity ballots of the build
+// ARE the list's ballots and the frame is not read again; the block ranges read the finished cache back after a barrier (same compute unit, same L1).
+// Same arithmetic per pixel as k_build_cache_zn (contraction off), same list order, same ranges: the three kernels stay for caches this one does not cover
+// (more than 32 768 cached pixels, width or height not a multiple of 8).
+__global__ void __launch_bounds__(1024) k_frame_cache_fused(int W, int H, int Wd, int Hd, const float *const *__restrict__ depth, const float *const *__restrict__ normals,
+                                                           float4 *zn_out, int *__restrict__ n_valid, const int *__restrict__ out_slot,
+                                                           uint32_t *__restrict__ lists, int *__restrict__ counts, float2 *__restrict__ ranges)
+{
+#pragma clang fp contract(off)
+    __shared__ int wave_tot[16];
+    const int f = blockIdx.x;
+    const int fo = out_slot ? out_slot[f] : f;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int npix = Wd * Hd;
+    float4 *z = zn_out + (size_t)fo * npix;
+    const float *dp = depth[f];
+    const float4 *np4 = reinterpret_cast<const float4 *>(normals[f]);
+    const float scaleW = (float)(W - 1) / (float)(Wd - 1);
+    const float scaleH = (float)(H - 1) / (float)(Hd - 1);
+    const int seg = (((npix + 15) / 16) + 63) & ~63, trips = seg / 64;      // <= kListTrips (the host checks)
+    const int s_wave = wave * seg;
+    unsigned long long m[kListTrips];
+#pragma unroll
+    for (int k0 = 0; k0 < kListTrips; k0 += 8) {
+        float dd[8]; float4 nn[8]; bool in[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k0 + u, o = s_wave + k * 64 + lane;
+            in[u] = false; dd[u] = 0.0f; nn[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < trips && o < npix) {
+                const int x = o % Wd, y = o / Wd;
+                const unsigned xi = (unsigned)(x * scaleW + 0.5f);
+                const unsigned yi = (unsigned)(y * scaleH + 0.5f);
+                if (xi < (unsigned)W && yi < (unsigned)H) {
+                    const size_t s = (size_t)yi * W + xi;
+                    in[u] = true; dd[u] = dp[s]; nn[u] = np4[s];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k0 + u, o = s_wave + k * 64 + lane;
+            const bool valid = in[u] && ((double)dd[u] >= 0.1);
+            if (in[u]) z[o] = make_float4(valid ? dd[u] : 0.0f, nn[u].x, nn[u].y, nn[u].z);
+            m[k] = __builtin_amdgcn_ballot_w64(valid);
+        }
+    }
+    int cnt = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kListTrips; k++) cnt += __popcll(m[k]);
+    if (lane == 0) wave_tot[wave] = cnt;
+    __syncthreads();                      // (also: every wave's part of the cache is written and visible to the workgroup)
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const int t = wave_tot[w]; if (w < wave) base += t; total += t; }
+    uint32_t *out = lists + (size_t)fo * npix;
+#pragma unroll
+    for (int k = 0; k < kListTrips; k++) {
+        const unsigned long long b = m[k];
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0));
+        if ((b >> lane) & 1ull) out[base + before] = (uint32_t)(s_wave + k * 64 + lane);
+        base += __popcll(b);
+    }
+    if (threadIdx.x == 0) { counts[fo] = total; if (n_valid) n_valid[fo] = total; }
+    if (ranges) {
+        const int bw = Wd >> 3, nblk = bw * (Hd >> 3);
+        for (int blk = wave; blk < nblk; blk += 16) {
+            const int by = blk / bw, bx = blk - by * bw;
+            const float d = z[(size_t)((by * 8 + (lane >> 3)) * Wd + bx * 8 + (lane & 7))].x;
+            const bool ok = d > 0.0f;
+            float lo = ok ? d : INFINITY, hi = ok ? d : -INFINITY;
+#pragma unroll
+            for (int q = 32; q >= 1; q >>= 1) { lo = fminf(lo, __shfl_xor(lo, q)); hi = fmaxf(hi, __shfl_xor(hi, q)); }
+            if (lane == 0) ranges[(size_t)fo * nblk + blk] = make_float2(lo, hi);
+        }
+    }
+}
+
 // The same sweep on the compact cache: ONE 16-byte load per source pixel and per tap (5 loads instead of 10),
 // camera-space points re-derived from z with the cache builder's exact arithmetic (zn_backproject).
 template <bool SIMPLE, bool LISTS>
@@ -993,7 +1074,10 @@ __device__ __forceinline__ float4 gather16(const float4 *base, unsigned byte_off
 // compiler cannot fold it and spends a vector add per tap)
 template <int IMM> __device__ __forceinline__ float4 gather16_imm(const char *base, unsigned byte_off) { return *reinterpret_cast<const float4 *>(base + (size_t)byte_off + IMM); }
 #ifndef BTBA_POSE_LDS
-#define BTBA_POSE_LDS 1
+#define BTBA_POSE_LDS 0      // measured, round 6 (profiles/r06/sweep_diet.json): 16 fewer scalar-operand instructions per trip, 4 more broadcast LDS reads: 161 -> 169 us per launch.  Off.
+#endif
+#ifndef BTBA_POSE_VGPR
+#define BTBA_POSE_VGPR 0
 #endif
 #ifndef BTBA_TAP_BASES
 #define BTBA_TAP_BASES 1
@@ -1259,6 +1343,10 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
 #endif
     typedef const volatile __attribute__((address_space(3))) btba_f4v lds_cv4;        // (an explicit LDS pointer: a volatile access through a generic one stays a flat_load)
     lds_cv4 *pose_v = (lds_cv4 *)pose_l;
+#if BTBA_POSE_VGPR
+    btba_f4v pv0 = (btba_f4v){ C.R[0], C.R[1], C.R[2], C.t[0] }, pv1 = (btba_f4v){ C.R[3], C.R[4], C.R[5], C.t[1] }, pv2 = (btba_f4v){ C.R[6], C.R[7], C.R[8], C.t[2] }, pvk = (btba_f4v){ D.fx, D.fy, D.cx, D.cy };
+    asm volatile("" : "+v"(pv0), "+v"(pv1), "+v"(pv2), "+v"(pvk));
+#endif
     const char *tap_row0 = reinterpret_cast<const char *>(zn_t), *tap_row1 = tap_row0 + C.row16;
     const float lut_addr_f = (float)lds_address(lut), ybase4_abs = C.ybase4 + lut_addr_f;
     auto pixel = [&](const float4 &zs, unsigned ox, unsigned oy) {
@@ -1270,13 +1358,21 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const bool src_ok = (__float_as_uint(d) - C.zmin_bits) < C.zrange_bits;
         // transform the point, project
         const float4 ra = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(colA) + ox), rb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(colA) + oy);
-#if BTBA_POSE_LDS
+#if BTBA_POSE_VGPR
+        const btba_f4v P0 = pv0, P1 = pv1, P2 = pv2, PK = pvk;                              // developer experiment: the sixteen operands in VGPRs for the whole loop (needs 5 waves per SIMD: -DBTBA_FUSED_WAVES=5)
+        const float qx = fma_nd(ra.x + rb.x, d, P0.w), qy = fma_nd(ra.y + rb.y, d, P1.w), qz = fma_nd(ra.z + rb.z, d, P2.w);
+        const float rqz = fast_rcp(qz);
+        const float u = __builtin_fmaf(qx * PK.x, rqz, PK.z), v = __builtin_fmaf(qy * PK.y, rqz, PK.w);      // NOT fma_nd: see below
+#elif BTBA_POSE_LDS
         const btba_f4v P0 = pose_v[0], P1 = pose_v[1], P2 = pose_v[2], PK = pose_v[3];      // volatile: re-read every trip, never hoisted into loop-long registers
         // (fma_nd: with every operand in a VGPR the compiler overwrites the addend's register, and such a read-modify-write FMA issues at half rate when its
         // two multiplicands share a register parity -- the allocator's luck; a fresh destination is full rate whatever it gets)
         const float qx = fma_nd(ra.x + rb.x, d, P0.w), qy = fma_nd(ra.y + rb.y, d, P1.w), qz = fma_nd(ra.z + rb.z, d, P2.w);
         const float rqz = fast_rcp(qz);
-        const float u = fma_nd(qx * PK.x, rqz, PK.z), v = fma_nd(qy * PK.y, rqz, PK.w);
+        // (u, v through the compiler's own FMA, not fma_nd: an inline-asm consumer directly behind v_rcp_f32 is invisible to the hazard recognizer, which then
+        // does not insert the wait state gfx950 needs between a transcendental and a VALU use of its result -- round 6's first build of this switch read a
+        // stale reciprocal now and then: non-deterministic poses, 2e-4 off, caught by tests/test_cpp_bundler.py and scripts/r06/determinism.py)
+        const float u = __builtin_fmaf(qx * PK.x, rqz, PK.z), v = __builtin_fmaf(qy * PK.y, rqz, PK.w);
 #else
         const float qx = (ra.x + rb.x) * d + C.t[0], qy = (ra.y + rb.y) * d + C.t[1], qz = (ra.z + rb.z) * d + C.t[2];
         const float rqz = fast_rcp(qz);
@@ -1296,7 +1392,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
 #endif
         // rotate the normal (only the waves that go on need it: half of the block trips end above)
-#if BTBA_POSE_LDS
+#if BTBA_POSE_LDS || BTBA_POSE_VGPR
         const float nqx = fma_nd(P0.z, zs.w, fma_nd(P0.y, zs.z, P0.x * zs.y));
         const float nqy = fma_nd(P1.z, zs.w, fma_nd(P1.y, zs.z, P1.x * zs.y));
         const float nqz = fma_nd(P2.z, zs.w, fma_nd(P2.y, zs.z, P2.x * zs.y));

@@ -71,7 +71,23 @@ def first_decision_divergence(hip_pcg, hip_counts, ora_pcg, ora_counts):
     return None
 
 
-def check_parity_with_decisions(hip_T, ora_T, div, pose_error, tol=1e-4, tol_after_divergence=1e-3, what="", spread_T=None):
+def reference_licence(R, pose_error, campos, normals, intr, corr, poses, variants=None, **solve_kw):
+    """THE LICENCE for an iterate above 1e-4 (round 6): how far is the reference from ITSELF on this window?  Runs the reference's own solver (oracle/_ref) under
+    three other legal execution orders of its float atomics and under the model of its own -use_fast_math build (oracle/reference.py::self_spread) and returns
+    (cum [G] = per iterate the largest pose difference of any of those runs from the forward / IEEE run, cumulative over the iterates so far;
+     runs [V, G, N, 4, 4] = every run's iterates, runs[0] the forward / IEEE one)."""
+    spread, runs = R.self_spread(campos, normals, intr, corr, poses, pose_error, variants=variants, **solve_kw)
+    return np.maximum.accumulate(spread), runs
+
+
+def beyond_reference_spread(hip_T, ref_T, cum_spread, pose_error, tol=1e-4, factor=3.0):
+    """Iterates at which the HIP path is further from the reference's forward / IEEE run than max(tol, factor x the reference's own spread so far)."""
+    G, N = ref_T.shape[0], ref_T.shape[1]
+    err = [max(max(pose_error(hip_T[it, k], ref_T[it, k])) for k in range(N)) for it in range(G)]
+    return [it for it in range(G) if err[it] >= max(tol, factor * cum_spread[it])], err
+
+
+def check_parity_with_decisions(hip_T, ora_T, div, pose_error, tol=1e-4, tol_after_divergence=1e-3, what="", spread_T=None, ref_spread=None):
     """Per-iterate parity rule.  An iterate may leave the 1e-4 bar only if it is EXPLAINED:
       * from the iterate of the first differing accept / guard decision on (a flipped decision is a different -- equally legitimate --
         trajectory of the reference's own discontinuous algorithm), the looser bound applies;
@@ -79,6 +95,8 @@ def check_parity_with_decisions(hip_T, ora_T, div, pose_error, tol=1e-4, tol_aft
         sequential fp32 sums, ora_T with exactly rounded sums): on a window where the reference's arithmetic itself is not determined
         to 1e-4 -- a dense-only two-frame window, say -- round-off alone, amplified by five PCG steps on an ill-conditioned system,
         is that large, and the reference's float atomics land in an arbitrary order.
+    Round 6: where the reference's OWN spread on the window is known (ref_spread [G], cumulative: reference_licence above -- the reference's code under other legal
+    atomic orders and under its own fast-math flags) it REPLACES the oracle's summation spread as the floor: the licence is what the reference does to itself.
     Returns (worst before the divergence, worst after)."""
     G, N = ora_T.shape[0], ora_T.shape[1]
     first = div[0] if div is not None else G
@@ -87,9 +105,12 @@ def check_parity_with_decisions(hip_T, ora_T, div, pose_error, tol=1e-4, tol_aft
         e = max(max(pose_error(hip_T[it, k], ora_T[it, k])) for k in range(N))
         if it < first:
             wb = max(wb, e)
-            floor = 0.0 if spread_T is None else max(max(pose_error(spread_T[it2, k], ora_T[it2, k])) for it2 in range(it + 1) for k in range(N))
+            if ref_spread is not None:
+                floor = float(ref_spread[it])
+            else:
+                floor = 0.0 if spread_T is None else max(max(pose_error(spread_T[it2, k], ora_T[it2, k])) for it2 in range(it + 1) for k in range(N))
             assert e < max(tol, 3.0 * floor), (f"{what}: iterate {it} differs by {e:.2e} although every decision so far was identical "
-                                               f"(first divergence: {div}; the oracle's own summation-order spread up to here: {floor:.2e})")
+                                               f"(first divergence: {div}; the {'reference' if ref_spread is not None else 'oracle'}'s own spread up to here: {floor:.2e})")
         else:
             wa = max(wa, e)
             assert e < tol_after_divergence, f"{what}: iterate {it} differs by {e:.2e} after divergence {div}"

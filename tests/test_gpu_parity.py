@@ -816,6 +816,10 @@ def test_randomised_windows_are_explained(gpu, oracle):
     for rec in fz.run_cases(14, explain_always=True):
         assert rec["finite"], rec
         assert rec["unexplained_iterates"] == [], rec
+        # round 6, the licence: no iterate of the traced solve and not the boundary's own result further from the reference's forward / IEEE run than
+        # max(1e-4, 3 x what the reference's own code does to itself on that window under other atomic orders and its own fast-math flags)
+        if "beyond_reference_spread" in rec:
+            assert rec["beyond_reference_spread"] == [] and not rec["boundary_final_beyond_reference_spread"], rec
         n_tight += max(rec["per_iterate"]) < 1e-4
     assert n_tight >= 7               # the well-posed half of the draw holds the plain 1e-4 bar on every iterate
 

@@ -164,22 +164,21 @@ def test_hip_frame_cache_and_preprocessing_match_the_reference_kernels():
 
 def test_random_windows_match_the_reference_solver(oracle):
     """Forty seeded windows of random shape (2-9 frames, 0-400 matches per pair, masked or 100 %-valid frames, feature and
-    dense weights on or off, perturbations up to 3 deg / 8 mm) through the HIP path and through the reference's own solver.
+    dense weights on or off, perturbations up to 3 deg / 8 mm) through the HIP path and through the reference's own solver, EVERY
+    Gauss-Newton iterate (the reference's iterates recorded by the launch emulator's hook, oracle/ref_solver_wrap.h).
     Well-conditioned windows (>= 150 matches per pair on an object mask, or features alone) are held to the 1e-4 bar.
-    The others -- 100 %-valid frames, the dense term alone, or only 40 matches per pair next to it -- are the windows the
-    reference itself determines only to ~1e-3: the dense term's accept tests (<= 2 cm, >= cos 45 deg, in-image) are
-    discontinuous, one pixel flipping on a last-bit difference moves such a window by ~1e-4 and the next iterations
-    amplify it (tests/tools/dbg_window.py 9 shows it iterate by iterate).  They are held to 5e-3
-    (the worst, a dense-only K=3 window on 100 %-valid frames, sits at 2e-3).
-    That explanation is ASSERTED, not assumed: every window is also run through the oracle with traces, and per iterate the HIP
-    path may leave the 1e-4 bar only from the first accept / epsilon-guard decision it takes differently from the oracle on
-    (helpers.first_decision_divergence), or -- before that -- by no more than 3x the oracle's own summation-order spread on that
-    window (sequential fp32 sums vs exactly rounded sums: what round-off alone does to an ill-conditioned window)."""
-    from helpers import check_parity_with_decisions, first_decision_divergence
+    The others -- 100 %-valid frames, the dense term alone, or only 40 matches per pair next to it -- are windows the reference does
+    not determine to 1e-4 ITSELF, and round 6 measures that instead of asserting it: a window on which the HIP path leaves the bar is
+    run through the reference's own code under three other legal execution orders of its float atomics (SolverBundlingDenseUtil.h:217-285,
+    SolverBundling.cu:575-818) and under a model of its own build flags (-use_fast_math, CMakeLists.txt:7) -- helpers.reference_licence,
+    profiles/r06/reference_self_spread.json -- and the HIP iterate must lie within max(1e-4, 3 x the reference's spread so far).
+    A window above 1e-4 that the reference DOES hold against itself is listed as `beyond`; it must then at least be explained by the older
+    rule (a differing accept / epsilon-guard decision before the excursion, helpers.first_decision_divergence), and there may be at most two."""
+    from helpers import beyond_reference_spread, check_parity_with_decisions, first_decision_divergence, reference_licence
     rng = np.random.default_rng(2024)
     worst_strict = worst_loose = 0.0
-    n_strict = n_identical = 0
-    above, by_roundoff = [], []
+    n_strict = n_held = 0
+    above, licensed, beyond = [], [], []
     n_windows = 40
     for trial in range(n_windows):
         K = int(rng.integers(2, 10))
@@ -190,31 +189,39 @@ def test_random_windows_match_the_reference_solver(oracle):
             wd = 1.0
         pb = S.make_problem(K, m, 5000 + trial, background=bg, full_res=False, perturb_deg=float(rng.uniform(0.5, 3.0)), perturb_m=float(rng.uniform(0.001, 0.008)))
         campos, normals, intr = S.analytic_cache(pb)
-        ref, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, weight_dense=wd)
+        ref, _, ref_T = R.solve(campos, normals, intr, pb.corr, pb.poses_init, weight_dense=wd, want_iterates=True)
         got, tv = hip_solve(pb, wd, want_trace=True)
         assert np.isfinite(got).all()
         err = max(max(S.pose_error(got[k], ref[k])) for k in range(K))
-        ora = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=wd))
-        div = first_decision_divergence(tv.pcg_scalars[0], tv.dense_pair[0][..., 27] if wd > 0 else None, ora.pcg_scalars, ora.dense_count if wd > 0 else None)
-        seq = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=wd, accum_mode=0))
-        wb, _ = check_parity_with_decisions(tv.T_after[0], ora.T_after, div, S.pose_error, 1e-4, 5e-3, f"window {trial} (K={K}, m={m}, bg={bg}, wd={wd})", spread_T=seq.T_after)
-        if wb >= 1e-4:
-            by_roundoff.append((trial, float(f"{wb:.1e}")))
-        n_identical += div is None
+        per_it = [max(max(S.pose_error(tv.T_after[0, it, k], ref_T[it, k])) for k in range(K)) for it in range(ref_T.shape[0])]
         strict = (m >= 150) and (wd == 0.0 or not bg) and K >= 3
         if strict:
             worst_strict = max(worst_strict, err); n_strict += 1
-            assert err < 1e-4, (trial, K, m, bg, wd, err)
+            assert max(per_it) < 1e-4, (trial, K, m, bg, wd, per_it)
         else:
             worst_loose = max(worst_loose, err)
             assert err < 5e-3, (trial, K, m, bg, wd, err)
-            if err >= 1e-4:
-                above.append((trial, K, m, 'full' if bg else 'mask', wd, float(f'{err:.1e}')))
-    print(f"random windows: {n_strict} well-conditioned, worst {worst_strict:.2e}; {n_windows - n_strict} weakly conditioned, worst {worst_loose:.2e}, "
-          f"{len(above)} of them above 1e-4 (trial, K, m, frames, w_dense, err): {above}")
-    print(f"{n_identical} of {n_windows} windows take identical accept / guard decisions in the HIP path and in the oracle at every iterate; "
-          f"above 1e-4 before any differing decision, within 3x the oracle's own summation-order spread: {by_roundoff}")
+        if max(per_it) < 1e-4:
+            n_held += 1
+            continue
+        above.append((trial, K, m, 'full' if bg else 'mask', wd, float(f'{max(per_it):.1e}')))
+        cum, _ = reference_licence(R, S.pose_error, campos, normals, intr, pb.corr, pb.poses_init, weight_dense=wd)
+        bad, _ = beyond_reference_spread(tv.T_after[0], ref_T, cum, S.pose_error)
+        if not bad:
+            licensed.append((trial, float(f"{cum[-1]:.1e}")))
+            continue
+        # the reference holds this window tighter than the HIP path does: the older explanation must apply, and the window is counted
+        beyond.append((trial, K, m, 'full' if bg else 'mask', wd, [float(f"{x:.1e}") for x in per_it], [float(f"{x:.1e}") for x in cum]))
+        ora = oracle.solve(campos, normals, intr, pb.corr, pb.poses_init, params=oracle.default_params(weight_dense_depth=wd))
+        div = first_decision_divergence(tv.pcg_scalars[0], tv.dense_pair[0][..., 27] if wd > 0 else None, ora.pcg_scalars, ora.dense_count if wd > 0 else None)
+        check_parity_with_decisions(tv.T_after[0], ora.T_after, div, S.pose_error, 1e-4, 5e-3, f"window {trial} (K={K}, m={m}, bg={bg}, wd={wd})", ref_spread=cum)
+    print(f"random windows: {n_strict} well-conditioned, worst {worst_strict:.2e}; {n_windows - n_strict} weakly conditioned, worst {worst_loose:.2e}; "
+          f"{n_held} of {n_windows} hold 1e-4 against the reference's own solver on EVERY iterate")
+    print(f"{len(above)} leave the bar (trial, K, m, frames, w_dense, worst iterate): {above}")
+    print(f"of those, {len(licensed)} within 3x the reference's OWN spread (trial, the reference's spread at the last iterate): {licensed}")
+    print(f"beyond the reference's own spread: {len(beyond)}: {beyond}")
     assert len(above) <= n_windows // 4                  # even in the weak class most windows agree to 1e-4
+    assert len(beyond) <= 2, beyond
     assert n_strict >= 6
 
 
@@ -251,19 +258,23 @@ def test_per_iteration_weights_match_the_reference_seam(name, ws, wd):
     assert moved > 2e-4, "the weight schedule must matter for this to test anything"
 
 
-def test_c3_every_gauss_newton_iterate_against_the_reference():
-    """north_star's tolerance is PER Gauss-Newton iterate against the reference.  One instance of the benched batch (c3: K = 15, 2 000 matches per pair,
-    dense + Huber, seed of instance 0): the HIP path's traced iterates T_after[n] against solveBundlingStub (SolverBundling.cu:931-1003, the reference's
-    own code through the CPU launch emulator) stopped after n + 1 iterations, n = 0 ... 6 -- 28 emulated iterations, about a minute.  Closes the chain
-    HIP <-> oracle per iterate (test_gpu_fullsize.py), oracle <-> reference per iterate on small windows, HIP <-> reference final poses only."""
-    K = 15
-    pb = S.make_problem(K, 2000, S.config_seed(5, 0), background=True, full_res=False)
+@pytest.mark.parametrize("name,K,m,wd,seed,bg", [
+    ("c3 benched instance 0", 15, 2000, 1.0, S.config_seed(5, 0), True),
+    ("c3-masked", 15, 2000, 1.0, S.config_seed(3), False),        # the tracker's operating point
+    ("c2", 10, 1000, 0.0, S.config_seed(2), True),
+    ("c4", 30, 4000, 1.0, S.config_seed(4), True),                # K = 30: k_solve_mid; ~40 s of thread-by-thread emulation
+])
+def test_every_gauss_newton_iterate_against_the_reference(name, K, m, wd, seed, bg):
+    """north_star's tolerance is PER Gauss-Newton iterate against the reference.  The HIP path's traced iterates T_after[n] against solveBundlingStub
+    (SolverBundling.cu:931-1003, the reference's own code through the CPU launch emulator), whose unknowns after every iteration are recorded by the emulator's
+    launch hook at the top of the next one (oracle/ref_solver_wrap.h: ref_solve4) -- one emulated solve per configuration (round 5: seven solves stopped after
+    n = 1 ... 7 iterations, c3 only).  BASELINE configs[1], [2] (100 %-valid and object-masked) and [3]."""
+    angles = S.pruned_pool_angles(60, 30, seed) if K == 30 else None
+    pb = S.make_problem(K, m, seed, background=bg, full_res=False, angles=angles)
     campos, normals, intr = S.analytic_cache(pb)
-    _, tv = hip_solve(pb, 1.0, want_trace=True)
-    worst = []
-    for n in range(7):
-        ref, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, n_gn=n + 1, weight_dense=1.0)
-        w = max(max(S.pose_error(tv.T_after[0, n, k], ref[k])) for k in range(K))
-        worst.append(w)
-        assert w < 1e-4, (n, worst)
-    print("c3 instance 0, HIP vs the reference's own solver per Gauss-Newton iterate: " + " ".join(f"{w:.1e}" for w in worst))
+    _, tv = hip_solve(pb, wd, want_trace=True)
+    ref, _, ref_T = R.solve(campos, normals, intr, pb.corr, pb.poses_init, weight_dense=wd, want_iterates=True)
+    assert np.array_equal(ref_T[-1], ref)
+    worst = [max(max(S.pose_error(tv.T_after[0, n, k], ref_T[n, k])) for k in range(K)) for n in range(7)]
+    print(f"{name}, HIP vs the reference's own solver per Gauss-Newton iterate: " + " ".join(f"{w:.1e}" for w in worst))
+    assert max(worst) < 1e-4, worst

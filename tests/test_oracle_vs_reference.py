@@ -338,3 +338,41 @@ def test_random_windows_oracle_vs_reference(oracle):
             assert err < 5e-3, (trial, K, m, bg, wd, err)
     print(f"random windows, oracle vs reference: {n_strict} well-conditioned, worst {worst_strict:.2e}; {40 - n_strict} weakly conditioned, worst {worst_loose:.2e}")
     assert n_strict >= 6
+
+
+def test_the_iterate_record_of_the_emulator_equals_stopping_the_reference_early():
+    """The per-iterate record rests on the emulator's launch hook: iterate n of ONE reference solve must be bit-identical to the reference stopped after
+    n + 1 iterations (round 5's way of obtaining it), and the execution-order switch must leave the forward order's bits alone."""
+    pb = S.make_problem(5, 300, 28, background=False, full_res=False)
+    campos, normals, intr = S.analytic_cache(pb)
+    _, _, ref_T = R.solve(campos, normals, intr, pb.corr, pb.poses_init, want_iterates=True)
+    for n in (0, 3, 6):
+        stopped, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, n_gn=n + 1)
+        assert np.array_equal(stopped, ref_T[n])
+    rev, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, order="reverse")
+    again, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init)
+    assert np.array_equal(again, ref_T[-1]) and not np.array_equal(rev, again)
+
+
+def test_the_reference_against_itself_on_a_well_conditioned_and_on_a_weak_window():
+    """Round 6: the launch emulator's execution-order switch (forward | reverse | seeded shuffle of every launch's (block, thread) cells: each a legal order of
+    kernels that meet only through float atomics) and the `_fm` build (a model of the reference's own -use_fast_math flags, oracle/Makefile) -- the tools that
+    measure how far the reference is from ITSELF (profiles/r06/reference_self_spread.json).  A shuffled run is reproducible for its seed; on a tracker-like window
+    (K = 5, 300 matches per pair, object mask) all eight runs agree to well inside the 1e-4 bar; on a dense-only two-frame window of 100 %-valid frames they do not."""
+    from helpers import reference_licence
+    pb = S.make_problem(5, 300, 28, background=False, full_res=False)
+    campos, normals, intr = S.analytic_cache(pb)
+    a, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, order="shuffle:7")
+    b, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, order="shuffle:7")
+    c, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, order="shuffle:8")
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    fm1, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, fastmath=True, fastmath_seed=1)
+    fm2, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, fastmath=True, fastmath_seed=2)
+    assert not np.array_equal(fm1, fm2)                                   # another seed = another (equally legal) libdevice
+    cum, runs = reference_licence(R, S.pose_error, campos, normals, intr, pb.corr, pb.poses_init)
+    assert runs.shape[:2] == (8, 7) and cum[-1] < 1e-4 and cum[0] > 0.0, cum
+    weak = S.make_problem(2, 0, 5003, background=True, full_res=False, perturb_deg=2.0, perturb_m=0.005)
+    cw, nw, iw = S.analytic_cache(weak)
+    cum_w, _ = reference_licence(R, S.pose_error, cw, nw, iw, weak.corr, weak.poses_init)
+    print(f"reference vs reference, last iterate: tracker-like window {cum[-1]:.2e}, dense-only two-frame window {cum_w[-1]:.2e}")
+    assert cum_w[-1] > cum[-1]

@@ -107,6 +107,16 @@ def test_c1_sliding_window_hip_vs_oracle(oracle, tmp_path):
         c, o, mx = bs.pack_correspondences([corr], N)
         tv = bs.trace_view(bs.solve_zn(zn[None], H, W, K, torch.from_numpy(c.view(np.uint8).reshape(1, -1, 32)).to(dev), torch.from_numpy(o.astype(np.int32)).to(dev), mx,
                                        torch.from_numpy(np.asarray(poses_in, np.float32)[None].copy()).to(dev), trace=True))
+        # round 6, the licence first: is the HIP result within 3x what the REFERENCE'S OWN code does to itself on this call under other legal orders of its float
+        # atomics and under its own fast-math flags?  (helpers.reference_licence; oracle/_ref prebuilt -- skipped where it is absent)
+        from oracle import reference as R
+        if os.path.exists(R.SO_SOLVER) and os.path.exists(R.SO_SOLVER_FM):
+            from helpers import reference_licence
+            cam, nrm = np.stack([c["campos"] for c in caches]), np.stack([c["normals"] for c in caches])
+            cum, runs = reference_licence(R, S.pose_error, cam, nrm, caches[0]["intr"], corr, poses_in)
+            e_ref = max(max(S.pose_error(tv.T_after[0, -1, k], runs[0, -1, k])) for k in range(N))
+            if e_ref < max(1e-4, 3.0 * cum[-1]):
+                return ("reference-spread", {"hip_vs_reference": e_ref, "reference_vs_itself": float(cum[-1])})
         div = first_decision_divergence(tv.pcg_scalars[0], tv.dense_pair[0][..., 27], ora.pcg_scalars, ora.dense_count)
         if div is None:          # no decision differs: is the oracle's own summation-order spread on this call of that size? (round-off on an ill-conditioned window)
             cam, nrm = np.stack([c["campos"] for c in caches]), np.stack([c["normals"] for c in caches])

@@ -62,15 +62,19 @@ def run_cases(n_cases, explain_always=False, only=None, hook=None, prepare=None)
                 # path above 1e-4 is `beyond_reference_spread` unless it is within 3x that spread (cumulative over the iterates so far).
                 hip_ref = [max(max(S.pose_error(tv.T_after[0, it, k], Tref[it, k])) for k in range(K)) for it in range(G)]
                 rec["vs_reference_per_iterate"] = [float(f"{x:.3g}") for x in hip_ref]
-                if max(hip_ref) >= 1e-4:
+                if max(hip_ref) >= 1e-4 or rec["vs_reference_final"] >= 1e-4:
                     sp, runs = R.self_spread(campos, nrm, caches[0]["intr"], corr, pb.poses_init, S.pose_error)
                     cum = np.maximum.accumulate(sp)
                     nearest = [min(max(max(S.pose_error(tv.T_after[0, it, k], runs[v, it, k])) for k in range(K)) for v in range(runs.shape[0])) for it in range(G)]
+                    # the drop-in boundary's result (compact cache, the library's own tile / chunk choice: other sums than the traced batch entry) has a final iterate only
+                    b_near = min(max(max(S.pose_error(poses[k], runs[v, -1, k])) for k in range(K)) for v in range(runs.shape[0]))
                     rec.update({"reference_self_spread": [float(f"{x:.3g}") for x in sp], "hip_to_nearest_reference_run": [float(f"{x:.3g}") for x in nearest],
                                 "beyond_reference_spread": [it for it in range(G) if hip_ref[it] >= max(1e-4, 3.0 * cum[it])],
+                                "boundary_final_beyond_reference_spread": bool(rec["vs_reference_final"] >= max(1e-4, 3.0 * cum[-1])),
+                                "boundary_final_to_nearest_reference_run": float(f"{b_near:.3g}"),
                                 "reference_holds_1e-4_against_itself": bool(sp.max() < 1e-4)})
                 else:
-                    rec.update({"reference_self_spread": None, "beyond_reference_spread": []})
+                    rec.update({"reference_self_spread": None, "beyond_reference_spread": [], "boundary_final_beyond_reference_spread": False})
             if unexplained:
                 # Second opinion before calling an iterate unexplained: the oracle's sequential-sum run (`seq`) is an OpenMP reduction whose order -- and
                 # with it `spread` -- changes with the box's thread count (case 13, an ill-conditioned K = 5 window with 5 matches per pair: 4.6e-5,
@@ -116,13 +120,14 @@ def main():
         worst = max(worst, rec["rot"], rec["trans"])
         recs.append(rec)
         print(json.dumps(rec), flush=True)
-    above_ref = [r for r in recs if r.get("vs_reference_per_iterate") and max(r["vs_reference_per_iterate"]) >= 1e-4]
+    above_ref = [r for r in recs if r.get("reference_self_spread")]      # a traced iterate or the boundary's final pose above 1e-4 against the reference's forward / IEEE run
     summary = {"cases": n_cases, "worst_vs_oracle": worst,
                "final_above_1e-4_vs_oracle": sum(max(r["rot"], r["trans"]) >= 1e-4 for r in recs),
                "final_above_1e-4_vs_reference": sum(r.get("vs_reference_final", 0.0) >= 1e-4 for r in recs),
-               "any_iterate_above_1e-4_vs_reference": len(above_ref),
+               "above_1e-4_vs_reference (a traced iterate or the boundary's final pose)": len(above_ref),
                "of_those_the_reference_cannot_hold_to_1e-4_against_itself": sum(not r["reference_holds_1e-4_against_itself"] for r in above_ref),
                "windows_with_an_iterate_beyond_3x_the_reference_self_spread": [r["case"] for r in above_ref if r["beyond_reference_spread"]],
+               "windows_whose_boundary_result_is_beyond_3x_the_reference_self_spread": [r["case"] for r in above_ref if r["boundary_final_beyond_reference_spread"]],
                "windows_above_1e-4_that_the_reference_itself_holds": [r["case"] for r in above_ref if r["reference_holds_1e-4_against_itself"]],
                "unexplained_by_the_decision_rule": [r["case"] for r in recs if r.get("unexplained_iterates")]}
     print(json.dumps(summary))
