@@ -322,7 +322,8 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic instances generated per GPU (seeds 1234 + 1000 config + global instance id; tiled to --instances if fewer)")
     ap.add_argument("--masked", action="store_true", help="realistic ~5%%-valid object mask instead of the 100%%-valid roofline variant")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline leg (and, unless --parity is given, the parity leg: both run the CPU oracle)")
+    ap.add_argument("--parity", action="store_true", help="run the parity leg (the timed output of every distinct instance against the CPU oracle) even with --no-cpu-baseline: lines of record for the other configs are self-checking without the 25 s baseline")
     ap.add_argument("--no-tracker-call", action="store_true", help="skip the extra field `tracker_call` (one object-masked c3 window per call through btba_optimize_frames_keyed, measured after the timed region)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--float4-cache", action="store_true", help="reference-layout float4 camPos + float4 normal caches (32 B/pixel) instead of the compact (z, n) cache")
@@ -639,7 +640,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(cfg, inst)
             note("CPU baseline done")
         parity_ok = True
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline or args.parity:
             picks = list(range(n_distinct))       # every distinct instance of the timed batch (instance b of the batch is inst[b % n_distinct]); ~70 ms each on 16 threads
             res["parity"] = oracle_parity(cfg, inst, picks, out_poses.reshape(B, K, 4, 4))
             parity_ok = res["parity"]["ok"]

@@ -142,6 +142,7 @@ struct btba_workspace {
     // live in pool slots that survive across calls; a keyframe is cached once, not once per BA call.
     struct FrameSlot { uint64_t key = 0; const float *depth = nullptr, *normal = nullptr; uint64_t stamp = 0; bool live = false; int32_t n_valid = 0; };
     DevBuf pool_zn, pool_lists, pool_counts, pool_nvalid, pool_map, pool_ranges;
+    size_t pool_map_offset = 0;                             // bytes into pool_map at which the window's frame -> slot map starts (behind the call's pointer table)
     // keyed correspondence cache (BTBA_FLAG_KEYED_CORR): the EntryJ segment of a frame PAIR stays on the device under the pair's two
     // frame keys; a sliding window then uploads only the new frame's K - 1 segments
     struct CorrSeg { uint32_t off = 0, count = 0; };
@@ -1312,7 +1313,7 @@ int btba_build_cache(btba_workspace *ws, int n_frames, int H, int W, const float
 static int pool_resolve(btba_workspace *ws, int N, int H, int W, int Hd, int Wd, const float *K, float downscale, const uint64_t *keys,
                         const float *const *depth_dev, const float *const *normal_dev, std::vector<int> &slot_of, int *n_built, const int32_t **nv_pinned);
 static void pool_commit(btba_workspace *ws, int N, const std::vector<int> &slot_of, const int32_t *nv_pinned, std::vector<int32_t> &nv_out);
-static int enqueue_frame_cache(btba_workspace *ws, int M, int H, int W, int Hd, int Wd, const float *const *ptrs_dev, const int *slots_dev,
+static int enqueue_frame_cache(btba_workspace *ws, int M, int H, int W, int Hd, int Wd, const float *const *ptrs_dev, const int *slots_dev, const int32_t *slots_host,
                                float4 *zn, int32_t *nvalid, uint32_t *lists, int *counts, float2 *ranges);
 
 static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params_in, int n_frames, int H, int W, const float *K,
@@ -1518,7 +1519,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
             pp[k] = depth_dev[k]; pp[N + k] = normal_dev[k];
         }
         if ((e = hipMemcpyAsync(ws->ptrs.p, ws->pin, sizeof(void *) * 2 * (size_t)N, hipMemcpyHostToDevice, ws->stream)) != hipSuccess) return hip_fail(e);
-        rc = enqueue_frame_cache(ws, N, H, W, Hd, Wd, ws->ptrs.as<const float *>(), nullptr, ws->campos.as<float4>(), ws->nvalid.as<int32_t>(),
+        rc = enqueue_frame_cache(ws, N, H, W, Hd, Wd, ws->ptrs.as<const float *>(), nullptr, nullptr, ws->campos.as<float4>(), ws->nvalid.as<int32_t>(),
                                  ws->valid_lists.as<uint32_t>(), ws->valid_counts.as<int>(), ws->block_ranges.as<float2>());
         if (!rc) {
             nv_pinned = reinterpret_cast<const int32_t *>(static_cast<unsigned char *>(ws->pin) + off_nv);
@@ -1585,7 +1586,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     ZnSpec Z;
     if (compact) {
         Z.zn = keyed ? ws->pool_zn.as<float>() : ws->campos.as<float>(); Z.H = H; Z.W = W; Z.K = K;
-        if (keyed) { Z.frame_slot = ws->pool_map.as<int>(); Z.lists = ws->pool_lists.as<uint32_t>(); Z.counts = ws->pool_counts.as<int>(); if (Wd % 8 == 0 && Hd % 8 == 0) Z.block_ranges = ws->pool_ranges.as<float>(); }
+        if (keyed) { Z.frame_slot = reinterpret_cast<const int *>(static_cast<const unsigned char *>(ws->pool_map.p) + ws->pool_map_offset); Z.lists = ws->pool_lists.as<uint32_t>(); Z.counts = ws->pool_counts.as<int>(); if (Wd % 8 == 0 && Hd % 8 == 0) Z.block_ranges = ws->pool_ranges.as<float>(); }
         else if (have_aux) { Z.lists = ws->valid_lists.as<uint32_t>(); Z.counts = ws->valid_counts.as<int>(); if (Wd % 8 == 0 && Hd % 8 == 0) Z.block_ranges = ws->block_ranges.as<float>(); }
         if (!(prm.flags & (BTBA_FLAG_COMPACTION | BTBA_FLAG_NO_COMPACTION))) {
             // a tracker's frames are masked to the object: walk valid-pixel lists when under 60 % of the pixels carry a depth.
@@ -1692,27 +1693,25 @@ int btba_frame_cache_evict(btba_workspace *ws, uint64_t frame_key)
 // yet (same key AND same device buffers) -- in a tracker that is the one new frame, the keyframes were cached by
 // earlier calls (the reference re-caches all K frames on every call, LossGPU.cu:74-78).  Least-recently-used slots
 // are recycled.  Leaves the slot map on the device (ws->pool_map) and the per-frame valid counts in nv_out.
-// The frame cache of M frames in ONE launch where k_frame_cache_fused covers the cache size (<= 32 768 cached pixels: compact cache, valid-pixel lists, counts and -- for
-// widths / heights that are multiples of 8 -- the per-block depth ranges), the three kernels of rounds 1-5 otherwise.  ptrs_dev: [M depth pointers][M normal pointers],
-// slots_dev: destination slot per frame or NULL (frame f -> slot f).  Enqueue only.
-static int enqueue_frame_cache(btba_workspace *ws, int M, int H, int W, int Hd, int Wd, const float *const *ptrs_dev, const int *slots_dev,
+// The frame cache of M frames: compact cache, valid-pixel lists + counts, per-block depth ranges.  ptrs_dev: [M depth pointers][M normal pointers];
+// slots_dev / slots_host: destination slot per frame or NULL (frame f -> slot f).  Enqueue only -- no host synchronisation.
+static int enqueue_frame_cache(btba_workspace *ws, int M, int H, int W, int Hd, int Wd, const float *const *ptrs_dev, const int *slots_dev, const int32_t *slots_host,
                                float4 *zn, int32_t *nvalid, uint32_t *lists, int *counts, float2 *ranges)
 {
+    // Three launches back to back, nothing between them on the host: compact cache (all frames in one grid), ordered valid-pixel lists + counts, per-block depth
+    // ranges.  (Round 6 tried them as ONE launch twice -- a workgroup per frame: 33 us per frame, its 1.5 MB of samples through one compute unit; sixteen slices
+    // per frame with the last arriver finishing lists and ranges: 40 us for one frame, 143 us for fifteen -- against ~20 us for these three; since the call's
+    // EntryJ upload now runs beside them on its own stream their time is hidden anyway.  profiles/r06/boundary_timing_experiments.json)
     const int npix = Hd * Wd;
-    const bool blocks8 = (Wd % 8 == 0 && Hd % 8 == 0);
-    const int seg = (((npix + 15) / 16) + 63) & ~63;
     int rc;
+    if (slots_host) { for (int m = 0; m < M; m++) HIP_TRY(hipMemsetAsync(nvalid + slots_host[m], 0, sizeof(int32_t), ws->stream)); }
+    else HIP_TRY(hipMemsetAsync(nvalid, 0, sizeof(int32_t) * (size_t)M, ws->stream));
     size_t tslot;
     if ((rc = time_begin(ws, true, 4, &tslot))) return rc;
-    if (seg / 64 <= kListTrips) {
-        k_frame_cache_fused<<<M, 1024, 0, ws->stream>>>(W, H, Wd, Hd, ptrs_dev, ptrs_dev + M, zn, nvalid, slots_dev, lists, counts, blocks8 ? ranges : nullptr);
-    } else {
-        if (slots_dev) return BTBA_EINVAL;       // (the pool path sizes its slots for the fused kernel's range; pool_resolve falls back before it gets here)
-        HIP_TRY(hipMemsetAsync(nvalid, 0, sizeof(int32_t) * (size_t)M, ws->stream));
-        k_build_cache_zn<<<dim3((npix + kBlock - 1) / kBlock, M), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, ptrs_dev, ptrs_dev + M, zn, nvalid, nullptr);
-        k_valid_lists<<<M, 1024, 0, ws->stream>>>(npix, zn, lists, counts, nullptr);
-        if (blocks8) k_block_ranges<<<dim3((unsigned)(((Wd / 8) * (Hd / 8) + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)M), kBlock, 0, ws->stream>>>(Wd, Hd, zn, nullptr, ranges);
-    }
+    k_build_cache_zn<<<dim3((npix + kBlock - 1) / kBlock, M), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, ptrs_dev, ptrs_dev + M, zn, nvalid, slots_dev);
+    k_valid_lists<<<M, 1024, 0, ws->stream>>>(npix, zn, lists, counts, slots_dev);
+    if (Wd % 8 == 0 && Hd % 8 == 0)
+        k_block_ranges<<<dim3((unsigned)(((Wd / 8) * (Hd / 8) + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)M), kBlock, 0, ws->stream>>>(Wd, Hd, zn, slots_dev, ranges);
     if ((rc = time_end(ws, tslot))) return rc;
     HIP_TRY(hipGetLastError());
     return BTBA_OK;
@@ -1778,34 +1777,21 @@ static int pool_resolve(btba_workspace *ws, int N, int H, int W, int Hd, int Wd,
     int32_t *pin_map = reinterpret_cast<int32_t *>(pin + off_map);
     for (int k = 0; k < N; k++) pin_map[k] = slot_of[k];
     *nv_pinned = reinterpret_cast<const int32_t *>(pin + off_nv);
+    // ONE copy out of the pinned block carries [pointers | destination slots | slot map] (ws->pool_map holds all three; Z.frame_slot points at its tail)
+    const size_t up_bytes = off_map + sizeof(int32_t) * (size_t)N;
+    if ((rc = ws->pool_map.ensure(up_bytes + 16))) return rc;
+    ws->pool_map_offset = off_map;
     if (M > 0) {
-        if ((rc = ws->ptrs.ensure(off_map))) return rc;
         auto **pp = reinterpret_cast<const float **>(pin);
         auto *ps = reinterpret_cast<int32_t *>(pin + off_slots);
         for (int m = 0; m < M; m++) { pp[m] = depth_dev[miss[m]]; pp[M + m] = normal_dev[miss[m]]; ps[m] = slot_of[miss[m]]; }
-        HIP_TRY(hipMemcpyAsync(ws->ptrs.p, pin, off_map, hipMemcpyHostToDevice, ws->stream));
-        const int *slots_dev = reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(ws->ptrs.p) + off_slots);
-        const int seg = (((npix + 15) / 16) + 63) & ~63;
-        if (seg / 64 <= kListTrips) {
-            if ((rc = enqueue_frame_cache(ws, M, H, W, Hd, Wd, ws->ptrs.as<const float *>(), slots_dev, ws->pool_zn.as<float4>(), ws->pool_nvalid.as<int32_t>(),
-                                          ws->pool_lists.as<uint32_t>(), ws->pool_counts.as<int>(), ws->pool_ranges.as<float2>()))) return rc;
-        } else {      // large caches: the three kernels, with the slot indirection
-            for (int m = 0; m < M; m++) HIP_TRY(hipMemsetAsync(ws->pool_nvalid.as<int32_t>() + ps[m], 0, sizeof(int32_t), ws->stream));
-            size_t tslot;
-            if ((rc = time_begin(ws, true, 4, &tslot))) return rc;
-            k_build_cache_zn<<<dim3((npix + kBlock - 1) / kBlock, M), kBlock, 0, ws->stream>>>(W, H, Wd, Hd, ws->ptrs.as<const float *>(), ws->ptrs.as<const float *>() + M,
-                                                                                            ws->pool_zn.as<float4>(), ws->pool_nvalid.as<int32_t>(), slots_dev);
-            k_valid_lists<<<M, 1024, 0, ws->stream>>>(npix, ws->pool_zn.as<const float4>(), ws->pool_lists.as<uint32_t>(), ws->pool_counts.as<int>(), slots_dev);
-            if (Wd % 8 == 0 && Hd % 8 == 0)
-                k_block_ranges<<<dim3((unsigned)(((Wd / 8) * (Hd / 8) + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)M), kBlock, 0, ws->stream>>>(Wd, Hd, ws->pool_zn.as<const float4>(), slots_dev, ws->pool_ranges.as<float2>());
-            if ((rc = time_end(ws, tslot))) return rc;
-            HIP_TRY(hipGetLastError());
-        }
+        HIP_TRY(hipMemcpyAsync(ws->pool_map.p, pin, up_bytes, hipMemcpyHostToDevice, ws->stream));
+        const int *slots_dev = reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(ws->pool_map.p) + off_slots);
+        if ((rc = enqueue_frame_cache(ws, M, H, W, Hd, Wd, ws->pool_map.as<const float *>(), slots_dev, ps, ws->pool_zn.as<float4>(), ws->pool_nvalid.as<int32_t>(),
+                                      ws->pool_lists.as<uint32_t>(), ws->pool_counts.as<int>(), ws->pool_ranges.as<float2>()))) return rc;
         HIP_TRY(hipMemcpyAsync(pin + off_nv, ws->pool_nvalid.p, sizeof(int32_t) * cap, hipMemcpyDeviceToHost, ws->stream));
         for (int m = 0; m < M; m++) ws->pool_pending.push_back({ ps[m], keys[miss[m]], depth_dev[miss[m]], normal_dev[miss[m]] });
-    }
-    if ((rc = ws->pool_map.ensure(sizeof(int) * (size_t)N))) return rc;
-    HIP_TRY(hipMemcpyAsync(ws->pool_map.p, pin_map, sizeof(int) * (size_t)N, hipMemcpyHostToDevice, ws->stream));
+    } else HIP_TRY(hipMemcpyAsync(ws->pool_map.p, pin, up_bytes, hipMemcpyHostToDevice, ws->stream));      // (off_map == 0: the map alone)
     return BTBA_OK;
 }
 

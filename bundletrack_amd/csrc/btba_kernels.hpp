@@ -868,87 +868,6 @@ __global__ void __launch_bounds__(1024) k_valid_lists(int npix, const float4 *__
     if (threadIdx.x == 0) counts[f] = total;
 }
 
-// Round 6: the WHOLE frame cache of a frame in ONE launch -- compact cache (k_build_cache_zn), ordered valid-pixel list and count (k_valid_lists) and the
-// per-block depth ranges (k_block_ranges).  One workgroup of 16 waves per frame.  A tracker caches ONE new frame per call: as three launches that cost
-// 21 us of device time against 14 us for fifteen frames in one k_build_cache_zn launch (profiles/r05/boundary_timing.jsonl: the keyed path was SLOWER
-// than re-caching everything).  Wave w builds the contiguous pixel segment the list phase of k_valid_lists gives it, so the validity ballots of the build
-// ARE the list's ballots and the frame is not read again; the block ranges read the finished cache back after a barrier (same compute unit, same L1).
-// Same arithmetic per pixel as k_build_cache_zn (contraction off), same list order, same ranges: the three kernels stay for caches this one does not cover
-// (more than 32 768 cached pixels, width or height not a multiple of 8).
-__global__ void __launch_bounds__(1024) k_frame_cache_fused(int W, int H, int Wd, int Hd, const float *const *__restrict__ depth, const float *const *__restrict__ normals,
-                                                           float4 *zn_out, int *__restrict__ n_valid, const int *__restrict__ out_slot,
-                                                           uint32_t *__restrict__ lists, int *__restrict__ counts, float2 *__restrict__ ranges)
-{
-#pragma clang fp contract(off)
-    __shared__ int wave_tot[16];
-    const int f = blockIdx.x;
-    const int fo = out_slot ? out_slot[f] : f;
-    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-    const int npix = Wd * Hd;
-    float4 *z = zn_out + (size_t)fo * npix;
-    const float *dp = depth[f];
-    const float4 *np4 = reinterpret_cast<const float4 *>(normals[f]);
-    const float scaleW = (float)(W - 1) / (float)(Wd - 1);
-    const float scaleH = (float)(H - 1) / (float)(Hd - 1);
-    const int seg = (((npix + 15) / 16) + 63) & ~63, trips = seg / 64;      // <= kListTrips (the host checks)
-    const int s_wave = wave * seg;
-    unsigned long long m[kListTrips];
-#pragma unroll
-    for (int k0 = 0; k0 < kListTrips; k0 += 8) {
-        float dd[8]; float4 nn[8]; bool in[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = k0 + u, o = s_wave + k * 64 + lane;
-            in[u] = false; dd[u] = 0.0f; nn[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < trips && o < npix) {
-                const int x = o % Wd, y = o / Wd;
-                const unsigned xi = (unsigned)(x * scaleW + 0.5f);
-                const unsigned yi = (unsigned)(y * scaleH + 0.5f);
-                if (xi < (unsigned)W && yi < (unsigned)H) {
-                    const size_t s = (size_t)yi * W + xi;
-                    in[u] = true; dd[u] = dp[s]; nn[u] = np4[s];
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = k0 + u, o = s_wave + k * 64 + lane;
-            const bool valid = in[u] && ((double)dd[u] >= 0.1);
-            if (in[u]) z[o] = make_float4(valid ? dd[u] : 0.0f, nn[u].x, nn[u].y, nn[u].z);
-            m[k] = __builtin_amdgcn_ballot_w64(valid);
-        }
-    }
-    int cnt = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < kListTrips; k++) cnt += __popcll(m[k]);
-    if (lane == 0) wave_tot[wave] = cnt;
-    __syncthreads();                      // (also: every wave's part of the cache is written and visible to the workgroup)
-    int base = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) { const int t = wave_tot[w]; if (w < wave) base += t; total += t; }
-    uint32_t *out = lists + (size_t)fo * npix;
-#pragma unroll
-    for (int k = 0; k < kListTrips; k++) {
-        const unsigned long long b = m[k];
-        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0));
-        if ((b >> lane) & 1ull) out[base + before] = (uint32_t)(s_wave + k * 64 + lane);
-        base += __popcll(b);
-    }
-    if (threadIdx.x == 0) { counts[fo] = total; if (n_valid) n_valid[fo] = total; }
-    if (ranges) {
-        const int bw = Wd >> 3, nblk = bw * (Hd >> 3);
-        for (int blk = wave; blk < nblk; blk += 16) {
-            const int by = blk / bw, bx = blk - by * bw;
-            const float d = z[(size_t)((by * 8 + (lane >> 3)) * Wd + bx * 8 + (lane & 7))].x;
-            const bool ok = d > 0.0f;
-            float lo = ok ? d : INFINITY, hi = ok ? d : -INFINITY;
-#pragma unroll
-            for (int q = 32; q >= 1; q >>= 1) { lo = fminf(lo, __shfl_xor(lo, q)); hi = fmaxf(hi, __shfl_xor(hi, q)); }
-            if (lane == 0) ranges[(size_t)fo * nblk + blk] = make_float2(lo, hi);
-        }
-    }
-}
-
 // The same sweep on the compact cache: ONE 16-byte load per source pixel and per tap (5 loads instead of 10),
 // camera-space points re-derived from z with the cache builder's exact arithmetic (zn_backproject).
 template <bool SIMPLE, bool LISTS>
