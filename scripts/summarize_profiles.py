@@ -1,5 +1,5 @@
 """Turn the rocprofv3 outputs of scripts/profile_bench.sh (gpurun_out/prof_<tag>) into the small tracked summaries under
-profiles/r04/ and add / replace that workload's record in profiles/sweep_counters.json -- what bench.py quotes as roofline.traffic /
+profiles/<round>/ (BTBA_PROFILE_ROUND, default r06) and add / replace that workload's record in profiles/sweep_counters.json -- what bench.py quotes as roofline.traffic /
 roofline.valu_issue.  A record is keyed by a hash of the kernel sources AND by the whole workload (config, instances, distinct
 instances, mask, cache and correspondence layout): bench.py quotes it only for a line measured on exactly that.
     python scripts/summarize_profiles.py <tag> <version> [--masked] [--config c3] [--instances 32] [--distinct 32] [--entryj]"""
@@ -7,7 +7,7 @@ import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ROUND = "r05"
+ROUND = os.environ.get("BTBA_PROFILE_ROUND", "r06")
 
 
 def agg(path):
