@@ -327,7 +327,8 @@ def main():
     ap.add_argument("--no-tracker-call", action="store_true", help="skip the extra field `tracker_call` (one object-masked c3 window per call through btba_optimize_frames_keyed, measured after the timed region)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--float4-cache", action="store_true", help="reference-layout float4 camPos + float4 normal caches (32 B/pixel) instead of the compact (z, n) cache")
-    ap.add_argument("--latency", action="store_true", help="also measure single-instance latency mode (extra field)")
+    ap.add_argument("--latency", action="store_true", help="also measure single-instance latency mode (extra field; always on at --gpus 1 unless --no-single-instance)")
+    ap.add_argument("--no-single-instance", action="store_true", help="skip the `single_instance` leg: profiling passes, whose per-kernel averages must be those of the benched launches alone (the B = 1 solves launch the same kernels)")
     ap.add_argument("--same-instances", action="store_true", help="every rank solves the SAME instances (global ids 0 ..): the per-rank pose checksums must then agree -- a consistency check of the sharded run, not a benchmark")
     ap.add_argument("--entryj", action="store_true", help="keep the device-resident correspondences as 32-byte EntryJ instead of packing them to 24-byte records before the timed region")
     ap.add_argument("--corr24", action="store_true", help="24-byte records also with --masked (default there: EntryJ, which measured 4 %% faster on the masked launch: profiles/r03)")
@@ -604,7 +605,7 @@ def main():
                                "algorithmic_32B_GBps": round(32 * n_corr / (avg_ms * 1e-3) / 1e9, 1),
                                "layout_bytes_per_launch": (24 if use_c24 else 32) * n_corr,
                                "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_sparse_launches"]}
-        if args.latency or world == 1:
+        if args.latency or (world == 1 and not args.no_single_instance):
             # BASELINE.json's metric read literally -- ONE K=15 x 2k problem at a time (B = 1), resident inputs, pose in -> pose out: always in the
             # single-GPU line (10 ms of GPU time); `value` above is the batch of 32 such problems per GPU that SURVEY.md 8(d) names for the headline
             bs1 = BatchSolver(ws, weight_dense_depth=cfg["w_dense"])

@@ -21,9 +21,9 @@ BTBA_BENCH_NPROC=8 timeout 300 python "$REPO/bench.py" --no-cpu-baseline --steps
 echo "pre rc=$?" >> "$OUT/pre.log"
 export BTBA_BENCH_NPROC=1
 # the stats pass runs bench.py's DEFAULT step counts, so that the kernel durations are taken at the same clocks as the bench line
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$REPO/bench.py" --no-cpu-baseline --no-tracker-call --no-incl-pack $* > "$OUT/stats.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$REPO/bench.py" --no-cpu-baseline --no-tracker-call --no-incl-pack --no-single-instance $* > "$OUT/stats.log" 2>&1
 echo "stats rc=$?" >> "$OUT/stats.log"
-ARGS="--steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-tracker-call --no-incl-pack --no-kernel-timing $*"
+ARGS="--steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-tracker-call --no-incl-pack --no-single-instance --no-kernel-timing $*"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o bench -- python "$REPO/bench.py" $ARGS > "$OUT/fetch.log" 2>&1
 echo "fetch rc=$?" >> "$OUT/fetch.log"
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o bench -- python "$REPO/bench.py" $ARGS > "$OUT/write.log" 2>&1

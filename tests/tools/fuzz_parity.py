@@ -68,6 +68,18 @@ def run_cases(n_cases, explain_always=False, only=None, hook=None, prepare=None)
                     nearest = [min(max(max(S.pose_error(tv.T_after[0, it, k], runs[v, it, k])) for k in range(K)) for v in range(runs.shape[0])) for it in range(G)]
                     # the drop-in boundary's result (compact cache, the library's own tile / chunk choice: other sums than the traced batch entry) has a final iterate only
                     b_near = min(max(max(S.pose_error(poses[k], runs[v, -1, k])) for k in range(K)) for v in range(runs.shape[0]))
+                    def beyond_any(cum_):
+                        return any(hip_ref[it] >= max(1e-4, 3.0 * cum_[it]) for it in range(G)) or rec["vs_reference_final"] >= max(1e-4, 3.0 * cum_[-1])
+                    if beyond_any(cum):
+                        # Eight runs SAMPLE what the reference does to itself; one flipped accept decision is a rare, large event (fuzz case 113: a dense-only four-frame
+                        # window -- seven of the eight runs within 1e-4, the boundary path 1.2e-3 away; of 48 runs one lands 1.24e-3 from the forward run as well).
+                        # Before a window is called beyond the reference's spread, 48 more runs (24 shuffles x IEEE / fast-math) are drawn.
+                        more = [(f"shuffle:{sd}", fm) for sd in range(3, 27) for fm in (False, True)]
+                        sp2, runs2 = R.self_spread(campos, nrm, caches[0]["intr"], corr, pb.poses_init, S.pose_error, variants=[("forward", False)] + more)
+                        sp = np.maximum(sp, sp2); cum = np.maximum.accumulate(sp); runs = np.concatenate([runs, runs2[1:]])
+                        nearest = [min(max(max(S.pose_error(tv.T_after[0, it, k], runs[v, it, k])) for k in range(K)) for v in range(runs.shape[0])) for it in range(G)]
+                        b_near = min(max(max(S.pose_error(poses[k], runs[v, -1, k])) for k in range(K)) for v in range(runs.shape[0]))
+                        rec["reference_runs"] = int(runs.shape[0])
                     rec.update({"reference_self_spread": [float(f"{x:.3g}") for x in sp], "hip_to_nearest_reference_run": [float(f"{x:.3g}") for x in nearest],
                                 "beyond_reference_spread": [it for it in range(G) if hip_ref[it] >= max(1e-4, 3.0 * cum[it])],
                                 "boundary_final_beyond_reference_spread": bool(rec["vs_reference_final"] >= max(1e-4, 3.0 * cum[-1])),
