@@ -66,6 +66,13 @@ __device__ __forceinline__ Mat4 mat_inverse(const Mat4 &a)
     return o;
 }
 
+// Division and square root of the SE(3) helpers.  FAST = false: IEEE (v_div_scale / v_div_fmas / v_div_fixup sequences, refined square root) -- what the seam
+// kernels (k_prepare, k_poses_to_matrices) and k_system_solve use.  FAST = true (round 6, the update phase of k_solve_small / k_solve_mid): x * v_rcp_f32(y) and
+// v_sqrt_f32, 1 ulp each -- the class of arithmetic the reference's own build has (-use_fast_math: --prec-div=false --prec-sqrt=false, CMakeLists.txt:7) and the
+// PCG's alpha / beta already use; ten divisions and nine square roots are ~170 of the ~650 dependent instructions of the one-lane-per-frame update chain.
+template <bool FAST> __device__ __forceinline__ float se3_div(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <bool FAST> __device__ __forceinline__ float se3_sqrt(float x) { return FAST ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+
 #define BTBA_ONE_TWENTIETH 0.05f
 #define BTBA_ONE_SIXTH 0.16666667f
 
@@ -84,10 +91,11 @@ __device__ __forceinline__ void rodrigues(const float w[3], float A, float B, fl
     r[5] = b - a; r[7] = b + a;
 }
 
+template <bool FAST = false>
 __device__ __forceinline__ void exp_rotation(const float w[3], float r[9])
 {
     const float theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-    const float theta = sqrtf(theta_sq);
+    const float theta = se3_sqrt<FAST>(theta_sq);
     float A, B;
     if ((double)theta_sq < 1e-8) {
         A = 1.0f - BTBA_ONE_SIXTH * theta_sq;
@@ -96,7 +104,7 @@ __device__ __forceinline__ void exp_rotation(const float w[3], float r[9])
         B = 0.5f - 0.25f * BTBA_ONE_SIXTH * theta_sq;
         A = 1.0f - theta_sq * BTBA_ONE_SIXTH * (1.0f - BTBA_ONE_TWENTIETH * theta_sq);
     } else {
-        const float inv_theta = 1.0f / theta;
+        const float inv_theta = se3_div<FAST>(1.0f, theta);
         float sn, cs;
         sincosf(theta, &sn, &cs);                     // one argument reduction for both (the values of sinf / cosf, bit for bit)
         A = sn * inv_theta;
@@ -105,18 +113,19 @@ __device__ __forceinline__ void exp_rotation(const float w[3], float r[9])
     rodrigues(w, A, B, r);
 }
 
+template <bool FAST = false>
 __device__ __forceinline__ void ln_rotation(const float R[9], float out[3])
 {
     const float cos_angle = ((R[0] + R[4] + R[8]) - 1.0f) * 0.5f;
     float r0 = (R[7] - R[5]) * 0.5f, r1 = (R[2] - R[6]) * 0.5f, r2 = (R[3] - R[1]) * 0.5f;
-    const float sin_angle_abs = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+    const float sin_angle_abs = se3_sqrt<FAST>(r0 * r0 + r1 * r1 + r2 * r2);
     if (cos_angle > 0.70710678118654752440f) {
         if (sin_angle_abs > 0) {
-            const float s = asinf(sin_angle_abs) / sin_angle_abs;
+            const float s = se3_div<FAST>(asinf(sin_angle_abs), sin_angle_abs);
             r0 *= s; r1 *= s; r2 *= s;
         }
     } else if (cos_angle > -0.70710678118654752440f) {
-        const float s = acosf(cos_angle) / sin_angle_abs;
+        const float s = se3_div<FAST>(acosf(cos_angle), sin_angle_abs);
         r0 *= s; r1 *= s; r2 *= s;
     } else {
         const float angle = 3.14159265358979323846f - asinf(sin_angle_abs);
@@ -130,7 +139,7 @@ __device__ __forceinline__ void ln_rotation(const float R[9], float out[3])
             q0 = (R[2] + R[6]) * 0.5f; q1 = (R[7] + R[5]) * 0.5f; q2 = d2;
         }
         if (q0 * r0 + q1 * r1 + q2 * r2 < 0) { q0 = -q0; q1 = -q1; q2 = -q2; }
-        const float s = angle / sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+        const float s = se3_div<FAST>(angle, se3_sqrt<FAST>(q0 * q0 + q1 * q1 + q2 * q2));
         r0 = q0 * s; r1 = q1 * s; r2 = q2 * s;
     }
     out[0] = r0; out[1] = r1; out[2] = r2;
@@ -141,19 +150,20 @@ __device__ __forceinline__ void ln_rotation(const float R[9], float out[3])
 // |-rot / 2| = sqrtf(sum (rot_i / 2)^2) = theta / 2 BIT FOR BIT (scaling by a power of two commutes with every rounding of the sum and of the
 // correctly rounded square root), so one sincosf serves both -- ~40 instructions off k_solve_small's one-lane update chain, same bits
 // (tests/test_gpu_parity.py::test_se3_helpers_bit_exact against the reference's own LieDerivUtil.h).
+template <bool FAST = false>
 __device__ __forceinline__ void matrix_to_pose(const Mat4 &M, float rot[3], float trans[3])
 {
     const float R[9] = { M.m[0], M.m[1], M.m[2], M.m[4], M.m[5], M.m[6], M.m[8], M.m[9], M.m[10] };
     const float t[3] = { M.m[3], M.m[7], M.m[11] };
-    ln_rotation(R, rot);
-    const float theta = sqrtf(rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
+    ln_rotation<FAST>(R, rot);
+    const float theta = se3_sqrt<FAST>(rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
     float shtot = 0.5f, sn = 0.0f, cs = 1.0f;
-    if (theta > 0.00001f) { sincosf(theta * 0.5f, &sn, &cs); shtot = sn / theta; }
+    if (theta > 0.00001f) { sincosf(theta * 0.5f, &sn, &cs); shtot = se3_div<FAST>(sn, theta); }
     const float rh[3] = { rot[0] * -0.5f, rot[1] * -0.5f, rot[2] * -0.5f };
     float Hh[9];
     {   // exp_rotation(rh, Hh) with the sine and cosine of |rh| = theta / 2 from above
         const float theta_sq = rh[0] * rh[0] + rh[1] * rh[1] + rh[2] * rh[2];
-        const float theta_h = sqrtf(theta_sq);
+        const float theta_h = se3_sqrt<FAST>(theta_sq);
         float A, B;
         if ((double)theta_sq < 1e-8) {
             A = 1.0f - BTBA_ONE_SIXTH * theta_sq;
@@ -162,7 +172,7 @@ __device__ __forceinline__ void matrix_to_pose(const Mat4 &M, float rot[3], floa
             B = 0.5f - 0.25f * BTBA_ONE_SIXTH * theta_sq;
             A = 1.0f - theta_sq * BTBA_ONE_SIXTH * (1.0f - BTBA_ONE_TWENTIETH * theta_sq);
         } else {
-            const float inv_theta = 1.0f / theta_h;
+            const float inv_theta = se3_div<FAST>(1.0f, theta_h);
             A = sn * inv_theta;
             B = (1.0f - cs) * (inv_theta * inv_theta);
         }
@@ -173,18 +183,19 @@ __device__ __forceinline__ void matrix_to_pose(const Mat4 &M, float rot[3], floa
     float tr2 = Hh[6] * t[0] + Hh[7] * t[1] + Hh[8] * t[2];
     const float tdr = t[0] * rot[0] + t[1] * rot[1] + t[2] * rot[2];
     float s;
-    if (theta > 0.001f) s = tdr * (1.0f - 2.0f * shtot) / (rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
-    else s = tdr / 24.0f;
+    if (theta > 0.001f) s = se3_div<FAST>(tdr * (1.0f - 2.0f * shtot), rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
+    else s = se3_div<FAST>(tdr, 24.0f);
     tr0 -= rot[0] * s; tr1 -= rot[1] * s; tr2 -= rot[2] * s;
-    const float k = 1.0f / (2.0f * shtot);
+    const float k = se3_div<FAST>(1.0f, 2.0f * shtot);
     trans[0] = tr0 * k; trans[1] = tr1 * k; trans[2] = tr2 * k;
 }
 
 // SE(3) exp: (rot, trans) -> 4x4   (poseToMatrix)
+template <bool FAST = false>
 __device__ __forceinline__ Mat4 pose_to_matrix(const float rot[3], const float trans[3])
 {
     const float theta_sq = rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2];
-    const float theta = sqrtf(theta_sq);
+    const float theta = se3_sqrt<FAST>(theta_sq);
     float A, B;
     const float cr[3] = { rot[1] * trans[2] - rot[2] * trans[1], rot[2] * trans[0] - rot[0] * trans[2], rot[0] * trans[1] - rot[1] * trans[0] };
     float tx, ty, tz;
@@ -199,7 +210,7 @@ __device__ __forceinline__ Mat4 pose_to_matrix(const float rot[3], const float t
             A = 1.0f - theta_sq * C;
             B = 0.5f - 0.25f * BTBA_ONE_SIXTH * theta_sq;
         } else {
-            const float inv_theta = 1.0f / theta;
+            const float inv_theta = se3_div<FAST>(1.0f, theta);
             float sn, cs;
             sincosf(theta, &sn, &cs);
             A = sn * inv_theta;

@@ -359,13 +359,13 @@ __global__ void __launch_bounds__(kSmallBlock) k_solve_mid(const SmallSolveArgs 
         if (k > 0) {
             const float *dk = vd + 6 * (k - 1);
             const float dW[3] = { dk[3], dk[4], dk[5] }, dT[3] = { dk[0], dk[1], dk[2] };
-            const Mat4 U = pose_to_matrix(dW, dT);
+            const Mat4 U = pose_to_matrix<BTBA_SOLVE_FAST_SE3>(dW, dT);
             Mat4 C = load_mat4(vT + 16 * k);                                // = Exp(x_k), from the previous launch: a pose_to_matrix result,
             C.m[12] = 0.0f; C.m[13] = 0.0f; C.m[14] = 0.0f; C.m[15] = 1.0f;   // whose last row is these constants
-            matrix_to_pose(mat_mul(U, C), rot, trans);
+            matrix_to_pose<BTBA_SOLVE_FAST_SE3>(mat_mul(U, C), rot, trans);
             xk[0] = rot[0]; xk[1] = rot[1]; xk[2] = rot[2]; xk[3] = trans[0]; xk[4] = trans[1]; xk[5] = trans[2];
         }
-        const Mat4 E = pose_to_matrix(rot, trans);
+        const Mat4 E = pose_to_matrix<BTBA_SOLVE_FAST_SE3>(rot, trans);
         store_mat4(S.T + __umul24(b, (unsigned)S.pose_stride) + 16 * k, E);
         if (S.poses_out) store_mat4(S.poses_out + 16 * (b * N + k), E);      // last iterate: convertPosesToMatricesCU (SBA.cpp:115)
         store_mat4(vE + 16 * k, E);
@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(kSmallBlock) k_solve_mid(const SmallSolveArgs 
         const int g0 = lane & ~15;
         const float a0 = __shfl(adj, g0, 64), a4 = __shfl(adj, g0 + 4, 64), a8 = __shfl(adj, g0 + 8, 64), a12 = __shfl(adj, g0 + 12, 64);
         const float det = m[0] * a0 + m[1] * a4 + m[2] * a8 + m[3] * a12;
-        const float rdet = 1.0f / det;
+        const float rdet = se3_div<BTBA_SOLVE_FAST_SE3>(1.0f, det);
         S.Tinv[__umul24(b, (unsigned)S.pose_stride) + tid] = adj * rdet;
     }
     BTBA_MSTAMP(7);
