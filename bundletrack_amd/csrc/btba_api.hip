@@ -125,6 +125,17 @@ struct btba_workspace {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copy = nullptr, ev_cache = nullptr;
     void *pin = nullptr; size_t pin_cap = 0;
+    void *pin_io = nullptr; size_t pin_io_cap = 0;          // pinned: [poses out | poses in | pair offsets] of one optimize_frames call (small pageable copies cost ~10 us of host time each)
+    int pin_io_ensure(size_t bytes)
+    {
+        if (bytes <= pin_io_cap) return BTBA_OK;
+        if (pin_io) { (void)hipHostFree(pin_io); pin_io = nullptr; pin_io_cap = 0; }
+        const size_t want = bytes + bytes / 2 + 4096;
+        hipError_t e = hipHostMalloc(&pin_io, want, hipHostMallocDefault);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; pin_io = nullptr; return e == hipErrorOutOfMemory ? BTBA_ENOMEM : BTBA_EHIP; }
+        pin_io_cap = want;
+        return BTBA_OK;
+    }
     int pin_ensure(size_t bytes)
     {
         if (bytes <= pin_cap) return BTBA_OK;
@@ -301,6 +312,7 @@ void btba_workspace_destroy(btba_workspace *ws)
     if (ws->ev_copy) (void)hipEventDestroy(ws->ev_copy);
     if (ws->ev_cache) (void)hipEventDestroy(ws->ev_cache);
     if (ws->pin) (void)hipHostFree(ws->pin);
+    if (ws->pin_io) (void)hipHostFree(ws->pin_io);
     if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
     for (auto e : ws->ev_join) if (e) (void)hipEventDestroy(e);
     if (ws->ev_order) (void)hipEventDestroy(ws->ev_order);
@@ -1385,7 +1397,11 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     if ((rc = ws->nvalid.ensure(sizeof(int32_t) * N))) return finish(rc);
     auto hip_fail = [&](hipError_t e) { g_last_hip_error = (int)e; return finish(BTBA_EHIP); };
     hipError_t e;
-    std::vector<float> stage(16 * (size_t)N + 1);             // poses + one word for the device's "not pair-major" flag (0)
+    // poses in (+ one word for the device's "not pair-major" flag, 0), poses out and the pair offsets go through a pinned block of the workspace (round 6)
+    const size_t io_floats = 16 * (size_t)N + 1;
+    if ((rc = ws->pin_io_ensure(sizeof(float) * 2 * io_floats + sizeof(uint32_t) * (size_t)(P + 1) + 64))) return finish(rc);
+    float *out = static_cast<float *>(ws->pin_io), *stage = out + io_floats;
+    uint32_t *offsets_pin = reinterpret_cast<uint32_t *>(stage + io_floats);
     // Keyed correspondence cache: with frame keys, the trusted pair-major layout and BTBA_FLAG_KEYED_CORR, a pair's segment is looked
     // up under (key_i, key_j, count); only the segments not seen before cross PCIe (into the pool), then one small kernel gathers
     // the window's P segments from the pool into the contiguous pair-major array the sweeps read, rewriting imgIdx_i / imgIdx_j to
@@ -1479,10 +1495,11 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
             stage_longest_fresh = longest_fresh;
         } else if (kept && (r = hipMemcpyAsync(ws->corr.p, upload, sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
         offsets_up.swap(offs_up);
-        if ((r = hipMemcpyAsync(ws->offsets.p, offsets_up.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
-        std::memcpy(stage.data(), poses, sizeof(float) * 16 * N);
+        std::memcpy(offsets_pin, offsets_up.data(), sizeof(uint32_t) * (size_t)(P + 1));
+        if ((r = hipMemcpyAsync(ws->offsets.p, offsets_pin, sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
+        std::memcpy(stage, poses, sizeof(float) * 16 * N);
         stage[16 * (size_t)N] = 0.0f;
-        return hipMemcpyAsync(ws->poses.p, stage.data(), sizeof(float) * stage.size(), hipMemcpyHostToDevice, up_st);
+        return hipMemcpyAsync(ws->poses.p, stage, sizeof(float) * io_floats, hipMemcpyHostToDevice, up_st);
     };
     // ---- round 6: frame cache FIRST, on the workspace's stream; the EntryJ / pose upload meanwhile on a stream of its own (a pageable hipMemcpyAsync blocks
     // the host for the copy's ~0.13 ms at c3: the cache kernel runs under it); `stream` waits for the upload's event before anything reads the correspondences
@@ -1602,7 +1619,6 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
             if (tot * 10 < (long)N * npix * 6) prm.flags |= BTBA_FLAG_COMPACTION;
         }
     }
-    std::vector<float> out(16 * (size_t)N + 1);
     btba_stats S;
     int *order_flag = reinterpret_cast<int *>(ws->poses.as<float>() + 16 * (size_t)N);
     auto solve_and_read = [&]() -> int {
@@ -1612,7 +1628,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
                               corr_in_pool, corr_in_pool ? ws->corr_lens.as<uint32_t>() : nullptr);
         if (r) return r;
         hipError_t he;
-        if ((he = hipMemcpyAsync(out.data(), ws->poses.p, sizeof(float) * out.size(), hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) { g_last_hip_error = (int)he; return BTBA_EHIP; }
+        if ((he = hipMemcpyAsync(out, ws->poses.p, sizeof(float) * io_floats, hipMemcpyDeviceToHost, ws->stream)) != hipSuccess) { g_last_hip_error = (int)he; return BTBA_EHIP; }
         return btba_collect_stats(ws, &S);       // synchronises
     };
     ws->always_time_region = true;               // ms_solve is reported by this entry point whatever the flags
@@ -1635,7 +1651,7 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     ws->always_time_region = false;
     if (rc) return finish(rc);
     for (size_t k = 0; k < 16 * (size_t)N; k++) if (!std::isfinite(out[k])) return finish(BTBA_ENUMERIC);
-    std::memcpy(poses, out.data(), sizeof(float) * 16 * (size_t)N);
+    std::memcpy(poses, out, sizeof(float) * 16 * (size_t)N);
     if (stats) {
         S.n_corr = kept;
         S.cache_frames_built = n_built;
