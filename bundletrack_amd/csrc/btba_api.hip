@@ -1399,9 +1399,9 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
     hipError_t e;
     // poses in (+ one word for the device's "not pair-major" flag, 0), poses out and the pair offsets go through a pinned block of the workspace (round 6)
     const size_t io_floats = 16 * (size_t)N + 1;
-    if ((rc = ws->pin_io_ensure(sizeof(float) * 2 * io_floats + sizeof(uint32_t) * (size_t)(P + 1) + 64))) return finish(rc);
+    if ((rc = ws->pin_io_ensure(sizeof(float) * 2 * io_floats + sizeof(uint32_t) * (size_t)(P + 1) + sizeof(uint32_t) * 5 * (size_t)P + 64))) return finish(rc);
     float *out = static_cast<float *>(ws->pin_io), *stage = out + io_floats;
-    uint32_t *offsets_pin = reinterpret_cast<uint32_t *>(stage + io_floats);
+    uint32_t *offsets_pin = reinterpret_cast<uint32_t *>(stage + io_floats), *lens_pin = offsets_pin + (P + 1), *desc_pin = lens_pin + P;      // (keyed correspondences: segment lengths [P], descriptors [<= 4 P])
     // Keyed correspondence cache: with frame keys, the trusted pair-major layout and BTBA_FLAG_KEYED_CORR, a pair's segment is looked
     // up under (key_i, key_j, count); only the segments not seen before cross PCIe (into the pool), then one small kernel gathers
     // the window's P segments from the pool into the contiguous pair-major array the sweeps read, rewriting imgIdx_i / imgIdx_j to
@@ -1487,10 +1487,12 @@ static int optimize_frames_impl(btba_workspace *ws_in, const btba_params *params
             if (staged) {
                 if ((r = hipMemcpyAsync(ws->corr_stage_dev.p, ws->corr_stage, sizeof(btba_entryj) * staged, hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
                 if (ws->corr_desc.ensure(sizeof(uint32_t) * desc.size()) != BTBA_OK) return hipErrorOutOfMemory;
-                if ((r = hipMemcpyAsync(ws->corr_desc.p, desc.data(), sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
+                std::memcpy(desc_pin, desc.data(), sizeof(uint32_t) * desc.size());
+                if ((r = hipMemcpyAsync(ws->corr_desc.p, desc_pin, sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
             }
             if (ws->corr_lens.ensure(sizeof(uint32_t) * (size_t)P) != BTBA_OK) return hipErrorOutOfMemory;
-            if ((r = hipMemcpyAsync(ws->corr_lens.p, lens.data(), sizeof(uint32_t) * (size_t)P, hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
+            std::memcpy(lens_pin, lens.data(), sizeof(uint32_t) * (size_t)P);
+            if ((r = hipMemcpyAsync(ws->corr_lens.p, lens_pin, sizeof(uint32_t) * (size_t)P, hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;
             corr_in_pool = true;
             stage_longest_fresh = longest_fresh;
         } else if (kept && (r = hipMemcpyAsync(ws->corr.p, upload, sizeof(btba_entryj) * kept, hipMemcpyHostToDevice, up_st)) != hipSuccess) return r;

@@ -34,3 +34,9 @@ cut -c1-600 $OUT/wg_trace_c3x32_r06_1tile.json; du -sh gpurun_out
 # the parity records: the per-iterate and random-window tests with their printed figures, the 120-window fuzz against the reference and its self-spread
 timeout 900 python -m pytest tests/test_gpu_vs_reference.py -q -m gpu -s -k "every_gauss_newton or random_windows or matches_the_reference_solver" 2>&1 | grep -v "^$" | grep -i "vs the reference\|random windows\|leave the bar\|within 3x\|beyond\|passed\|failed" > $OUT/reference_tests_printed.txt; cat $OUT/reference_tests_printed.txt | cut -c1-400
 timeout 1800 python tests/tools/fuzz_parity.py 120 > $OUT/fuzz_parity_120.jsonl 2> $OUT/fuzz.err; tail -1 $OUT/fuzz_parity_120.jsonl
+timeout 600 python scripts/boundary_timing.py > $OUT/boundary_timing.jsonl 2>/dev/null; python - <<'PY'
+import json
+for l in open("gpurun_out/r06_final/boundary_timing.jsonl"):
+    r = json.loads(l); print(r["K"], r["corr_per_pair"], r["valid_fraction"], "stateless", r["wall_ms_median"], "keyed", r["wall_ms_median_keyed"], "keyed+corr", r["wall_ms_median_keyed_frames_and_correspondences"])
+PY
+timeout 1800 python -m pytest tests -q -m gpu > $OUT/gputests.log 2>&1; tail -3 $OUT/gputests.log
