@@ -369,6 +369,10 @@ def test_the_reference_against_itself_on_a_well_conditioned_and_on_a_weak_window
     fm1, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, fastmath=True, fastmath_seed=1)
     fm2, _ = R.solve(campos, normals, intr, pb.corr, pb.poses_init, fastmath=True, fastmath_seed=2)
     assert not np.array_equal(fm1, fm2)                                   # another seed = another (equally legal) libdevice
+    # the fast-math library flushes denormals only INSIDE its own calls: linked with gcc's math flags it would pull in crtfastmath.o, whose constructor
+    # sets flush-to-zero for the whole process when the library is loaded (numpy, the oracle and the IEEE reference library included) -- oracle/Makefile links it without them
+    tiny = np.float32(1e-40)
+    assert tiny * np.float32(1.0) != 0 and np.finfo(np.float32).smallest_subnormal > 0
     cum, runs = reference_licence(R, S.pose_error, campos, normals, intr, pb.corr, pb.poses_init)
     assert runs.shape[:2] == (8, 7) and cum[-1] < 1e-4 and cum[0] > 0.0, cum
     weak = S.make_problem(2, 0, 5003, background=True, full_res=False, perturb_deg=2.0, perturb_m=0.005)
