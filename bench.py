@@ -604,7 +604,12 @@ def main():
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pc.get("hbm_bytes_per_launch") if pc else None, "algorithmic_bytes_per_launch": 32 * n_corr,
                                "algorithmic_32B_GBps": round(32 * n_corr / (avg_ms * 1e-3) / 1e9, 1),
                                "layout_bytes_per_launch": (24 if use_c24 else 32) * n_corr,
-                               "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_sparse_launches"]}
+                               "avg_launch_ms": round(avg_ms, 5), "launches_timed": st["n_sparse_launches"],
+                               "valu_issue": ({"busy_frac": pc["valu_busy_frac"], "cycles_per_instruction": pc.get("valu_cycles_per_inst"), "dual_issued_frac": pc.get("valu_dual_issued_frac"),
+                                               "waves_per_simd": pc.get("waves_per_simd"), "source": pc.get("source_sq"), "kernel_source_hash": pc.get("kernel_source_hash")}
+                                              if pc and pc.get("valu_busy_frac") is not None else None),
+                               "note": "HBM roofline of the sparse sweep: bytes the device layout moves per launch / launch time (hipEvents on the workspace stream) against 8 TB/s; the launch is 9 us long -- "
+                                       "mostly ramp-up and drain -- so `traffic` (L2 fetch bytes from the counter pass) over its duration is far below what the part streams"}
         if args.latency or (world == 1 and not args.no_single_instance):
             # BASELINE.json's metric read literally -- ONE K=15 x 2k problem at a time (B = 1), resident inputs, pose in -> pose out: always in the
             # single-GPU line (10 ms of GPU time); `value` above is the batch of 32 such problems per GPU that SURVEY.md 8(d) names for the headline
