@@ -373,6 +373,7 @@ def main():
         bs.params.flags |= _lib.FLAG_TIME_KERNELS | _lib.FLAG_TIME_SAMPLED      # one Gauss-Newton iteration of every solve is bracketed with hipEvents (rotating): every launch costs ~4 %
     bs.params.flags |= int(os.environ.get("BTBA_BENCH_FLAGS", "0"))          # developer A/B of tuning flags
     bs.params.dense_tiles = int(os.environ.get("BTBA_BENCH_TILES", "0"))     # 0 = the library's choice
+    bs.params.sparse_chunks = int(os.environ.get("BTBA_BENCH_CHUNKS", "0"))  # 0 = the library's choice
     if args.masked and not args.float4_cache:
         bs.params.flags |= _lib.FLAG_COMPACTION         # workload hint: masked frames -> walk valid-pixel lists (optimize_frames decides this by itself)
     corr, offs, mx = bs.pack_correspondences([p["corr"] for p in pick], K)
