@@ -269,7 +269,9 @@ BTBA_API int btba_workspace_signal_stream(btba_workspace *ws, void *stream);
  * only for some calls must not race them against its own non-blocking streams.
  * n_match_per_pair must hold P = n_frames (n_frames - 1) / 2 ints when non-NULL (the host wrappers pass NULL when the
  * caller's vector has another length).
- * Synchronous: poses are valid on return. */
+ * Synchronous: poses are valid on return.  Inside the call (round 6) the host is not synchronised before the end: the frame cache is built on the workspace's stream while
+ * the EntryJ array and the poses are uploaded on a second, non-blocking stream the workspace owns (it touches the workspace's own buffers only; the solve waits for its event),
+ * and every small table crosses through pinned blocks of the workspace -- with ws == NULL those are created and destroyed per call like everything else. */
 BTBA_API int btba_optimize_frames(btba_workspace *ws, const btba_params *params,
                          int n_frames, int H, int W, const float *K_rowmajor,
                          const btba_entryj *corres_host, uint32_t n_corres, const int *n_match_per_pair,
