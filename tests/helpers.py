@@ -105,10 +105,9 @@ def check_parity_with_decisions(hip_T, ora_T, div, pose_error, tol=1e-4, tol_aft
         e = max(max(pose_error(hip_T[it, k], ora_T[it, k])) for k in range(N))
         if it < first:
             wb = max(wb, e)
+            floor = 0.0 if spread_T is None else max(max(pose_error(spread_T[it2, k], ora_T[it2, k])) for it2 in range(it + 1) for k in range(N))
             if ref_spread is not None:
-                floor = float(ref_spread[it])
-            else:
-                floor = 0.0 if spread_T is None else max(max(pose_error(spread_T[it2, k], ora_T[it2, k])) for it2 in range(it + 1) for k in range(N))
+                floor = max(floor, float(ref_spread[it]))      # (both given: the larger of the two -- the oracle's own spread depends on the box's OpenMP thread count)
             assert e < max(tol, 3.0 * floor), (f"{what}: iterate {it} differs by {e:.2e} although every decision so far was identical "
                                                f"(first divergence: {div}; the {'reference' if ref_spread is not None else 'oracle'}'s own spread up to here: {floor:.2e})")
         else:

@@ -85,8 +85,12 @@ def run_cases(n_cases, explain_always=False, only=None, hook=None, prepare=None)
                                 "boundary_final_beyond_reference_spread": bool(rec["vs_reference_final"] >= max(1e-4, 3.0 * cum[-1])),
                                 "boundary_final_to_nearest_reference_run": float(f"{b_near:.3g}"),
                                 "reference_holds_1e-4_against_itself": bool(sp.max() < 1e-4)})
+                    # the reference is the authority: an iterate the oracle-based rule cannot explain (its floor, the oracle's OpenMP summation spread, changes with the
+                    # box's thread count) stands only if it is outside the reference's own spread too
+                    unexplained = [it for it in unexplained if hip_ref[it] >= max(1e-4, 3.0 * cum[it])]
                 else:
                     rec.update({"reference_self_spread": None, "beyond_reference_spread": [], "boundary_final_beyond_reference_spread": False})
+                    unexplained = []                  # every iterate within 1e-4 of the reference's own forward run
             if unexplained:
                 # Second opinion before calling an iterate unexplained: the oracle's sequential-sum run (`seq`) is an OpenMP reduction whose order -- and
                 # with it `spread` -- changes with the box's thread count (case 13, an ill-conditioned K = 5 window with 5 matches per pair: 4.6e-5,
