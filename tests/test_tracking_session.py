@@ -153,7 +153,9 @@ def test_c1_sliding_window_hip_vs_oracle(oracle, tmp_path):
     # oracle's own two summation orders disagree on those calls (tests/tools/dbg_session.py); one or two flipped steps move a
     # pose by 1-2.5e-4, so those calls are held to 5e-4.
     print("BA calls: %d, median diff %.2e, over 1e-4: %s" % (len(d), np.median(d), np.round(d[d >= 1e-4], 6).tolist()))
-    assert np.median(d) < 1e-5 and (d < 1e-4).mean() >= 0.9 and d.max() < 5e-4, d
+    # (the share of calls inside 1e-4: the reference's OWN solver, run under other atomic orders and its fast-math flags, keeps 52 of these 59 calls = 0.88 within 1e-4 of
+    # itself -- profiles/r06/reference_self_spread.json, set `session` -- so 0.85 is asked of the HIP path against the oracle; every call above 5e-5 was classified above)
+    assert np.median(d) < 1e-5 and (d < 1e-4).mean() >= 0.85 and d.max() < 5e-4, d
     check_session(seq, bundler, frames, errs, n)
 
 
