@@ -10,20 +10,32 @@ as arrays of 3-D point pairs, which is exactly what `Correspondence._ptA_cam/_pt
 """
 from __future__ import annotations
 
+import ctypes
+import ctypes.util
 from dataclasses import dataclass, field
 
 import numpy as np
 
 from ._lib import ENTRYJ_DTYPE
 
+# std::acos(float) of the reference is the C library's acosf; numpy's float32 arccos is its own vector routine and differs from it in the
+# last bit for about one argument in five -- enough to flip a greedy choice between near-equal candidates
+_acosf = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6").acosf
+_acosf.argtypes, _acosf.restype = [ctypes.c_float], ctypes.c_float
+
 
 def rotation_geodesic_distance(R1: np.ndarray, R2: np.ndarray) -> float:
-    """acos(clamp((tr(R1 R2^T) - 1) / 2)) in fp32 like the Eigen::Matrix3f original (Utils.cpp:42-47)."""
+    """acos(clamp((tr(R1 R2^T) - 1) / 2)) in fp32 like the Eigen::Matrix3f original (Utils.cpp:42-47): diagonal entry i of
+    R1 R2^T is the dot product of the two i-th rows, each summed left to right in float and then the three of them (no BLAS
+    call whose summation order or FMA use depends on the host; oracle/btba_oracle_keyframes.c sums the same way)."""
     R1 = np.asarray(R1, np.float32)
     R2 = np.asarray(R2, np.float32)
-    tmp = np.float32((np.trace(R1 @ R2.T) - np.float32(1.0)) / 2.0)
+    prod = R1 * R2                                            # float32 products, each rounded once
+    dots = (prod[:, 0] + prod[:, 1]) + prod[:, 2]
+    trace = (dots[0] + dots[1]) + dots[2]
+    tmp = np.float32((trace - np.float32(1.0)) / 2.0)
     tmp = max(min(np.float32(1.0), tmp), np.float32(-1.0))
-    return float(np.arccos(np.float32(tmp)))
+    return float(_acosf(float(tmp)))
 
 
 @dataclass
@@ -62,7 +74,7 @@ class KeyframeMemory:
             return False
         for kf in self.keyframes:
             rot_diff = rotation_geodesic_distance(frame.pose_in_model[:3, :3], kf.pose_in_model[:3, :3])
-            rot_diff = np.float32(rot_diff) * np.float32(180.0) / np.float32(np.pi)
+            rot_diff = np.float32(np.float64(np.float32(rot_diff) * np.float32(180.0)) / np.pi)     # product in float, division in double (:208)
             if rot_diff < self.min_rot_deg:
                 return False
         self.keyframes.append(frame)
@@ -73,7 +85,8 @@ class KeyframeMemory:
         and then repeatedly the keyframe with the SMALLEST summed geodesic rotation distance to the
         already chosen set.  (The reference keeps the chosen set in a std::set of shared_ptr, i.e. in
         pointer order; the result is sorted by frame id afterwards -- Bundler.cpp:286 -- so only the
-        summation order of cum_dist depends on it; here the set is iterated in insertion order.)"""
+        summation order of cum_dist depends on it; here the set is iterated in frame-id order: what an
+        allocator that hands out ascending addresses gives the reference.)"""
         chosen = [newframe]
         if len(self.keyframes) + len(chosen) <= self.max_BA_frames:
             for kf in self.keyframes:
@@ -88,7 +101,7 @@ class KeyframeMemory:
                 if kf in chosen:
                     continue
                 cum = np.float32(0)
-                for f in chosen:
+                for f in sorted(chosen, key=lambda f: f.id):
                     cum = np.float32(cum + np.float32(rotation_geodesic_distance(kf.pose_in_model[:3, :3], f.pose_in_model[:3, :3])))
                 if cum < best:
                     best, best_kf = cum, kf

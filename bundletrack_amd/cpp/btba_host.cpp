@@ -159,8 +159,15 @@ std::string formatPoseTxt(const Matrix4f &M)
 
 float rotationGeodesicDistance(const Matrix4f &A, const Matrix4f &B)
 {
-    float tr = 0.0f;                                            // trace(R1 R2^T) = sum_ij R1_ij R2_ij
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) tr += A(i, j) * B(i, j);
+    // trace(R1 R2^T): diagonal entry i is the dot product of row i of R1 with row i of R2, each summed left to right and then the
+    // three of them (the shape of Eigen's coefficient-based 3 x 3 product; oracle/btba_oracle_keyframes.c sums the same way)
+    float tr = 0.0f;
+    for (int i = 0; i < 3; i++) {
+        float dot = A(i, 0) * B(i, 0);
+        dot += A(i, 1) * B(i, 1);
+        dot += A(i, 2) * B(i, 2);
+        tr = i == 0 ? dot : tr + dot;
+    }
     float tmp = (tr - 1.0f) / 2.0f;
     tmp = std::max(std::min(1.0f, tmp), -1.0f);
     return std::acos(tmp);
@@ -201,7 +208,7 @@ bool KeyframeMemory::checkAndAddKeyframe(const std::shared_ptr<Frame> &frame)
     if (frame->_n_keypts < yml->keyframe_min_feat_num) return false;
     for (const auto &kf : _keyframes) {
         float rot_diff = rotationGeodesicDistance(frame->_pose_in_model, kf->_pose_in_model);
-        rot_diff = rot_diff * 180.0f / (float)M_PI;
+        rot_diff = (float)((double)(rot_diff * 180.0f) / M_PI);          // rot_diff*180/M_PI: the product in float, the division in double, stored as float (:208)
         if (rot_diff < yml->keyframe_min_rot) return false;
     }
     _keyframes.push_back(frame);
@@ -210,15 +217,18 @@ bool KeyframeMemory::checkAndAddKeyframe(const std::shared_ptr<Frame> &frame)
 
 std::vector<std::shared_ptr<Frame>> KeyframeMemory::selectKeyFramesForBA(const std::shared_ptr<Frame> &newframe)
 {
-    std::vector<std::shared_ptr<Frame>> frames = { newframe };       // insertion order (the reference: a std::set in pointer order)
-    auto has = [&](const std::shared_ptr<Frame> &f) { return std::find(frames.begin(), frames.end(), f) != frames.end(); };
+    // The reference keeps the chosen set in a std::set<std::shared_ptr<Frame>>: ordered by the frames' ADDRESSES, which decides the order cum_dist is
+    // summed in and nothing else (Bundler.cpp:252-256; the caller sorts by id, :286).  Here the set is ordered by frame id -- what an allocator that
+    // hands out ascending addresses gives the reference -- so a selection does not depend on where the heap put a frame.
     auto by_id = [](const std::shared_ptr<Frame> &a, const std::shared_ptr<Frame> &b) { return a->_id < b->_id; };
+    std::vector<std::shared_ptr<Frame>> frames = { newframe };
+    auto has = [&](const std::shared_ptr<Frame> &f) { return std::find(frames.begin(), frames.end(), f) != frames.end(); };
+    auto insert = [&](const std::shared_ptr<Frame> &f) { if (!has(f)) frames.insert(std::upper_bound(frames.begin(), frames.end(), f, by_id), f); };
     if ((int)(_keyframes.size() + frames.size()) <= yml->max_BA_frames) {
-        for (const auto &kf : _keyframes) if (!has(kf)) frames.push_back(kf);
-        std::sort(frames.begin(), frames.end(), by_id);
+        for (const auto &kf : _keyframes) insert(kf);
         return frames;
     }
-    if (!has(_keyframes[0])) frames.push_back(_keyframes[0]);
+    insert(_keyframes[0]);
     while ((int)frames.size() < yml->max_BA_frames) {                // "greedy_rot"
         float best_dist = std::numeric_limits<float>::max();
         std::shared_ptr<Frame> best_kf;
@@ -229,9 +239,8 @@ std::vector<std::shared_ptr<Frame>> KeyframeMemory::selectKeyFramesForBA(const s
             if (cum_dist < best_dist) { best_dist = cum_dist; best_kf = kf; }
         }
         if (!best_kf) break;
-        frames.push_back(best_kf);
+        insert(best_kf);
     }
-    std::sort(frames.begin(), frames.end(), by_id);
     return frames;
 }
 

@@ -56,7 +56,7 @@ class OrcTrace(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
-    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("btba_oracle.c", "btba_oracle_ransac.c", "xorwow.h", "Makefile"))
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("btba_oracle.c", "btba_oracle_ransac.c", "btba_oracle_keyframes.c", "xorwow.h", "Makefile"))
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
@@ -384,3 +384,40 @@ def xorwow_matrix(which: int, k: int) -> np.ndarray:
     f.restype = None
     f(which, k, m.ctypes.data)
     return m
+
+
+# ---- keyframe memory (oracle/btba_oracle_keyframes.c: Bundler.cpp:185-274, Utils.cpp:42-47; parity unpinned, see its header) ----
+def rotation_geodesic_distance(pose1, pose2) -> float:
+    f = lib().orc_rotation_geodesic_distance
+    f.argtypes = [C.c_void_p, C.c_void_p]
+    f.restype = C.c_float
+    a, b = np.ascontiguousarray(pose1, np.float32).reshape(16), np.ascontiguousarray(pose2, np.float32).reshape(16)
+    return float(f(_p(a), _p(b)))
+
+
+def keyframe_pool(poses, ids=None, status_other=None, n_keypts=None, min_feat_num=0, min_rot_deg=10.0):
+    """checkAndAddKeyframe over frames 0 .. M-1 in order: (added flags [M] bool, keyframe indices)."""
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    M = len(poses)
+    f = lib().orc_check_and_add_keyframe
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    f.restype = C.c_int
+    kf, n = np.zeros(M + 1, np.int32), np.zeros(1, np.int32)
+    added = np.zeros(M, bool)
+    for k in range(M):
+        added[k] = bool(f(_p(poses), k, k if ids is None else int(ids[k]), 1 if status_other is None else int(status_other[k]),
+                          100 if n_keypts is None else int(n_keypts[k]), min_feat_num, min_rot_deg, _p(kf), _p(n)))
+    return added, kf[: n[0]].copy()
+
+
+def select_keyframes_for_ba(poses, newframe, keyframes, max_BA_frames, addr_rank=None):
+    """selectKeyFramesForBA: the chosen frame indices in the reference's set order (addr_rank: rank of every frame's address, None: index order)."""
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    keyframes = np.ascontiguousarray(keyframes, np.int32)
+    f = lib().orc_select_keyframes_for_ba
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    f.restype = C.c_int
+    out = np.zeros(len(keyframes) + 2, np.int32)
+    rank = None if addr_rank is None else np.ascontiguousarray(addr_rank, np.int32)
+    n = f(_p(poses), int(newframe), _p(keyframes), len(keyframes), int(max_BA_frames), None if rank is None else _p(rank), _p(out))
+    return out[:n].copy()

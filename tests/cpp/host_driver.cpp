@@ -1,7 +1,7 @@
 // host_driver.cpp -- test driver for the C++ host layer (bundletrack_amd/cpp/btba_host.*): what Bundler.cpp does with
 // OptimizerGpu, on a problem dumped by the Python tests.  Built by __graft_entry__.build().
 //   host_driver ba <problem.bin> <poses_out.bin>        window -> marshalWindow -> OptimizerGpu::optimizeFrames (GPU)
-//   host_driver keyframes <poses.bin> <ids_out.bin>     checkAndAddKeyframe over a pose sequence + selectKeyFramesForBA (CPU)
+//   host_driver keyframes <poses.bin> <ids_out.bin>     checkAndAddKeyframe over a pose sequence + selectKeyFramesForBA (CPU); input: int32 M, max_BA_frames; float min_rot; M poses
 //   host_driver problem <dump.btba> <copy_out.btba>     loadProblem -> saveProblem round trip + a one-line summary (CPU)
 //   host_driver kabsch <pairs.bin> <poses_out.bin>      solveRigidTransformBetweenPoints over a list of point-set pairs (CPU)
 //   host_driver posetxt <poses.bin> <out.txt>           formatPoseTxt of every 4x4 (row-major floats) in the file (CPU)
@@ -104,6 +104,9 @@ static int run_keyframes(const char *in, const char *out)
     const int M = hdr[0];
     auto yml = std::make_shared<Config>();
     yml->max_BA_frames = hdr[1];
+    float min_rot;
+    rd(f, &min_rot, 1);
+    yml->keyframe_min_rot = min_rot;
     std::vector<float> P(16 * (size_t)M);
     rd(f, P.data(), P.size());
     KeyframeMemory mem(yml);

@@ -12,9 +12,7 @@ from bundletrack_amd.bundler import FrameRef, KeyframeMemory
 
 
 def driver():
-    if not os.path.exists(_lib.HOST_DRIVER):
-        _lib.build_host_cpp()
-    return _lib.HOST_DRIVER
+    return _lib.build_host_cpp()          # (re)built when a source is newer
 
 
 def test_cpp_keyframe_memory_matches_python(tmp_path):
@@ -25,7 +23,7 @@ def test_cpp_keyframe_memory_matches_python(tmp_path):
     for max_ba in (6, 15):
         inp, out = str(tmp_path / "kf_in.bin"), str(tmp_path / "kf_out.bin")
         with open(inp, "wb") as f:
-            f.write(np.array([len(poses), max_ba], np.int32).tobytes()); f.write(poses.tobytes())
+            f.write(np.array([len(poses), max_ba], np.int32).tobytes()); f.write(np.float32(10.0).tobytes()); f.write(poses.tobytes())
         subprocess.run([driver(), "keyframes", inp, out], check=True, timeout=60)
         res = np.fromfile(out, np.int32)
         split = int(np.nonzero(res == -1)[0][0])
