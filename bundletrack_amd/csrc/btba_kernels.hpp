@@ -1138,7 +1138,13 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     // (Round 2: work table -> poses / ranges -> hull test -> list, four dependent round trips, 7.2 of a workgroup's 39 us.)
     int fi, fj, p;                                        // fi = target, fj = source
     dense_work_item(D, q, fi, fj, p);
+#ifdef BTBA_DEV_ALIAS
+    // timing probe (profiles/r06/l2_alias_probe.json): every instance reads the frames of instance b % BTBA_DEV_ALIAS -- with a batch of identical instances the
+    // same bits, and a frame working set BTBA_DEV_ALIAS instances wide instead of the batch: what would an L2 that held every tap be worth?
+    const size_t fb = (size_t)(b % BTBA_DEV_ALIAS) * D.n_frames;
+#else
     const size_t fb = (size_t)b * D.n_frames;
+#endif
     const size_t slot_t = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fi));
     const size_t slot_s = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fj));
     const unsigned pb = (unsigned)b * (unsigned)D.pose_stride;
@@ -1447,7 +1453,15 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
             // (the lane offset goes through an opaque copy: seen as loop-invariant, `frame base + lane offset` is hoisted as a 64-bit VECTOR address and the block
             // offset becomes a 64-bit vector add per trip)
             asm volatile("" : "+v"(lane_off16));          // (in place: no copy)
+#ifdef BTBA_SRC_NT
+            {   // developer experiment (profiles/r06/l2_alias_probe.json): the source block as a non-temporal load -- read once per item, it need not displace tap lines
+                typedef float btba_nt4 __attribute__((ext_vector_type(4)));
+                const btba_nt4 v = __builtin_nontemporal_load(reinterpret_cast<const btba_nt4 *>(reinterpret_cast<const char *>(zn_s) + (size_t)(16u * ((code >> 16) * 8u * (unsigned)D.width + (code & 0xFFFFu) * 8u)) + (size_t)lane_off16));
+                zs = make_float4(v.x, v.y, v.z, v.w);
+            }
+#else
             zs = gather16_imm<0>(reinterpret_cast<const char *>(zn_s) + (size_t)(16u * ((code >> 16) * 8u * (unsigned)D.width + (code & 0xFFFFu) * 8u)), lane_off16);
+#endif
 #else
             zs = gather16(zn_s, 16u * ((code >> 16) * 8u * (unsigned)D.width + (code & 0xFFFFu) * 8u + lane_px));
 #endif

@@ -18,7 +18,7 @@ def child(lib):
     out = {"lib": os.path.basename(lib)}
     for tag, inst in data.items():
         B = int(os.environ.get("AB_B", "32"))
-        pick = [inst[b % len(inst)] for b in range(B)]
+        pick = [inst[(b % len(inst)) % int(os.environ.get("AB_DISTINCT", "8"))] for b in range(B)]        # AB_DISTINCT=1: a batch of identical instances (l2 alias probe)
         bs = BatchSolver(ws)
         bs.params.flags |= (0 if os.environ.get("AB_NO_TIMING") else _lib.FLAG_TIME_KERNELS) | (_lib.FLAG_COMPACTION if tag == "masked" else 0) | int(os.environ.get("AB_FLAGS", "0"))
         bs.params.dense_tiles = int(os.environ.get("BTBA_BENCH_TILES", "0"))
