@@ -1010,6 +1010,9 @@ template <int IMM> __device__ __forceinline__ float4 gather16_imm(const char *ba
 #ifndef BTBA_LIST_LANES
 #define BTBA_LIST_LANES 1
 #endif
+#ifndef BTBA_PK_SGPR
+#define BTBA_PK_SGPR 0       // round 6: the pose / intrinsics operands of the pixel loop as SGPR PAIRS of packed fp32 instructions (see the pixel lambda)
+#endif
 // LDS byte address of a pointer into the workgroup's LDS, and two consecutive floats at an absolute LDS byte address: the table base rides in the fp32 address
 // arithmetic (exact below 2^24) instead of costing a vector add behind every float -> int conversion
 __device__ __forceinline__ unsigned lds_address(const void *p) { return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)p; }
@@ -1272,6 +1275,12 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     btba_f4v pv0 = (btba_f4v){ C.R[0], C.R[1], C.R[2], C.t[0] }, pv1 = (btba_f4v){ C.R[3], C.R[4], C.R[5], C.t[1] }, pv2 = (btba_f4v){ C.R[6], C.R[7], C.R[8], C.t[2] }, pvk = (btba_f4v){ D.fx, D.fy, D.cx, D.cy };
     asm volatile("" : "+v"(pv0), "+v"(pv1), "+v"(pv2), "+v"(pvk));
 #endif
+#if BTBA_PK_SGPR
+    typedef float pk2 __attribute__((ext_vector_type(2)));
+    auto sgpr_pair = [](float lo, float hi) { return (unsigned long long)__float_as_uint(lo) | ((unsigned long long)__float_as_uint(hi) << 32); };
+    const unsigned long long pk_t01 = sgpr_pair(C.t[0], C.t[1]), pk_fxfy = sgpr_pair(sgpr(D.fx), sgpr(D.fy)), pk_cxcy = sgpr_pair(sgpr(D.cx), sgpr(D.cy));
+    const unsigned long long pk_r0 = sgpr_pair(C.R[0], C.R[3]), pk_r1 = sgpr_pair(C.R[1], C.R[4]), pk_r2 = sgpr_pair(C.R[2], C.R[5]);
+#endif
     const char *tap_row0 = reinterpret_cast<const char *>(zn_t), *tap_row1 = tap_row0 + C.row16;
     const float lut_addr_f = (float)lds_address(lut), ybase4_abs = C.ybase4 + lut_addr_f;
     auto pixel = [&](const float4 &zs, unsigned ox, unsigned oy) {
@@ -1298,6 +1307,26 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         // does not insert the wait state gfx950 needs between a transcendental and a VALU use of its result -- round 6's first build of this switch read a
         // stale reciprocal now and then: non-deterministic poses, 2e-4 off, caught by tests/test_cpp_bundler.py and scripts/r06/determinism.py)
         const float u = __builtin_fmaf(qx * PK.x, rqz, PK.z), v = __builtin_fmaf(qy * PK.y, rqz, PK.w);
+#elif BTBA_PK_SGPR
+        // A VALU instruction with a scalar-register source issues at half rate (4 cycles); v_pk_fma_f32 / v_pk_mul_f32 take 4 cycles for TWO lanes of work with or
+        // without an SGPR-pair source (profiles/r02/valu_calibration.md, rows `x:`).  So the x / y halves of the transform, the projection and the normal rotation go
+        // through packed instructions whose wave-uniform operand is an aligned SGPR pair: 16 scalar-operand instructions (64 issue cycles) become 7 packed ones + a
+        // move (30) and three plain ones for the z row.  No VGPR and no LDS traffic added -- what BTBA_POSE_VGPR / BTBA_POSE_LDS paid for the same saving.
+        // Same operations on the same values in the same order (mul, fma, fma -- the contraction the compiler chose): same bits.
+        const pk2 zs_xy = (pk2){ zs.x, zs.y }, zs_zw = (pk2){ zs.z, zs.w };      // (d, n.x), (n.y, n.z): sub-registers of the stream load's result
+        const pk2 sum_xy = (pk2){ ra.x + rb.x, ra.y + rb.y };
+        pk2 q_xy;
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(q_xy) : "v"(sum_xy), "v"(zs_xy), "s"(pk_t01));              // (sum.x, sum.y) * d + (t0, t1)
+        const float qx = q_xy.x, qy = q_xy.y, qz = (ra.z + rb.z) * d + C.t[2];
+        const float rqz = fast_rcp(qz);
+        pk2 qf;
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(qf) : "v"(q_xy), "s"(pk_fxfy));                                                    // (qx fx, qy fy)
+        // (rqz, rqz) is made by the compiler: the move it places behind v_rcp_f32 is the wait state gfx950 needs between a transcendental and a use of its result,
+        // which an inline-asm consumer directly behind the reciprocal would not get -- see the lesson next to fma_nd)
+        const pk2 rq2 = (pk2){ rqz, rqz };
+        pk2 uv;
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(uv) : "v"(qf), "v"(rq2), "s"(pk_cxcy));                                        // * rqz + (cx, cy)
+        const float u = uv.x, v = uv.y;
 #else
         const float qx = (ra.x + rb.x) * d + C.t[0], qy = (ra.y + rb.y) * d + C.t[1], qz = (ra.z + rb.z) * d + C.t[2];
         const float rqz = fast_rcp(qz);
@@ -1321,6 +1350,13 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const float nqx = fma_nd(P0.z, zs.w, fma_nd(P0.y, zs.z, P0.x * zs.y));
         const float nqy = fma_nd(P1.z, zs.w, fma_nd(P1.y, zs.z, P1.x * zs.y));
         const float nqz = fma_nd(P2.z, zs.w, fma_nd(P2.y, zs.z, P2.x * zs.y));
+#elif BTBA_PK_SGPR
+        pk2 nq_xy;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(nq_xy) : "s"(pk_r0), "v"(zs_xy));                      // (R00, R10) n.x
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(nq_xy) : "s"(pk_r1), "v"(zs_zw));                             // + (R01, R11) n.y
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(nq_xy) : "s"(pk_r2), "v"(zs_zw));              // + (R02, R12) n.z
+        const float nqx = nq_xy.x, nqy = nq_xy.y;
+        const float nqz = C.R[6] * zs.y + C.R[7] * zs.z + C.R[8] * zs.w;
 #else
         const float nqx = C.R[0] * zs.y + C.R[1] * zs.z + C.R[2] * zs.w;
         const float nqy = C.R[3] * zs.y + C.R[4] * zs.z + C.R[5] * zs.w;
