@@ -1281,6 +1281,13 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     const unsigned long long pk_t01 = sgpr_pair(C.t[0], C.t[1]), pk_fxfy = sgpr_pair(sgpr(D.fx), sgpr(D.fy)), pk_cxcy = sgpr_pair(sgpr(D.cx), sgpr(D.cy));
     const unsigned long long pk_r0 = sgpr_pair(C.R[0], C.R[3]), pk_r1 = sgpr_pair(C.R[1], C.R[4]), pk_r2 = sgpr_pair(C.R[2], C.R[5]);
 #endif
+#ifdef BTBA_PROBE_EXTRA_TAPS
+    __shared__ float4 probe_sink[kBlock + 4];      // (+ 4: the instruction offset of an LDS-direct load moves its LDS destination as well -- 48 bytes past the last wave's window)
+    const unsigned probe_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_address(probe_sink) + 1024u * (tid >> 6)));
+#endif
+#ifdef BTBA_PROBE_EXTRA_FMA
+    float probe_zero = sgpr(D.depth_min * 0.0f);          // a wave-uniform 0 the compiler cannot fold: every probe FMA adds wa_r * 0 (21 per trip, scalar operand: 4 issue cycles each)
+#endif
     const char *tap_row0 = reinterpret_cast<const char *>(zn_t), *tap_row1 = tap_row0 + C.row16;
     const float lut_addr_f = (float)lds_address(lut), ybase4_abs = C.ybase4 + lut_addr_f;
     auto pixel = [&](const float4 &zs, unsigned ox, unsigned oy) {
@@ -1370,6 +1377,16 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         // one computed byte offset for the 2 x 2 block: the second row's base is a scalar add (wave-uniform), the + 16 the load's immediate offset field
         const unsigned o00 = (unsigned)(fy0 * C.w16 + 16.0f * fx0);                             // byte offset, fp32-exact below 2^24
         const float4 z00 = gather16_imm<0>(tap_row0, o00), z10 = gather16_imm<16>(tap_row0, o00), z01 = gather16_imm<0>(tap_row1, o00), z11 = gather16_imm<16>(tap_row1, o00);
+#ifdef BTBA_PROBE_EXTRA_TAPS      // sensitivity probe, SAME results (profiles/r06/bound_probes.json): BTBA_PROBE_EXTRA_TAPS (2 or 4) more 16-byte-per-lane gathers per trip from the taps' own
+        {                             // lines, as LDS-direct loads into a sink: the texture addresser's work without a single VGPR (the kernel sits at its 80-register cap)
+            unsigned keep_m0;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 offset:32\n\tglobal_load_lds_dwordx4 %1, %4 offset:32\n\t"
+#if BTBA_PROBE_EXTRA_TAPS >= 4
+                         "global_load_lds_dwordx4 %1, %3 offset:48\n\tglobal_load_lds_dwordx4 %1, %4 offset:48\n\t"
+#endif
+                         "s_mov_b32 m0, %0" : "=&s"(keep_m0) : "v"(o00), "s"(probe_lds), "s"(tap_row0), "s"(tap_row1) : "memory");
+        }
+#endif
 #else
         const unsigned o00 = (unsigned)(fy0 * C.w16 + 16.0f * fx0), o01 = o00 + C.row16;      // byte offsets, fp32-exact below 2^24
         const float4 z00 = gather16(zn_t, o00), z10 = gather16(zn_t, o00 + 16u), z01 = gather16(zn_t, o01), z11 = gather16(zn_t, o01 + 16u);
@@ -1434,10 +1451,19 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         for (int r = 0; r < 6; r++) { pr[r] = (f2v){ wgt * a[r], a[r] }; asm volatile("" : "+v"(pr[r])); }
         f2v rr = (f2v){ wgt, res };
         asm volatile("" : "+v"(rr));
+
 #pragma unroll
         for (int r = 0; r < 6; r++) {
 #pragma unroll
-            for (int c = r; c < 6; c++) acc[k++] += pr[r].x * pr[c].y;
+            for (int c = r; c < 6; c++) {
+#ifdef BTBA_PROBE_EXTRA_FMA      // sensitivity probe, SAME results: every accumulate of the 6 x 6 triangle followed by a second FMA that adds wa_r * 0 (21 more full-rate FMAs per trip)
+                acc[k] += pr[r].x * pr[c].y;
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(pr[r].x), "s"(probe_zero));
+                k++;
+#else
+                acc[k++] += pr[r].x * pr[c].y;
+#endif
+            }
             acc[21 + r] += pr[r].x * rr.y;
         }
         acc[27] += masked(1.0f);
