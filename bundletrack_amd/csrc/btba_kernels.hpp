@@ -1010,6 +1010,9 @@ template <int IMM> __device__ __forceinline__ float4 gather16_imm(const char *ba
 #ifndef BTBA_LIST_LANES
 #define BTBA_LIST_LANES 1
 #endif
+#ifndef BTBA_TAPS_EXEC
+#define BTBA_TAPS_EXEC 1     // round 6 (profiles/r06/bound_probes.json, taps_exec.json): the four tap gathers only for lanes that passed the in-image / source-depth tests; same bits, -1.5 % on the launch
+#endif
 #ifndef BTBA_PK_SGPR
 #define BTBA_PK_SGPR 0       // round 6: the pose / intrinsics operands of the pixel loop as SGPR PAIRS of packed fp32 instructions (see the pixel lambda)
 #endif
@@ -1376,7 +1379,16 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
 #if BTBA_TAP_BASES
         // one computed byte offset for the 2 x 2 block: the second row's base is a scalar add (wave-uniform), the + 16 the load's immediate offset field
         const unsigned o00 = (unsigned)(fy0 * C.w16 + 16.0f * fx0);                             // byte offset, fp32-exact below 2^24
+#if BTBA_TAPS_EXEC      // lanes that already failed the in-image / source-depth tests (8.8 % in the trips that go on, clustered along block edges) issue no taps: the texture
+        float4 z00, z10, z01, z11;      // addresser's service time is exposed almost in full (bound_probes.json) and follows the active lanes.  Their registers stay undefined and are never
+                                        // used: `ok` contains `valid`, and `keep` zeroes everything a rejected lane contributes (AND, NaN-safe).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wconditional-uninitialized"
+        if (valid) { z00 = gather16_imm<0>(tap_row0, o00); z10 = gather16_imm<16>(tap_row0, o00); z01 = gather16_imm<0>(tap_row1, o00); z11 = gather16_imm<16>(tap_row1, o00); }
+#pragma clang diagnostic pop
+#else
         const float4 z00 = gather16_imm<0>(tap_row0, o00), z10 = gather16_imm<16>(tap_row0, o00), z01 = gather16_imm<0>(tap_row1, o00), z11 = gather16_imm<16>(tap_row1, o00);
+#endif
 #ifdef BTBA_PROBE_EXTRA_TAPS      // sensitivity probe, SAME results (profiles/r06/bound_probes.json): BTBA_PROBE_EXTRA_TAPS (2 or 4) more 16-byte-per-lane gathers per trip from the taps' own
         {                             // lines, as LDS-direct loads into a sink: the texture addresser's work without a single VGPR (the kernel sits at its 80-register cap)
             unsigned keep_m0;
