@@ -1013,9 +1013,6 @@ template <int IMM> __device__ __forceinline__ float4 gather16_imm(const char *ba
 #ifndef BTBA_TAPS_EXEC
 #define BTBA_TAPS_EXEC 1     // round 6 (profiles/r06/bound_probes.json, taps_exec.json): the four tap gathers only for lanes that passed the in-image / source-depth tests; same bits, -1.5 % on the launch
 #endif
-#ifndef BTBA_PK_SGPR
-#define BTBA_PK_SGPR 0       // round 6: the pose / intrinsics operands of the pixel loop as SGPR PAIRS of packed fp32 instructions (see the pixel lambda)
-#endif
 // LDS byte address of a pointer into the workgroup's LDS, and two consecutive floats at an absolute LDS byte address: the table base rides in the fp32 address
 // arithmetic (exact below 2^24) instead of costing a vector add behind every float -> int conversion
 __device__ __forceinline__ unsigned lds_address(const void *p) { return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)p; }
@@ -1144,13 +1141,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     // (Round 2: work table -> poses / ranges -> hull test -> list, four dependent round trips, 7.2 of a workgroup's 39 us.)
     int fi, fj, p;                                        // fi = target, fj = source
     dense_work_item(D, q, fi, fj, p);
-#ifdef BTBA_DEV_ALIAS
-    // timing probe (profiles/r06/l2_alias_probe.json): every instance reads the frames of instance b % BTBA_DEV_ALIAS -- with a batch of identical instances the
-    // same bits, and a frame working set BTBA_DEV_ALIAS instances wide instead of the batch: what would an L2 that held every tap be worth?
-    const size_t fb = (size_t)(b % BTBA_DEV_ALIAS) * D.n_frames;
-#else
     const size_t fb = (size_t)b * D.n_frames;
-#endif
     const size_t slot_t = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fi));
     const size_t slot_s = (size_t)__builtin_amdgcn_readfirstlane((int)frame_slot_of(D, fb + fj));
     const unsigned pb = (unsigned)b * (unsigned)D.pose_stride;
@@ -1278,19 +1269,6 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
     btba_f4v pv0 = (btba_f4v){ C.R[0], C.R[1], C.R[2], C.t[0] }, pv1 = (btba_f4v){ C.R[3], C.R[4], C.R[5], C.t[1] }, pv2 = (btba_f4v){ C.R[6], C.R[7], C.R[8], C.t[2] }, pvk = (btba_f4v){ D.fx, D.fy, D.cx, D.cy };
     asm volatile("" : "+v"(pv0), "+v"(pv1), "+v"(pv2), "+v"(pvk));
 #endif
-#if BTBA_PK_SGPR
-    typedef float pk2 __attribute__((ext_vector_type(2)));
-    auto sgpr_pair = [](float lo, float hi) { return (unsigned long long)__float_as_uint(lo) | ((unsigned long long)__float_as_uint(hi) << 32); };
-    const unsigned long long pk_t01 = sgpr_pair(C.t[0], C.t[1]), pk_fxfy = sgpr_pair(sgpr(D.fx), sgpr(D.fy)), pk_cxcy = sgpr_pair(sgpr(D.cx), sgpr(D.cy));
-    const unsigned long long pk_r0 = sgpr_pair(C.R[0], C.R[3]), pk_r1 = sgpr_pair(C.R[1], C.R[4]), pk_r2 = sgpr_pair(C.R[2], C.R[5]);
-#endif
-#ifdef BTBA_PROBE_EXTRA_TAPS
-    __shared__ float4 probe_sink[kBlock + 4];      // (+ 4: the instruction offset of an LDS-direct load moves its LDS destination as well -- 48 bytes past the last wave's window)
-    const unsigned probe_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_address(probe_sink) + 1024u * (tid >> 6)));
-#endif
-#ifdef BTBA_PROBE_EXTRA_FMA
-    float probe_zero = sgpr(D.depth_min * 0.0f);          // a wave-uniform 0 the compiler cannot fold: every probe FMA adds wa_r * 0 (21 per trip, scalar operand: 4 issue cycles each)
-#endif
     const char *tap_row0 = reinterpret_cast<const char *>(zn_t), *tap_row1 = tap_row0 + C.row16;
     const float lut_addr_f = (float)lds_address(lut), ybase4_abs = C.ybase4 + lut_addr_f;
     auto pixel = [&](const float4 &zs, unsigned ox, unsigned oy) {
@@ -1317,26 +1295,6 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         // does not insert the wait state gfx950 needs between a transcendental and a VALU use of its result -- round 6's first build of this switch read a
         // stale reciprocal now and then: non-deterministic poses, 2e-4 off, caught by tests/test_cpp_bundler.py and scripts/r06/determinism.py)
         const float u = __builtin_fmaf(qx * PK.x, rqz, PK.z), v = __builtin_fmaf(qy * PK.y, rqz, PK.w);
-#elif BTBA_PK_SGPR
-        // A VALU instruction with a scalar-register source issues at half rate (4 cycles); v_pk_fma_f32 / v_pk_mul_f32 take 4 cycles for TWO lanes of work with or
-        // without an SGPR-pair source (profiles/r02/valu_calibration.md, rows `x:`).  So the x / y halves of the transform, the projection and the normal rotation go
-        // through packed instructions whose wave-uniform operand is an aligned SGPR pair: 16 scalar-operand instructions (64 issue cycles) become 7 packed ones + a
-        // move (30) and three plain ones for the z row.  No VGPR and no LDS traffic added -- what BTBA_POSE_VGPR / BTBA_POSE_LDS paid for the same saving.
-        // Same operations on the same values in the same order (mul, fma, fma -- the contraction the compiler chose): same bits.
-        const pk2 zs_xy = (pk2){ zs.x, zs.y }, zs_zw = (pk2){ zs.z, zs.w };      // (d, n.x), (n.y, n.z): sub-registers of the stream load's result
-        const pk2 sum_xy = (pk2){ ra.x + rb.x, ra.y + rb.y };
-        pk2 q_xy;
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(q_xy) : "v"(sum_xy), "v"(zs_xy), "s"(pk_t01));              // (sum.x, sum.y) * d + (t0, t1)
-        const float qx = q_xy.x, qy = q_xy.y, qz = (ra.z + rb.z) * d + C.t[2];
-        const float rqz = fast_rcp(qz);
-        pk2 qf;
-        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(qf) : "v"(q_xy), "s"(pk_fxfy));                                                    // (qx fx, qy fy)
-        // (rqz, rqz) is made by the compiler: the move it places behind v_rcp_f32 is the wait state gfx950 needs between a transcendental and a use of its result,
-        // which an inline-asm consumer directly behind the reciprocal would not get -- see the lesson next to fma_nd)
-        const pk2 rq2 = (pk2){ rqz, rqz };
-        pk2 uv;
-        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(uv) : "v"(qf), "v"(rq2), "s"(pk_cxcy));                                        // * rqz + (cx, cy)
-        const float u = uv.x, v = uv.y;
 #else
         const float qx = (ra.x + rb.x) * d + C.t[0], qy = (ra.y + rb.y) * d + C.t[1], qz = (ra.z + rb.z) * d + C.t[2];
         const float rqz = fast_rcp(qz);
@@ -1360,13 +1318,6 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         const float nqx = fma_nd(P0.z, zs.w, fma_nd(P0.y, zs.z, P0.x * zs.y));
         const float nqy = fma_nd(P1.z, zs.w, fma_nd(P1.y, zs.z, P1.x * zs.y));
         const float nqz = fma_nd(P2.z, zs.w, fma_nd(P2.y, zs.z, P2.x * zs.y));
-#elif BTBA_PK_SGPR
-        pk2 nq_xy;
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(nq_xy) : "s"(pk_r0), "v"(zs_xy));                      // (R00, R10) n.x
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(nq_xy) : "s"(pk_r1), "v"(zs_zw));                             // + (R01, R11) n.y
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(nq_xy) : "s"(pk_r2), "v"(zs_zw));              // + (R02, R12) n.z
-        const float nqx = nq_xy.x, nqy = nq_xy.y;
-        const float nqz = C.R[6] * zs.y + C.R[7] * zs.z + C.R[8] * zs.w;
 #else
         const float nqx = C.R[0] * zs.y + C.R[1] * zs.z + C.R[2] * zs.w;
         const float nqy = C.R[3] * zs.y + C.R[4] * zs.z + C.R[5] * zs.w;
@@ -1379,25 +1330,18 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
 #if BTBA_TAP_BASES
         // one computed byte offset for the 2 x 2 block: the second row's base is a scalar add (wave-uniform), the + 16 the load's immediate offset field
         const unsigned o00 = (unsigned)(fy0 * C.w16 + 16.0f * fx0);                             // byte offset, fp32-exact below 2^24
-#if BTBA_TAPS_EXEC      // lanes that already failed the in-image / source-depth tests (8.8 % in the trips that go on, clustered along block edges) issue no taps: the texture
-        float4 z00, z10, z01, z11;      // addresser's service time is exposed almost in full (bound_probes.json) and follows the active lanes.  Their registers stay undefined and are never
-                                        // used: `ok` contains `valid`, and `keep` zeroes everything a rejected lane contributes (AND, NaN-safe).
+#if BTBA_TAPS_EXEC
+        // Lanes that already failed the in-image / source-depth tests (8.8 % in the trips that go on, clustered along block edges: profiles/r06/sweep_census.json) issue no
+        // taps.  The texture addresser's service time per gather is exposed almost in full (profiles/r06/bound_probes.json: one more 16-byte gather per trip = +13.4 us
+        // per launch, linear) and it skips idle quads.  The registers of those lanes stay undefined and are never used: `ok` contains `valid`, and `keep` zeroes
+        // everything a rejected lane contributes (an AND: NaN-safe).
+        float4 z00, z10, z01, z11;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wconditional-uninitialized"
         if (valid) { z00 = gather16_imm<0>(tap_row0, o00); z10 = gather16_imm<16>(tap_row0, o00); z01 = gather16_imm<0>(tap_row1, o00); z11 = gather16_imm<16>(tap_row1, o00); }
 #pragma clang diagnostic pop
 #else
         const float4 z00 = gather16_imm<0>(tap_row0, o00), z10 = gather16_imm<16>(tap_row0, o00), z01 = gather16_imm<0>(tap_row1, o00), z11 = gather16_imm<16>(tap_row1, o00);
-#endif
-#ifdef BTBA_PROBE_EXTRA_TAPS      // sensitivity probe, SAME results (profiles/r06/bound_probes.json): BTBA_PROBE_EXTRA_TAPS (2 or 4) more 16-byte-per-lane gathers per trip from the taps' own
-        {                             // lines, as LDS-direct loads into a sink: the texture addresser's work without a single VGPR (the kernel sits at its 80-register cap)
-            unsigned keep_m0;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 offset:32\n\tglobal_load_lds_dwordx4 %1, %4 offset:32\n\t"
-#if BTBA_PROBE_EXTRA_TAPS >= 4
-                         "global_load_lds_dwordx4 %1, %3 offset:48\n\tglobal_load_lds_dwordx4 %1, %4 offset:48\n\t"
-#endif
-                         "s_mov_b32 m0, %0" : "=&s"(keep_m0) : "v"(o00), "s"(probe_lds), "s"(tap_row0), "s"(tap_row1) : "memory");
-        }
 #endif
 #else
         const unsigned o00 = (unsigned)(fy0 * C.w16 + 16.0f * fx0), o01 = o00 + C.row16;      // byte offsets, fp32-exact below 2^24
@@ -1463,19 +1407,10 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
         for (int r = 0; r < 6; r++) { pr[r] = (f2v){ wgt * a[r], a[r] }; asm volatile("" : "+v"(pr[r])); }
         f2v rr = (f2v){ wgt, res };
         asm volatile("" : "+v"(rr));
-
 #pragma unroll
         for (int r = 0; r < 6; r++) {
 #pragma unroll
-            for (int c = r; c < 6; c++) {
-#ifdef BTBA_PROBE_EXTRA_FMA      // sensitivity probe, SAME results: every accumulate of the 6 x 6 triangle followed by a second FMA that adds wa_r * 0 (21 more full-rate FMAs per trip)
-                acc[k] += pr[r].x * pr[c].y;
-                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(pr[r].x), "s"(probe_zero));
-                k++;
-#else
-                acc[k++] += pr[r].x * pr[c].y;
-#endif
-            }
+            for (int c = r; c < 6; c++) acc[k++] += pr[r].x * pr[c].y;
             acc[21 + r] += pr[r].x * rr.y;
         }
         acc[27] += masked(1.0f);
@@ -1527,15 +1462,7 @@ __device__ __forceinline__ void dense_block_pinhole(const SolveDims &D, const fl
             // (the lane offset goes through an opaque copy: seen as loop-invariant, `frame base + lane offset` is hoisted as a 64-bit VECTOR address and the block
             // offset becomes a 64-bit vector add per trip)
             asm volatile("" : "+v"(lane_off16));          // (in place: no copy)
-#ifdef BTBA_SRC_NT
-            {   // developer experiment (profiles/r06/l2_alias_probe.json): the source block as a non-temporal load -- read once per item, it need not displace tap lines
-                typedef float btba_nt4 __attribute__((ext_vector_type(4)));
-                const btba_nt4 v = __builtin_nontemporal_load(reinterpret_cast<const btba_nt4 *>(reinterpret_cast<const char *>(zn_s) + (size_t)(16u * ((code >> 16) * 8u * (unsigned)D.width + (code & 0xFFFFu) * 8u)) + (size_t)lane_off16));
-                zs = make_float4(v.x, v.y, v.z, v.w);
-            }
-#else
             zs = gather16_imm<0>(reinterpret_cast<const char *>(zn_s) + (size_t)(16u * ((code >> 16) * 8u * (unsigned)D.width + (code & 0xFFFFu) * 8u)), lane_off16);
-#endif
 #else
             zs = gather16(zn_s, 16u * ((code >> 16) * 8u * (unsigned)D.width + (code & 0xFFFFu) * 8u + lane_px));
 #endif
