@@ -29,6 +29,7 @@ import numpy as np  # noqa: E402
 METRIC = "Gauss-Newton iters/sec (K=15, 2k corr/frame-pair) + achieved HBM GB/s"
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
 VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector peak = dense f32 MFMA peak (64 flop/clk/SIMD, unpacked v_fma_f32; profiles/r02/valu_calibration.md)
+L1_RETURN_PEAK_TBS = 39.3    # vector L1 / texture-addresser return rate: 256 CUs x 64 B per clock x 2.4 GHz; MEASURED, not from the guide: one more 16-byte-per-lane gather per trip adds 15 clocks per wave-trip and CU (profiles/r06/bound_probes.json: 1 KB in 15-16 clocks)
 CONFIGS = {
     "c2": dict(K=10, m=1000, w_dense=0.0, config=2, desc="K=10, 1k corr/pair, feature residuals only"),
     "c3": dict(K=15, m=2000, w_dense=1.0, config=3, desc="K=15, 2k corr/pair, feature + dense point-to-plane ICP + Huber"),
@@ -566,6 +567,14 @@ def main():
                 res["roofline"]["executed"] = {"frac": round(flops_exec / (avg_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4), "achieved": round(flops_exec / (avg_ms * 1e-3) / 1e12, 2),
                                                "walked_pair_pixels_per_launch": int(live_px), "share_of_pair_pixels_walked": round(live_px / (sweeps_per_launch * pair_pixels), 4),
                                                "what": "flops of the blocks the dense sweep walks (counted by the kernel: BTBA_OPT_COUNT_LIVE, one solve) + the sparse items', over the same launch time and peak"}
+                # round 6 (profiles/r06/bound_probes.json): the pixel loop waits on the texture addresser / L1 return path -- one more 16-byte gather per trip costs the
+                # launch 13.4 us, linearly.  Gather bytes of the walked blocks (64 lanes x 5 gathers x 16 B: an upper bound, trips that end early issue one gather and lanes
+                # outside the target none) against the chip's L1 return rate, 256 CUs x 64 B / clock x 2.4 GHz.
+                gather_bytes = 80.0 * live_px
+                res["roofline"]["l1_gather"] = {"achieved_TBps": round(gather_bytes / (avg_ms * 1e-3) / 1e12, 2), "peak_TBps": L1_RETURN_PEAK_TBS,
+                                                "frac": round(gather_bytes / (avg_ms * 1e-3) / 1e12 / L1_RETURN_PEAK_TBS, 4), "gather_bytes_per_launch": int(gather_bytes),
+                                                "what": "walked blocks x 64 lanes x (1 source + 4 tap gathers) x 16 B over the launch time, against 256 CUs x 64 B/clk x 2.4 GHz; "
+                                                        "the pipe whose service time the loop exposes (profiles/r06/bound_probes.json)"}
             if pc and pc.get("valu_busy_frac") is not None:
                 res["roofline"]["valu_issue"] = {"busy_frac": pc["valu_busy_frac"], "cycles_per_instruction": pc.get("valu_cycles_per_inst"),
                                                  "dual_issued_frac": pc.get("valu_dual_issued_frac"), "waves_per_simd": pc.get("waves_per_simd"),
