@@ -5,7 +5,7 @@ sweep's and the system solve's average launch time and a checksum of the poses."
 import json, os, pickle, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-CACHE = "/tmp/ab_instances.pkl"
+CACHE = "/tmp/ab_instances_%s.pkl" % os.environ.get("AB_CONFIG", "c3")          # AB_CONFIG=c4: K = 30, 4 000 correspondences per pair (full frames only)
 
 
 def child(lib):
@@ -23,7 +23,7 @@ def child(lib):
         bs.params.flags |= (0 if os.environ.get("AB_NO_TIMING") else _lib.FLAG_TIME_KERNELS) | (_lib.FLAG_COMPACTION if tag == "masked" else 0) | int(os.environ.get("AB_FLAGS", "0"))
         bs.params.dense_tiles = int(os.environ.get("BTBA_BENCH_TILES", "0"))
         bs.params.reduction_mode = int(os.environ.get("AB_REDUCTION", "0"))
-        corr, offs, mx = bs.pack_correspondences([p["corr"] for p in pick], 15)
+        corr, offs, mx = bs.pack_correspondences([p["corr"] for p in pick], int(pick[0]["poses"].shape[0]))
         zn_d = torch.from_numpy(np.stack([p["zn"] for p in pick])).to(dev)
         corr_d = torch.from_numpy(corr.view(np.uint8).reshape(B, -1, 32)).to(dev); offs_d = torch.from_numpy(offs.astype(np.int32)).to(dev)
         poses0 = torch.from_numpy(np.stack([p["poses"] for p in pick])).to(dev)
@@ -49,9 +49,11 @@ def main():
         return child(sys.argv[2])
     import bench
     os.environ.setdefault("BTBA_BENCH_NPROC", "8")
-    cfg = bench.CONFIGS["c3"]
+    cfg = bench.CONFIGS[os.environ.get("AB_CONFIG", "c3")]
     if not os.path.exists(CACHE):
-        data = {"full": bench.generate_instances(cfg, list(range(8))), "masked": bench.generate_instances(cfg, list(range(8)), masked=True)}
+        data = {"full": bench.generate_instances(cfg, list(range(8)))}
+        if os.environ.get("AB_CONFIG", "c3") == "c3":
+            data["masked"] = bench.generate_instances(cfg, list(range(8)), masked=True)
         pickle.dump(data, open(CACHE, "wb"))
     for spec in sys.argv[1:]:
         lib, *sets = spec.split(":")                       # build/ab/x.so:BTBA_NO_PERSISTENT=1 -- environment of that child only
